@@ -1,0 +1,186 @@
+/*
+ * xdtts.h -- C ABI of libxdtts_hip.so: the MI355X (gfx950) implementation of xd-tts's
+ * mel-spectrogram synthesis + vocoding hot path.
+ *
+ * This is the drop-in boundary.  Every entry point below is what a Rust `extern "C"` block in
+ * the reference's src/tacotron2/mod.rs (and a replacement for the `griffin_lim` crate import at
+ * src/tacotron2/mod.rs:67-68, src/lib.rs:5) would bind; the reference interface each one
+ * replaces is cited as file:line under /root/reference.  INTEGRATION.md shows the Rust shim.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types; all floats are IEEE fp32, ids are i64
+ *   - every fallible call returns xdtts_status (0 = ok); xdtts_last_error() gives a thread-local
+ *     message; no exception or panic crosses this boundary
+ *   - handles are opaque, created by *_load / *_new and destroyed by *_free; one handle is bound
+ *     to one GPU (device_id) and serialises calls on its own HIP stream
+ *   - output buffers returned through `float **` are library-allocated pinned host memory: copy,
+ *     then release with xdtts_free()
+ *   - mel layout across the boundary is the reference's Array2<f32> (80, F), C order
+ *     (src/tacotron2/mod.rs:349-355,430); audio is Vec<f32> (src/lib.rs:141)
+ */
+#ifndef XDTTS_H
+#define XDTTS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t xdtts_status;
+enum {
+  XDTTS_OK = 0,
+  XDTTS_ERR_BAD_ARG = 1,  /* null pointer, bad shape, id out of range */
+  XDTTS_ERR_IO = 2,       /* weight container missing / malformed (anyhow context, mod.rs:249,254,259) */
+  XDTTS_ERR_HIP = 3,      /* HIP runtime error */
+  XDTTS_ERR_OOM = 4,
+  XDTTS_ERR_TOO_LONG = 5, /* a chunk longer than max_chunk: the reference's assert!, mod.rs:363 */
+  XDTTS_ERR_NO_DEVICE = 6 /* no gfx950 device: the product path never falls back to the CPU */
+};
+
+typedef struct xdtts_tacotron2 xdtts_tacotron2;
+typedef struct xdtts_griffinlim xdtts_griffinlim;
+
+/* Decoder options.  Defaults (xdtts_infer_opts_default) are the reference's hard-coded
+ * constants: gate_threshold 0.6 and max_steps 1000 (src/tacotron2/mod.rs:279-280), window 100
+ * (src/tacotron2/mod.rs:363,369-371,399). */
+typedef struct {
+  float gate_threshold;
+  int32_t max_steps;
+  int32_t fixed_steps;   /* 0: stop on the gate (reference behaviour); >0: emit exactly this many
+                            frames per chunk (deterministic work for benchmarks/parity) */
+  int32_t dropout_mode;  /* 0 off; 1 seeded counter-based masks (the exported decoder graph keeps
+                            the prenet's p=0.5 dropout on at inference) */
+  uint32_t dropout_seed;
+  int32_t max_chunk;     /* encoder window; chunks are zero-padded to exactly this length */
+  uint32_t item_base;    /* index of the first chunk in the dropout stream (batch sharding) */
+  uint32_t reserved;
+} xdtts_infer_opts;
+
+void xdtts_infer_opts_default(xdtts_infer_opts *opts);
+
+/* ---- Tacotron2 -------------------------------------------------------------------------- */
+
+/* Tacotron2::load(path) -- src/tacotron2/mod.rs:242-267.  `dir` holds the weight container
+ * `tacotron2.xdtw` (DESIGN.md "weight container"); the ONNX initialiser importer is the next
+ * scope row. */
+xdtts_status xdtts_tacotron2_load(const char *dir, int32_t device_id, xdtts_tacotron2 **out);
+
+/* Seeded synthetic weights with the checkpoint's exact shapes. */
+xdtts_status xdtts_tacotron2_load_synthetic(uint32_t seed, float rec_scale, int32_t device_id,
+                                            xdtts_tacotron2 **out);
+
+/* Weights from a caller-held flat fp32 blob in canonical tensor order (xdtts_tensor_*). */
+xdtts_status xdtts_tacotron2_load_blob(const float *blob, size_t n_floats, int32_t device_id,
+                                       xdtts_tacotron2 **out);
+
+/* Writes the handle's canonical weights as `dir`/tacotron2.xdtw. */
+xdtts_status xdtts_tacotron2_save(const xdtts_tacotron2 *h, const char *dir);
+
+/* Canonical tensor table (names follow the NVIDIA checkpoint the ONNX graphs were exported
+ * from, src/tacotron2/mod.rs:137-138). */
+int32_t xdtts_tensor_count(void);
+const char *xdtts_tensor_name(int32_t i);
+int32_t xdtts_tensor_ndim(int32_t i);
+int32_t xdtts_tensor_dim(int32_t i, int32_t d);
+size_t xdtts_tensor_offset(int32_t i);
+size_t xdtts_tensor_total(void);
+/* Copies the canonical (un-packed, un-folded) tensor i out of the handle. */
+xdtts_status xdtts_tacotron2_get_tensor(const xdtts_tacotron2 *h, int32_t i, float *out);
+
+/* Tacotron2::infer(&[Unit]) -- src/tacotron2/mod.rs:398-437, after the Unit->id mapping
+ * (:403-406) and find_splits (:399), which stay on the host side of the FFI (xdtts_host.h).
+ * `splits` are the chunk end offsets into ids (ascending, last == n); NULL/0 means one chunk.
+ * Each chunk must be <= max_chunk ids (else XDTTS_ERR_TOO_LONG, the reference's assert at :363).
+ * Chunks are independent (:422-434): they are decoded together as one batch and concatenated
+ * on the time axis (:430).  *mel receives 80 x (*n_frames) floats, C order. */
+xdtts_status xdtts_tacotron2_infer_ids(xdtts_tacotron2 *h, const int64_t *ids, size_t n,
+                                       const size_t *splits, size_t n_splits,
+                                       const xdtts_infer_opts *opts, float **mel,
+                                       size_t *n_frames);
+
+/* Batched form of infer_chunk (src/tacotron2/mod.rs:361-393): B independent chunks, ids is
+ * B x t_stride with lens[b] valid ids each.  fixed_steps_per_item may be NULL.  mels[b] is
+ * 80 x n_frames[b]. */
+xdtts_status xdtts_tacotron2_infer_batch(xdtts_tacotron2 *h, const int64_t *ids,
+                                         const int32_t *lens, int32_t B, int32_t t_stride,
+                                         const xdtts_infer_opts *opts,
+                                         const int32_t *fixed_steps_per_item, float **mels,
+                                         size_t *n_frames);
+
+/* Parity hooks: the three graphs of the reference one at a time.
+ * encoder.onnx (mod.rs:379): ids (T) -> memory (T x 512), processed_memory (T x 128). */
+xdtts_status xdtts_tacotron2_encoder(xdtts_tacotron2 *h, const int64_t *ids, int32_t T,
+                                     float *memory, float *processed_memory);
+/* run_decoder frame loop (mod.rs:272-342) on caller-supplied encoder outputs: frames are
+ * n_frames x 80 (pre-postnet, time-major), gates n_frames. Buffers sized for max_steps. */
+xdtts_status xdtts_tacotron2_decoder(xdtts_tacotron2 *h, const float *memory,
+                                     const float *processed_memory, int32_t T, int32_t n_valid,
+                                     const xdtts_infer_opts *opts, float *frames, float *gates,
+                                     size_t *n_frames);
+/* postnet.onnx (mod.rs:345-355): frames (F x 80) -> mel_outputs_postnet (80 x F). */
+xdtts_status xdtts_tacotron2_postnet(xdtts_tacotron2 *h, const float *frames, int32_t F,
+                                     float *mel_out);
+
+/* Phase timings of the last infer call on this handle, measured with HIP events on the
+ * handle's stream: ms[0] encoder, ms[1] decoder loop, ms[2] postnet, ms[3] total;
+ * steps = decoder steps executed. */
+xdtts_status xdtts_tacotron2_last_timings(const xdtts_tacotron2 *h, float ms[4], int32_t *steps);
+
+void xdtts_tacotron2_free(xdtts_tacotron2 *h);
+
+/* ---- Griffin-Lim ------------------------------------------------------------------------ */
+
+/* griffin_lim::mel::create_mel_filter_bank(sr, n_fft, n_mels, fmin, fmax: Option<f32>) --
+ * src/tacotron2/mod.rs:453.  fmax = NaN means None (sr/2).  out is n_mels x (n_fft/2+1). */
+xdtts_status xdtts_mel_filter_bank(float sample_rate, size_t n_fft, size_t n_mels, float fmin,
+                                   float fmax_or_nan, float *out);
+
+/* GriffinLim::new(mel_basis, noverlap, power, iter, momentum) -- src/tacotron2/mod.rs:456.
+ * n_fft = 2*(n_bins-1); hop = n_fft - noverlap. */
+xdtts_status xdtts_griffinlim_new(const float *mel_basis, size_t n_mels, size_t n_bins,
+                                  size_t noverlap, float power, size_t iters, float momentum,
+                                  int32_t device_id, xdtts_griffinlim **out);
+
+/* The random initial phase of the crate is un-seeded; here it is a counter-based stream. */
+xdtts_status xdtts_griffinlim_set_seed(xdtts_griffinlim *g, uint32_t seed);
+
+/* GriffinLim::infer(&Array2<f32>) -> Vec<f32> -- src/lib.rs:141.  mel is n_mels x F (C order,
+ * natural-log compressed as produced by Tacotron2); audio has hop*(F-1) samples. */
+xdtts_status xdtts_griffinlim_infer(xdtts_griffinlim *g, const float *mel, size_t n_mels,
+                                    size_t n_frames, float **audio, size_t *n_samples);
+
+/* Same, skipping the mel->linear inversion: S is n_bins x F linear magnitude; phase0 is
+ * n_bins x F x 2 (cos, sin) or NULL for the seeded stream; iters = 0 uses the handle's count. */
+xdtts_status xdtts_griffinlim_infer_linear(xdtts_griffinlim *g, const float *S,
+                                           const float *phase0, size_t n_frames, size_t iters,
+                                           float **audio, size_t *n_samples);
+
+/* mel -> linear magnitude only (step 1 of GriffinLim::infer): S_out is n_bins x F. */
+xdtts_status xdtts_griffinlim_mel_to_linear(xdtts_griffinlim *g, const float *mel,
+                                            size_t n_mels, size_t n_frames, float *S_out);
+
+/* ms[0] mel->linear, ms[1] iterations, ms[2] total of the last call (HIP events). */
+xdtts_status xdtts_griffinlim_last_timings(const xdtts_griffinlim *g, float ms[3]);
+
+void xdtts_griffinlim_free(xdtts_griffinlim *g);
+
+/* ---- XdTts::infer pipeline (src/lib.rs:110-159): mel-gen then vocoder with the mel kept in
+ * HBM between the two; both outputs are returned. ------------------------------------------ */
+xdtts_status xdtts_synthesize_ids(xdtts_tacotron2 *h, xdtts_griffinlim *g, const int64_t *ids,
+                                  size_t n, const size_t *splits, size_t n_splits,
+                                  const xdtts_infer_opts *opts, float **mel, size_t *n_frames,
+                                  float **audio, size_t *n_samples);
+
+/* ---- misc ------------------------------------------------------------------------------- */
+void xdtts_free(void *p);
+const char *xdtts_last_error(void);
+int32_t xdtts_device_count(void);
+/* Blocks until all work queued on the handle's stream has finished. */
+xdtts_status xdtts_tacotron2_sync(xdtts_tacotron2 *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XDTTS_H */

@@ -1,0 +1,64 @@
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    """The product package (directory `xd-tts_amd`); importing it loads libxdtts_hip.so."""
+    return importlib.import_module("xd-tts_amd")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    import oracle
+
+    return oracle.Oracle("f32")
+
+
+@pytest.fixture(scope="session")
+def orc64():
+    import oracle
+
+    return oracle.Oracle("f64")
+
+
+@pytest.fixture(scope="session")
+def blob(orc):
+    """Seeded synthetic Tacotron2 weights, canonical flat fp32 blob."""
+    return orc.weights_synthetic(seed=20240327, rec_scale=1.0)
+
+
+@pytest.fixture(scope="session")
+def model(pkg, blob):
+    if pkg.device_count() < 1:
+        pytest.skip("no HIP device")
+    m = pkg.Tacotron2.from_blob(blob)
+    yield m
+    m.close()
+
+
+def rms(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.sqrt(np.mean((a - b) ** 2)))
+
+
+def synth_ids(n, seed=1):
+    """BASELINE.md section 3 config-2 ids: ARPAbet range 64..147, space (11) every 6th, '.' (7) last."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    ids = 64 + rng.integers(0, 84, size=n)
+    ids[5::6] = 11
+    ids[-1] = 7
+    return ids.astype(np.int64)

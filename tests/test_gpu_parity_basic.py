@@ -1,0 +1,92 @@
+"""GPU parity, first slice: each graph of the reference (encoder / decoder_iter loop / postnet,
+src/tacotron2/mod.rs:379,304,347) and the vocoder against the CPU oracle, through the C ABI."""
+import numpy as np
+import pytest
+
+from conftest import rms, synth_ids
+
+pytestmark = pytest.mark.gpu
+
+
+def test_synthetic_weights_match_oracle(pkg, blob):
+    m = pkg.Tacotron2.synthetic(seed=20240327, rec_scale=1.0)
+    for name, shape, off in pkg.tensor_table():
+        n = int(np.prod(shape))
+        assert np.array_equal(m.get_tensor(name).ravel(), blob[off : off + n]), name
+    m.close()
+
+
+def test_encoder_parity(model, orc, blob):
+    ids = np.zeros(100, dtype=np.int64)
+    ids[:28] = [108, 119, 11, 88, 113, 108, 120, 11, 116, 73, 118, 129, 70, 130, 73, 133, 108, 143, 117, 114, 11, 118, 66, 90, 97, 119, 11, 7]
+    mem, pm = model.encoder(ids)
+    rmem, rpm = orc.encoder(blob, ids)
+    assert np.abs(mem - rmem).max() <= 1e-5
+    assert np.abs(pm - rpm).max() <= 1e-5
+
+
+def test_decoder_free_running_parity(model, orc, blob):
+    ids = np.zeros(100, dtype=np.int64)
+    ids[:40] = synth_ids(40)
+    rmem, rpm = orc.encoder(blob, ids)
+    steps = 60
+    frames, gates = model.decoder(rmem, rpm, 40, model_opts(model, steps))
+    rframes, rgates = orc.run_decoder(blob, rmem, rpm, 40, orc.default_opts(fixed_steps=steps, dropout_seed=7))
+    assert frames.shape == rframes.shape == (steps, 80)
+    assert rms(frames, rframes) <= 1e-5
+    assert np.abs(gates - rgates).max() <= 1e-5
+
+
+def model_opts(model, steps, seed=7):
+    import importlib
+
+    pkg = importlib.import_module("xd-tts_amd")
+    return pkg.default_opts(fixed_steps=steps, dropout_seed=seed)
+
+
+def test_postnet_parity(model, orc, blob):
+    rng = np.random.default_rng(0)
+    frames = rng.standard_normal((37, 80)).astype(np.float32)
+    out = model.postnet(frames)
+    ref = orc.postnet(blob, frames)
+    assert out.shape == (80, 37)
+    assert rms(out, ref) <= 1e-5
+
+
+def test_infer_end_to_end_parity(model, orc, blob, pkg):
+    ids = synth_ids(30)
+    steps = 40
+    mel = model.infer(ids, opts=pkg.default_opts(fixed_steps=steps, dropout_seed=11))
+    ref = orc.infer_chunk(blob, ids, orc.default_opts(fixed_steps=steps, dropout_seed=11))
+    assert mel.shape == (80, steps)
+    assert rms(mel, ref) <= 1e-4  # the north-star tolerance; typical is ~1e-7
+
+
+def test_griffinlim_parity(pkg, orc):
+    F = 64
+    t = np.arange(256 * (F - 1)) / 22050.0
+    sig = (0.5 * np.sin(2 * np.pi * 440 * t) + 0.3 * np.sin(2 * np.pi * (1000 + 2000 * t) * t)).astype(np.float32)
+    spec = orc.stft(sig)
+    S = np.hypot(spec[..., 0], spec[..., 1]).astype(np.float32)
+    phase0 = orc.phase_init(3, 513, F)
+    voc = pkg.create_griffin_lim(iters=30, seed=3)
+    audio = voc.infer_linear(S, phase0=phase0, iters=30)
+    ref = orc.griffinlim(S, phase0=phase0, iters=30)
+    assert audio.shape == ref.shape == (256 * (F - 1),)
+    assert rms(audio, ref) <= 1e-4
+    # seeded device-side phase init follows the same counter stream as the oracle
+    audio2 = voc.infer_linear(S, phase0=None, iters=30)
+    ref2 = orc.griffinlim(S, phase0=None, seed=3, iters=30)
+    assert rms(audio2, ref2) <= 1e-4
+    voc.close()
+
+
+def test_mel_to_linear_parity(pkg, orc):
+    rng = np.random.default_rng(1)
+    mel = rng.uniform(-8, 0.5, size=(80, 50)).astype(np.float32)
+    voc = pkg.create_griffin_lim()
+    S = voc.mel_to_linear(mel)
+    ref = orc.mel_to_linear(orc.pinv(orc.mel_filter_bank()), mel, power=1.7)
+    assert S.shape == ref.shape == (513, 50)
+    assert np.abs(S - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+    voc.close()

@@ -1,0 +1,330 @@
+"""xd-tts hot path on MI355X: Python mirror of the reference's Rust surface over the C ABI.
+
+The product is ``libxdtts_hip.so`` (HIP kernels + ``extern "C"`` entry points, declared in
+``include/xdtts.h``).  This module is the thin host-side binding used by tests and bench.py; it
+mirrors the reference's operator interface for the hot path:
+
+* ``Tacotron2.load(path)`` / ``Tacotron2.infer(ids)``   -- src/tacotron2/mod.rs:242,398
+* ``create_mel_filter_bank(...)``                       -- griffin_lim::mel, src/tacotron2/mod.rs:453
+* ``GriffinLim(mel_basis, noverlap, power, iter, momentum)`` / ``.infer(mel)``
+                                                        -- src/tacotron2/mod.rs:456, src/lib.rs:141
+* ``create_griffin_lim()``                              -- src/tacotron2/mod.rs:441-458
+
+There is no CPU fallback: if the shared library is missing, importing fails; if no HIP device is
+visible every call raises ``XdttsError`` (status XDTTS_ERR_NO_DEVICE).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libxdtts_hip.so")
+
+N_MEL = 80
+EMB = 512
+ATT_DIM = 128
+
+STATUS = {0: "OK", 1: "BAD_ARG", 2: "IO", 3: "HIP", 4: "OOM", 5: "TOO_LONG", 6: "NO_DEVICE"}
+XDTTS_ERR_BAD_ARG, XDTTS_ERR_IO, XDTTS_ERR_HIP, XDTTS_ERR_OOM, XDTTS_ERR_TOO_LONG, XDTTS_ERR_NO_DEVICE = 1, 2, 3, 4, 5, 6
+
+
+class XdttsError(RuntimeError):
+    """Non-zero xdtts_status; the Rust shim maps this to anyhow::Error (mod.rs:249,254,259)."""
+
+    def __init__(self, status, message):
+        super().__init__("xdtts status %d (%s): %s" % (status, STATUS.get(status, "?"), message))
+        self.status = status
+
+
+class InferOpts(C.Structure):
+    _fields_ = [
+        ("gate_threshold", C.c_float),
+        ("max_steps", C.c_int32),
+        ("fixed_steps", C.c_int32),
+        ("dropout_mode", C.c_int32),
+        ("dropout_seed", C.c_uint32),
+        ("max_chunk", C.c_int32),
+        ("item_base", C.c_uint32),
+        ("reserved", C.c_uint32),
+    ]
+
+
+# name -> (restype, argtypes).  Every symbol include/xdtts.h declares is listed here; the CPU-only
+# tests check that the library exports all of them.
+_VP, _I32, _U32, _SZ, _F = C.c_void_p, C.c_int32, C.c_uint32, C.c_size_t, C.c_float
+_PF = C.POINTER(C.c_float)
+SYMBOLS = {
+    "xdtts_infer_opts_default": (None, [C.POINTER(InferOpts)]),
+    "xdtts_tacotron2_load": (_I32, [C.c_char_p, _I32, C.POINTER(_VP)]),
+    "xdtts_tacotron2_load_synthetic": (_I32, [_U32, _F, _I32, C.POINTER(_VP)]),
+    "xdtts_tacotron2_load_blob": (_I32, [_VP, _SZ, _I32, C.POINTER(_VP)]),
+    "xdtts_tacotron2_save": (_I32, [_VP, C.c_char_p]),
+    "xdtts_tensor_count": (_I32, []),
+    "xdtts_tensor_name": (C.c_char_p, [_I32]),
+    "xdtts_tensor_ndim": (_I32, [_I32]),
+    "xdtts_tensor_dim": (_I32, [_I32, _I32]),
+    "xdtts_tensor_offset": (_SZ, [_I32]),
+    "xdtts_tensor_total": (_SZ, []),
+    "xdtts_tacotron2_get_tensor": (_I32, [_VP, _I32, _VP]),
+    "xdtts_tacotron2_infer_ids": (_I32, [_VP, _VP, _SZ, _VP, _SZ, C.POINTER(InferOpts), C.POINTER(_PF), C.POINTER(_SZ)]),
+    "xdtts_tacotron2_infer_batch": (_I32, [_VP, _VP, _VP, _I32, _I32, C.POINTER(InferOpts), _VP, C.POINTER(_PF), C.POINTER(_SZ)]),
+    "xdtts_tacotron2_encoder": (_I32, [_VP, _VP, _I32, _VP, _VP]),
+    "xdtts_tacotron2_decoder": (_I32, [_VP, _VP, _VP, _I32, _I32, C.POINTER(InferOpts), _VP, _VP, C.POINTER(_SZ)]),
+    "xdtts_tacotron2_postnet": (_I32, [_VP, _VP, _I32, _VP]),
+    "xdtts_tacotron2_last_timings": (_I32, [_VP, C.POINTER(C.c_float * 4), C.POINTER(_I32)]),
+    "xdtts_tacotron2_free": (None, [_VP]),
+    "xdtts_tacotron2_sync": (_I32, [_VP]),
+    "xdtts_mel_filter_bank": (_I32, [_F, _SZ, _SZ, _F, _F, _VP]),
+    "xdtts_griffinlim_new": (_I32, [_VP, _SZ, _SZ, _SZ, _F, _SZ, _F, _I32, C.POINTER(_VP)]),
+    "xdtts_griffinlim_set_seed": (_I32, [_VP, _U32]),
+    "xdtts_griffinlim_infer": (_I32, [_VP, _VP, _SZ, _SZ, C.POINTER(_PF), C.POINTER(_SZ)]),
+    "xdtts_griffinlim_infer_linear": (_I32, [_VP, _VP, _VP, _SZ, _SZ, C.POINTER(_PF), C.POINTER(_SZ)]),
+    "xdtts_griffinlim_mel_to_linear": (_I32, [_VP, _VP, _SZ, _SZ, _VP]),
+    "xdtts_griffinlim_last_timings": (_I32, [_VP, C.POINTER(C.c_float * 3)]),
+    "xdtts_griffinlim_free": (None, [_VP]),
+    "xdtts_synthesize_ids": (_I32, [_VP, _VP, _VP, _SZ, _VP, _SZ, C.POINTER(InferOpts), C.POINTER(_PF), C.POINTER(_SZ), C.POINTER(_PF), C.POINTER(_SZ)]),
+    "xdtts_free": (None, [_VP]),
+    "xdtts_last_error": (C.c_char_p, []),
+    "xdtts_device_count": (_I32, []),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s not found: build it with `make -C %s` (or __graft_entry__.build()); there is no CPU fallback" % (LIB_PATH, _HERE)
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def _check(status):
+    if status != 0:
+        raise XdttsError(status, lib.xdtts_last_error().decode("utf-8", "replace"))
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def default_opts(**kw):
+    o = InferOpts()
+    lib.xdtts_infer_opts_default(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def device_count():
+    return lib.xdtts_device_count()
+
+
+def tensor_table():
+    out = []
+    for i in range(lib.xdtts_tensor_count()):
+        shape = tuple(lib.xdtts_tensor_dim(i, d) for d in range(lib.xdtts_tensor_ndim(i)))
+        out.append((lib.xdtts_tensor_name(i).decode(), shape, lib.xdtts_tensor_offset(i)))
+    return out
+
+
+def _take(ptr, n, shape):
+    """Copy a library-owned pinned buffer into numpy and release it."""
+    try:
+        return np.ctypeslib.as_array(ptr, shape=(max(n, 1),))[:n].reshape(shape).copy()
+    finally:
+        lib.xdtts_free(ptr)
+
+
+class Tacotron2:
+    """Mirror of ``Tacotron2`` (src/tacotron2/mod.rs:139-148): ``load`` then ``infer``."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    # -- constructors ---------------------------------------------------------------------------
+    @classmethod
+    def load(cls, path, device_id=0):
+        """Tacotron2::load(path) -- src/tacotron2/mod.rs:242."""
+        h = C.c_void_p()
+        _check(lib.xdtts_tacotron2_load(os.fsencode(path), device_id, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def synthetic(cls, seed=20240327, rec_scale=1.0, device_id=0):
+        h = C.c_void_p()
+        _check(lib.xdtts_tacotron2_load_synthetic(seed, rec_scale, device_id, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_blob(cls, blob, device_id=0):
+        blob = np.ascontiguousarray(blob, dtype=np.float32)
+        h = C.c_void_p()
+        _check(lib.xdtts_tacotron2_load_blob(_ptr(blob), blob.size, device_id, C.byref(h)))
+        return cls(h)
+
+    def close(self):
+        if self._h:
+            lib.xdtts_tacotron2_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def save(self, path):
+        _check(lib.xdtts_tacotron2_save(self._h, os.fsencode(path)))
+
+    def get_tensor(self, name):
+        for i, (n, shape, _off) in enumerate(tensor_table()):
+            if n == name:
+                out = np.empty(shape, dtype=np.float32)
+                _check(lib.xdtts_tacotron2_get_tensor(self._h, i, _ptr(out)))
+                return out
+        raise KeyError(name)
+
+    # -- the reference surface --------------------------------------------------------------------
+    def infer(self, ids, splits=None, opts=None):
+        """Tacotron2::infer -- src/tacotron2/mod.rs:398; ids after best_match_for_unit, splits from
+        find_splits.  Returns the (80, F) mel like the reference's Array2<f32>."""
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        sp = None if splits is None else np.ascontiguousarray(splits, dtype=np.uintp)
+        mel, nf = _PF(), C.c_size_t()
+        _check(
+            lib.xdtts_tacotron2_infer_ids(
+                self._h, _ptr(ids), ids.size, None if sp is None else _ptr(sp), 0 if sp is None else sp.size, C.byref(opts) if opts else None, C.byref(mel), C.byref(nf)
+            )
+        )
+        return _take(mel, N_MEL * nf.value, (N_MEL, nf.value))
+
+    def infer_batch(self, ids_list, opts=None, fixed_steps=None):
+        """B independent chunks (infer_chunk, mod.rs:361-393) decoded in lock-step."""
+        B = len(ids_list)
+        lens = np.array([len(x) for x in ids_list], dtype=np.int32)
+        stride = int(lens.max()) if B else 1
+        ids = np.zeros((B, stride), dtype=np.int64)
+        for b, x in enumerate(ids_list):
+            ids[b, : len(x)] = x
+        fs = None if fixed_steps is None else np.ascontiguousarray(fixed_steps, dtype=np.int32)
+        mels = (_PF * B)()
+        nf = (C.c_size_t * B)()
+        _check(lib.xdtts_tacotron2_infer_batch(self._h, _ptr(ids), _ptr(lens), B, stride, C.byref(opts) if opts else None, None if fs is None else _ptr(fs), mels, nf))
+        return [_take(mels[b], N_MEL * nf[b], (N_MEL, nf[b])) for b in range(B)]
+
+    # -- parity hooks: the three graphs one at a time ---------------------------------------------
+    def encoder(self, ids):
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        T = ids.size
+        memory = np.empty((T, EMB), dtype=np.float32)
+        pmem = np.empty((T, ATT_DIM), dtype=np.float32)
+        _check(lib.xdtts_tacotron2_encoder(self._h, _ptr(ids), T, _ptr(memory), _ptr(pmem)))
+        return memory, pmem
+
+    def decoder(self, memory, pmem, n_valid, opts=None):
+        memory = np.ascontiguousarray(memory, dtype=np.float32)
+        pmem = np.ascontiguousarray(pmem, dtype=np.float32)
+        o = opts if opts else default_opts()
+        frames = np.empty((o.max_steps, N_MEL), dtype=np.float32)
+        gates = np.empty(o.max_steps, dtype=np.float32)
+        nf = C.c_size_t()
+        _check(lib.xdtts_tacotron2_decoder(self._h, _ptr(memory), _ptr(pmem), memory.shape[0], n_valid, C.byref(o), _ptr(frames), _ptr(gates), C.byref(nf)))
+        return frames[: nf.value].copy(), gates[: nf.value].copy()
+
+    def postnet(self, frames):
+        frames = np.ascontiguousarray(frames, dtype=np.float32)
+        F = frames.shape[0]
+        out = np.empty((N_MEL, F), dtype=np.float32)
+        _check(lib.xdtts_tacotron2_postnet(self._h, _ptr(frames), F, _ptr(out)))
+        return out
+
+    def last_timings(self):
+        ms = (C.c_float * 4)()
+        steps = C.c_int32()
+        _check(lib.xdtts_tacotron2_last_timings(self._h, C.byref(ms), C.byref(steps)))
+        return {"encoder_ms": ms[0], "decoder_ms": ms[1], "postnet_ms": ms[2], "total_ms": ms[3], "steps": steps.value}
+
+
+def create_mel_filter_bank(sample_rate, n_fft, n_mels, fmin, fmax=None):
+    """griffin_lim::mel::create_mel_filter_bank -- src/tacotron2/mod.rs:453 (fmax: Option<f32>)."""
+    out = np.empty((n_mels, n_fft // 2 + 1), dtype=np.float32)
+    _check(lib.xdtts_mel_filter_bank(sample_rate, n_fft, n_mels, fmin, float("nan") if fmax is None else fmax, _ptr(out)))
+    return out
+
+
+class GriffinLim:
+    """Mirror of griffin_lim::GriffinLim: ``new(mel_basis, noverlap, power, iter, momentum)``
+    (src/tacotron2/mod.rs:456) and ``infer(&mel)`` (src/lib.rs:141)."""
+
+    def __init__(self, mel_basis, noverlap, power, iters, momentum, device_id=0, seed=0):
+        basis = np.ascontiguousarray(mel_basis, dtype=np.float32)
+        self._h = C.c_void_p()
+        _check(lib.xdtts_griffinlim_new(_ptr(basis), basis.shape[0], basis.shape[1], noverlap, power, iters, momentum, device_id, C.byref(self._h)))
+        self.n_bins = basis.shape[1]
+        self.set_seed(seed)
+
+    def set_seed(self, seed):
+        _check(lib.xdtts_griffinlim_set_seed(self._h, seed))
+
+    def close(self):
+        if self._h:
+            lib.xdtts_griffinlim_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def infer(self, mel):
+        mel = np.ascontiguousarray(mel, dtype=np.float32)
+        audio, n = _PF(), C.c_size_t()
+        _check(lib.xdtts_griffinlim_infer(self._h, _ptr(mel), mel.shape[0], mel.shape[1], C.byref(audio), C.byref(n)))
+        return _take(audio, n.value, (n.value,))
+
+    def infer_linear(self, S, phase0=None, iters=0):
+        S = np.ascontiguousarray(S, dtype=np.float32)
+        p0 = None if phase0 is None else np.ascontiguousarray(phase0, dtype=np.float32)
+        audio, n = _PF(), C.c_size_t()
+        _check(lib.xdtts_griffinlim_infer_linear(self._h, _ptr(S), None if p0 is None else _ptr(p0), S.shape[1], iters, C.byref(audio), C.byref(n)))
+        return _take(audio, n.value, (n.value,))
+
+    def mel_to_linear(self, mel):
+        mel = np.ascontiguousarray(mel, dtype=np.float32)
+        S = np.empty((self.n_bins, mel.shape[1]), dtype=np.float32)
+        _check(lib.xdtts_griffinlim_mel_to_linear(self._h, _ptr(mel), mel.shape[0], mel.shape[1], _ptr(S)))
+        return S
+
+    def last_timings(self):
+        ms = (C.c_float * 3)()
+        _check(lib.xdtts_griffinlim_last_timings(self._h, C.byref(ms)))
+        return {"mel_to_linear_ms": ms[0], "iterations_ms": ms[1], "total_ms": ms[2]}
+
+
+def create_griffin_lim(device_id=0, iters=30, seed=0):
+    """create_griffin_lim() -- src/tacotron2/mod.rs:441-458 (sr 22050, n_fft 1024, 80 mels, fmin 0,
+    fmax 8000, noverlap 768, power 1.7, 30 iterations, momentum 0.99)."""
+    mel_basis = create_mel_filter_bank(22050.0, 1024, 80, 0.0, 8000.0)
+    return GriffinLim(mel_basis, 1024 - 256, 1.7, iters, 0.99, device_id=device_id, seed=seed)
+
+
+def synthesize(tacotron2, vocoder, ids, splits=None, opts=None):
+    """XdTts::infer (src/lib.rs:110-159): mel-gen then vocoder, mel kept in HBM in between."""
+    ids = np.ascontiguousarray(ids, dtype=np.int64)
+    sp = None if splits is None else np.ascontiguousarray(splits, dtype=np.uintp)
+    mel, nf, audio, ns = _PF(), C.c_size_t(), _PF(), C.c_size_t()
+    _check(
+        lib.xdtts_synthesize_ids(
+            tacotron2._h, vocoder._h, _ptr(ids), ids.size, None if sp is None else _ptr(sp), 0 if sp is None else sp.size, C.byref(opts) if opts else None, C.byref(mel), C.byref(nf), C.byref(audio), C.byref(ns)
+        )
+    )
+    return _take(mel, N_MEL * nf.value, (N_MEL, nf.value)), _take(audio, ns.value, (ns.value,))

@@ -1,0 +1,981 @@
+// api.cpp -- the extern "C" boundary of libxdtts_hip.so (declared in include/xdtts.h) and the
+// host-side orchestration of the HIP kernels.  No CPU compute path exists here: without a HIP
+// device every entry point fails with XDTTS_ERR_NO_DEVICE.
+#include <algorithm>
+#include <cmath>
+#include <memory>
+#include <mutex>
+
+#include "kernels.h"
+
+namespace xdtts {
+
+static thread_local std::string g_last_error;
+void set_last_error(const char *msg) { g_last_error = msg ? msg : ""; }
+void fail(xdtts_status code, const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  throw Error(code, buf);
+}
+
+template <class F>
+static xdtts_status guard(F &&f) {
+  try {
+    f();
+    return XDTTS_OK;
+  } catch (const Error &e) {
+    set_last_error(e.what());
+    return e.code;
+  } catch (const std::bad_alloc &) {
+    set_last_error("host allocation failed");
+    return XDTTS_ERR_OOM;
+  } catch (const std::exception &e) {
+    set_last_error(e.what());
+    return XDTTS_ERR_HIP;
+  }
+}
+
+static void select_device(int device_id) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    fail(XDTTS_ERR_NO_DEVICE, "no HIP device visible: libxdtts_hip has no CPU fallback");
+  if (device_id < 0 || device_id >= n) fail(XDTTS_ERR_BAD_ARG, "device_id %d out of range (0..%d)", device_id, n - 1);
+  HIP_CHECK(hipSetDevice(device_id));
+}
+
+static float *pinned_alloc(size_t n_floats) {
+  float *p = nullptr;
+  HIP_CHECK(hipHostMalloc((void **)&p, std::max<size_t>(n_floats, 1) * sizeof(float), hipHostMallocDefault));
+  return p;
+}
+
+struct Events {
+  hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
+  void create() {
+    for (auto &x : e) HIP_CHECK(hipEventCreate(&x));
+  }
+  ~Events() {
+    for (auto &x : e)
+      if (x) (void)hipEventDestroy(x);
+  }
+};
+
+}  // namespace xdtts
+
+using namespace xdtts;
+
+// ================================================================================================
+// Tacotron2 handle
+// ================================================================================================
+struct xdtts_tacotron2 {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::mutex mu;
+  std::vector<float> blob;  // canonical weights (host), for save/get_tensor
+  DeviceWeights w;
+  Events ev;
+  float last_ms[4] = {0, 0, 0, 0};
+  int last_steps = 0;
+
+  // workspaces (grown on demand)
+  DevBuf<int64_t> ids;
+  DevBuf<int> n_valid, limits, nframes, ctl;
+  DevBuf<float> xpadA, xpadB, xproj, memory, pmem;
+  DevBuf<float> att_h, att_c, dec_h, dec_c, aw, awc, ctx, x, q, frames, gates;
+  DevBuf<float> ppA, ppB, mel_dev;
+  int *host_ctl = nullptr;  // pinned: [0..1] ctl, [2..] nframes
+
+  // cached hipGraph of GRAPH_STEPS decoder steps for the current (B, T, buffers)
+  static constexpr int GRAPH_STEPS = 20;
+  hipGraphExec_t graph = nullptr;
+  DecoderBufs graph_key{};
+
+  ~xdtts_tacotron2() {
+    if (graph) (void)hipGraphExecDestroy(graph);
+    if (host_ctl) (void)hipHostFree(host_ctl);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+
+  void init(int dev) {
+    device = dev;
+    select_device(dev);
+    HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    ev.create();
+    HIP_CHECK(hipHostMalloc((void **)&host_ctl, sizeof(int) * (2 + 4096), hipHostMallocDefault));
+    w.upload(blob, stream);
+  }
+
+  // ---- encoder.onnx (mod.rs:379): ids [B][T] on device -> memory, pmem -------------------------
+  void run_encoder(int B, int T) {
+    const int pad = (ENC_K - 1) / 2, TP = T + 2 * pad;
+    const size_t padded = (size_t)B * TP * EMB;
+    xpadA.alloc(padded);
+    xpadB.alloc(padded);
+    xproj.alloc((size_t)2 * B * T * 4 * ENC_H);
+    memory.alloc((size_t)B * T * EMB);
+    pmem.alloc((size_t)B * T * ATT_DIM);
+    HIP_CHECK(hipMemsetAsync(xpadA.p, 0, padded * sizeof(float), stream));
+    HIP_CHECK(hipMemsetAsync(xpadB.p, 0, padded * sizeof(float), stream));
+    launch_embed(ids.p, w.emb.p, xpadA.p, B, T, pad, stream);
+    float *src = xpadA.p, *dst = xpadB.p;
+    for (int i = 0; i < ENC_CONVS; ++i) {
+      GemmArgs g{};
+      g.A = src;
+      g.lda = EMB;
+      g.strideA = (long)TP * EMB;
+      g.W = w.enc_conv[i].w.p;
+      g.bias = w.enc_conv[i].b.p;
+      g.C = dst + (size_t)pad * EMB;
+      g.ldc = EMB;
+      g.strideC = (long)TP * EMB;
+      g.M = T;
+      g.N = EMB;
+      g.K = ENC_K * EMB;
+      g.batch = B;
+      g.act = 1;
+      launch_gemm_nt(g, stream);
+      std::swap(src, dst);
+    }
+    for (int d = 0; d < 2; ++d) {  // BiLSTM input projections for all T at once
+      GemmArgs g{};
+      g.A = src + (size_t)pad * EMB;
+      g.lda = EMB;
+      g.strideA = (long)TP * EMB;
+      g.W = w.enc_wih[d].p;
+      g.bias = w.enc_bias[d].p;
+      g.C = xproj.p + (size_t)d * B * T * 4 * ENC_H;
+      g.ldc = 4 * ENC_H;
+      g.strideC = (long)T * 4 * ENC_H;
+      g.M = T;
+      g.N = 4 * ENC_H;
+      g.K = EMB;
+      g.batch = B;
+      launch_gemm_nt(g, stream);
+    }
+    launch_bilstm(xproj.p, w.enc_whhT[0].p, w.enc_whhT[1].p, memory.p, B, T, stream);
+    GemmArgs g{};  // processed_memory = memory_layer(memory)
+    g.A = memory.p;
+    g.lda = EMB;
+    g.strideA = (long)T * EMB;
+    g.W = w.mem_w.p;
+    g.C = pmem.p;
+    g.ldc = ATT_DIM;
+    g.strideC = (long)T * ATT_DIM;
+    g.M = T;
+    g.N = ATT_DIM;
+    g.K = EMB;
+    g.batch = B;
+    launch_gemm_nt(g, stream);
+  }
+
+  DecoderBufs decoder_bufs(int B, int T, const float *mem, const float *pm, const xdtts_infer_opts &o) {
+    const int ms = o.max_steps;
+    att_h.alloc((size_t)2 * B * ATT_RNN);
+    att_c.alloc((size_t)B * ATT_RNN);
+    dec_h.alloc((size_t)2 * B * DEC_RNN);
+    dec_c.alloc((size_t)B * DEC_RNN);
+    aw.alloc((size_t)B * T);
+    awc.alloc((size_t)B * T);
+    ctx.alloc((size_t)B * EMB);
+    x.alloc((size_t)B * PRENET);
+    q.alloc((size_t)B * ATT_DIM);
+    frames.alloc((size_t)B * ms * N_MEL);
+    gates.alloc((size_t)B * ms);
+    nframes.alloc(B);
+    ctl.alloc(2);
+    DecoderBufs d{};
+    d.B = B;
+    d.T = T;
+    d.memory = mem;
+    d.pmem = pm;
+    d.n_valid = n_valid.p;
+    d.att_h[0] = att_h.p;
+    d.att_h[1] = att_h.p + (size_t)B * ATT_RNN;
+    d.att_c = att_c.p;
+    d.dec_h[0] = dec_h.p;
+    d.dec_h[1] = dec_h.p + (size_t)B * DEC_RNN;
+    d.dec_c = dec_c.p;
+    d.aw = aw.p;
+    d.awc = awc.p;
+    d.ctx = ctx.p;
+    d.x = x.p;
+    d.q = q.p;
+    d.frames = frames.p;
+    d.gates = gates.p;
+    d.nframes = nframes.p;
+    d.ctl = ctl.p;
+    d.max_steps = ms;
+    d.use_gate = o.fixed_steps > 0 ? 0 : 1;
+    d.gate_threshold = o.gate_threshold;
+    d.dropout_mode = o.dropout_mode;
+    d.dropout_seed = o.dropout_seed;
+    d.item_base = o.item_base;
+    return d;
+  }
+
+  // Replays (building on first use) a hipGraph holding GRAPH_STEPS decoder steps.  The kernels
+  // read the step index from device memory, so one graph serves every position of the loop.
+  void replay_steps(const DecoderBufs &d) {
+    if (!graph || std::memcmp(&graph_key, &d, sizeof d) != 0) {
+      if (graph) {
+        (void)hipGraphExecDestroy(graph);
+        graph = nullptr;
+      }
+      hipGraph_t g = nullptr;
+      HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+      try {
+        launch_decoder_steps(d, w, GRAPH_STEPS, stream);
+      } catch (...) {
+        (void)hipStreamEndCapture(stream, &g);
+        if (g) (void)hipGraphDestroy(g);
+        throw;
+      }
+      HIP_CHECK(hipStreamEndCapture(stream, &g));
+      hipError_t e = hipGraphInstantiate(&graph, g, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(g);
+      HIP_CHECK(e);
+      graph_key = d;
+    }
+    HIP_CHECK(hipGraphLaunch(graph, stream));
+  }
+
+  // run_decoder frame loop (mod.rs:302-342) for B chunks; limits = per-chunk step caps (host).
+  // Returns the number of lock-step iterations executed; host_ctl[2+b] = frames of chunk b.
+  int run_decoder(const DecoderBufs &d, const std::vector<int> &lim) {
+    limits.upload(lim.data(), lim.size(), stream);
+    launch_decoder_init(d, limits.p, stream);
+    const int max_lim = *std::max_element(lim.begin(), lim.end());
+    int launched = 0;
+    auto fetch = [&]() {
+      HIP_CHECK(hipMemcpyAsync(host_ctl, d.ctl, sizeof(int) * 2, hipMemcpyDeviceToHost, stream));
+      HIP_CHECK(hipMemcpyAsync(host_ctl + 2, d.nframes, sizeof(int) * d.B, hipMemcpyDeviceToHost, stream));
+      HIP_CHECK(hipStreamSynchronize(stream));
+    };
+    if (!d.use_gate) {  // deterministic work: every chunk runs to its cap
+      while (launched < max_lim) {
+        replay_steps(d);
+        launched += GRAPH_STEPS;
+      }
+      fetch();
+    } else {
+      const int check_every = 3 * GRAPH_STEPS;
+      for (;;) {
+        for (int i = 0; i < check_every && launched < max_lim; i += GRAPH_STEPS) {
+          replay_steps(d);
+          launched += GRAPH_STEPS;
+        }
+        fetch();
+        int need = 0;
+        for (int b = 0; b < d.B; ++b) need = std::max(need, host_ctl[2 + b]);
+        if (host_ctl[0] >= need || launched >= max_lim) break;
+      }
+    }
+    int steps = 0;
+    for (int b = 0; b < d.B; ++b) steps = std::max(steps, host_ctl[2 + b]);
+    return steps;
+  }
+
+  // postnet.onnx (mod.rs:345-355) for one chunk: frames_dev [F][80] (row stride 80) ->
+  // out[m * ldc + t] for m < 80, t < F  (the (80 x F) Array2 layout), residual included.
+  void run_postnet(const float *frames_dev, int F, float *out, long ldc) {
+    const int pad = (POST_K - 1) / 2, FP = F + 2 * pad;
+    ppA.alloc((size_t)FP * POST_CH);
+    ppB.alloc((size_t)FP * POST_CH);
+    HIP_CHECK(hipMemsetAsync(ppA.p, 0, (size_t)FP * POST_CH * sizeof(float), stream));
+    HIP_CHECK(hipMemsetAsync(ppB.p, 0, (size_t)FP * POST_CH * sizeof(float), stream));
+    // layer 0 input: the frames themselves, viewed as a zero-padded [FP][80] buffer
+    HIP_CHECK(hipMemcpyAsync(ppB.p + (size_t)pad * N_MEL, frames_dev, (size_t)F * N_MEL * sizeof(float),
+                             hipMemcpyDeviceToDevice, stream));
+    float *src = ppB.p, *dst = ppA.p;
+    for (int i = 0; i < POST_CONVS; ++i) {
+      const ConvGemm &c = w.post_conv[i];
+      const bool last = i == POST_CONVS - 1;
+      GemmArgs g{};
+      g.A = src;
+      g.lda = c.ci;
+      g.W = c.w.p;
+      g.bias = c.b.p;
+      g.M = F;
+      g.N = c.co;
+      g.K = c.k * c.ci;
+      g.batch = 1;
+      if (!last) {
+        g.C = dst + (size_t)pad * c.co;
+        g.ldc = c.co;
+        g.act = 2;
+      } else {
+        g.C = out;
+        g.ldc = ldc;
+        g.transpose_out = 1;
+        g.R = frames_dev;
+        g.ldr = N_MEL;
+      }
+      launch_gemm_nt(g, stream);
+      if (i == 0) {
+        // ppB held the 80-channel input; clear it before it becomes a 512-channel buffer
+        HIP_CHECK(hipMemsetAsync(ppB.p, 0, (size_t)FP * POST_CH * sizeof(float), stream));
+      }
+      std::swap(src, dst);
+    }
+  }
+
+  // infer_chunk x B (mod.rs:361-393).  ids_host [B][T] already zero-padded.  Leaves the final mel
+  // of chunk b at mel_dev + col_off[b] with row stride F_total; returns per-chunk frame counts.
+  std::vector<int> infer_batch_device(const int64_t *ids_host, const int *lens, int B, int T,
+                                      const xdtts_infer_opts &o, const int *fixed_per_item, int *F_total) {
+    if (B <= 0 || B > 4096) fail(XDTTS_ERR_BAD_ARG, "batch %d out of range", B);
+    if (T <= 0 || T > T_MAX) fail(XDTTS_ERR_BAD_ARG, "window %d out of range (1..%d)", T, T_MAX);
+    if (o.max_steps <= 0 || o.max_steps > 100000) fail(XDTTS_ERR_BAD_ARG, "max_steps %d out of range", o.max_steps);
+    for (int b = 0; b < B; ++b) {
+      if (lens[b] <= 0) fail(XDTTS_ERR_BAD_ARG, "chunk %d is empty", b);
+      if (lens[b] > T) fail(XDTTS_ERR_TOO_LONG, "chunk %d has %d ids, window is %d", b, lens[b], T);
+      for (int t = 0; t < T; ++t) {
+        const int64_t id = ids_host[(size_t)b * T + t];
+        if (id < 0 || id >= N_SYMBOLS) fail(XDTTS_ERR_BAD_ARG, "id %lld out of range (0..%d)", (long long)id, N_SYMBOLS - 1);
+      }
+    }
+    HIP_CHECK(hipSetDevice(device));
+    HIP_CHECK(hipEventRecord(ev.e[0], stream));
+    ids.upload(ids_host, (size_t)B * T, stream);
+    n_valid.upload(lens, B, stream);
+    HIP_CHECK(hipStreamSynchronize(stream));  // ids_host may be a caller temporary
+    run_encoder(B, T);
+    HIP_CHECK(hipEventRecord(ev.e[1], stream));
+    std::vector<int> lim(B);
+    for (int b = 0; b < B; ++b) {
+      int l = fixed_per_item ? fixed_per_item[b] : (o.fixed_steps > 0 ? o.fixed_steps : o.max_steps);
+      lim[b] = std::min(std::max(l, 1), o.max_steps);
+    }
+    DecoderBufs d = decoder_bufs(B, T, memory.p, pmem.p, o);
+    if (fixed_per_item) d.use_gate = 0;
+    last_steps = run_decoder(d, lim);
+    HIP_CHECK(hipEventRecord(ev.e[2], stream));
+    std::vector<int> F(B);
+    int total = 0;
+    for (int b = 0; b < B; ++b) {
+      F[b] = host_ctl[2 + b];
+      total += F[b];
+    }
+    mel_dev.alloc((size_t)N_MEL * total);
+    int off = 0;
+    for (int b = 0; b < B; ++b) {
+      run_postnet(d.frames + (size_t)b * d.max_steps * N_MEL, F[b], mel_dev.p + off, total);
+      off += F[b];
+    }
+    HIP_CHECK(hipEventRecord(ev.e[3], stream));
+    *F_total = total;
+    return F;
+  }
+
+  void finish_timings() {
+    HIP_CHECK(hipStreamSynchronize(stream));
+    for (int i = 0; i < 3; ++i) HIP_CHECK(hipEventElapsedTime(&last_ms[i], ev.e[i], ev.e[i + 1]));
+    HIP_CHECK(hipEventElapsedTime(&last_ms[3], ev.e[0], ev.e[3]));
+  }
+};
+
+static void chunks_from_splits(const int64_t *ids, size_t n, const size_t *splits, size_t n_splits, int T,
+                               std::vector<int64_t> &padded, std::vector<int> &lens) {
+  if (!ids || n == 0) fail(XDTTS_ERR_BAD_ARG, "empty id sequence");
+  std::vector<size_t> ends;
+  if (splits && n_splits) ends.assign(splits, splits + n_splits);
+  if (ends.empty() || ends.back() != n) ends.push_back(n);  // mod.rs:412-414
+  size_t start = 0;
+  for (size_t e : ends) {
+    if (e < start || e > n) fail(XDTTS_ERR_BAD_ARG, "splits must be ascending offsets into ids");
+    if (e == start) continue;
+    const size_t len = e - start;
+    if ((int)len > T) fail(XDTTS_ERR_TOO_LONG, "chunk of %zu ids exceeds the %d-id window", len, T);  // mod.rs:363
+    lens.push_back((int)len);
+    const size_t base = padded.size();
+    padded.resize(base + (size_t)T, 0);  // pad id 0 = Unit::Padding, mod.rs:369-371
+    std::copy(ids + start, ids + e, padded.begin() + (long)base);
+    start = e;
+  }
+}
+
+// ================================================================================================
+// Griffin-Lim handle
+// ================================================================================================
+struct xdtts_griffinlim {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::mutex mu;
+  int n_mels = 0, nb = 0, n_fft = 0, hop = 0, iters = 0;
+  float power = 1.f, momentum = 0.99f;
+  uint32_t seed = 0;
+  Events ev;
+  float last_ms[3] = {0, 0, 0};
+  DevBuf<float> pinv, win, S, melT, mel_in, frames, y, audio, phase0;
+  DevBuf<float2> tw, ang, tprev;
+
+  ~xdtts_griffinlim() {
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+
+  GlBufs bufs(int F) {
+    S.alloc((size_t)F * nb);
+    ang.alloc((size_t)F * nb);
+    tprev.alloc((size_t)F * nb);
+    frames.alloc((size_t)F * n_fft);
+    y.alloc((size_t)std::max(1, hop * (F - 1)));
+    audio.alloc((size_t)std::max(1, hop * (F - 1)));
+    GlBufs g{};
+    g.F = F;
+    g.n_fft = n_fft;
+    g.hop = hop;
+    g.nb = nb;
+    g.S = S.p;
+    g.ang = ang.p;
+    g.tprev = tprev.p;
+    g.frames = frames.p;
+    g.y = y.p;
+    g.tw = tw.p;
+    g.win = win.p;
+    return g;
+  }
+
+  // step 1 of GriffinLim::infer: mel (device, n_mels x F, ln-compressed) -> S [F][nb]
+  void mel_to_linear(const float *mel_dev_ptr, int F) {
+    melT.alloc((size_t)F * n_mels);
+    launch_gl_exp_transpose(mel_dev_ptr, melT.p, n_mels, F, stream);
+    GemmArgs a{};
+    a.A = melT.p;
+    a.lda = n_mels;
+    a.W = pinv.p;
+    a.C = S.p;
+    a.ldc = nb;
+    a.M = F;
+    a.N = nb;
+    a.K = n_mels;
+    a.batch = 1;
+    a.act = 3;
+    a.p = 1.0f / power;
+    launch_gemm_nt(a, stream);
+  }
+
+  // phase init + iterations + final ISTFT; S already in place.  Result in audio (device).
+  void iterate(const GlBufs &g, const float *phase0_dev, int n_iter) {
+    launch_gl_phase_init(g, seed, phase0_dev, stream);
+    const float alpha = momentum / (1.0f + momentum);
+    for (int i = 0; i < n_iter; ++i) launch_gl_iteration(g, alpha, stream);
+    launch_gl_final(g, audio.p, stream);
+  }
+
+  void finish_timings() {
+    HIP_CHECK(hipStreamSynchronize(stream));
+    HIP_CHECK(hipEventElapsedTime(&last_ms[0], ev.e[0], ev.e[1]));
+    HIP_CHECK(hipEventElapsedTime(&last_ms[1], ev.e[1], ev.e[2]));
+    HIP_CHECK(hipEventElapsedTime(&last_ms[2], ev.e[0], ev.e[2]));
+  }
+};
+
+// Slaney-scale helpers for create_mel_filter_bank (librosa.filters.mel, htk=False, norm="slaney")
+static double hz_to_mel(double f) {
+  const double f_sp = 200.0 / 3.0, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp;
+  const double logstep = std::log(6.4) / 27.0;
+  return f >= min_log_hz ? min_log_mel + std::log(f / min_log_hz) / logstep : f / f_sp;
+}
+static double mel_to_hz(double m) {
+  const double f_sp = 200.0 / 3.0, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp;
+  const double logstep = std::log(6.4) / 27.0;
+  return m >= min_log_mel ? min_log_hz * std::exp(logstep * (m - min_log_mel)) : f_sp * m;
+}
+
+// pinv(A) = A^T (A A^T)^-1 for the full-row-rank mel basis, fp64 Cholesky.  librosa's nnls starts
+// from lstsq(A, M) clipped at 0 and its L-BFGS-B refinement stops at iteration 0 for this
+// objective scaling, so clip(pinv M, 0) is the inversion the vocoder performs.
+static void host_pinv(const float *basis, int n, int nbins, std::vector<float> &out) {
+  std::vector<double> G((size_t)n * n, 0.0), z(n);
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j <= i; ++j) {
+      double s = 0;
+      for (int b = 0; b < nbins; ++b) s += (double)basis[(size_t)i * nbins + b] * basis[(size_t)j * nbins + b];
+      G[(size_t)i * n + j] = G[(size_t)j * n + i] = s;
+    }
+  for (int j = 0; j < n; ++j) {
+    double d = G[(size_t)j * n + j];
+    for (int k = 0; k < j; ++k) d -= G[(size_t)j * n + k] * G[(size_t)j * n + k];
+    if (!(d > 0)) fail(XDTTS_ERR_BAD_ARG, "mel basis is rank deficient (filter %d)", j);
+    d = std::sqrt(d);
+    G[(size_t)j * n + j] = d;
+    for (int i = j + 1; i < n; ++i) {
+      double s = G[(size_t)i * n + j];
+      for (int k = 0; k < j; ++k) s -= G[(size_t)i * n + k] * G[(size_t)j * n + k];
+      G[(size_t)i * n + j] = s / d;
+    }
+  }
+  out.resize((size_t)nbins * n);
+  for (int b = 0; b < nbins; ++b) {
+    for (int i = 0; i < n; ++i) {
+      double s = basis[(size_t)i * nbins + b];
+      for (int k = 0; k < i; ++k) s -= G[(size_t)i * n + k] * z[k];
+      z[i] = s / G[(size_t)i * n + i];
+    }
+    for (int i = n - 1; i >= 0; --i) {
+      double s = z[i];
+      for (int k = i + 1; k < n; ++k) s -= G[(size_t)k * n + i] * z[k];
+      z[i] = s / G[(size_t)i * n + i];
+    }
+    for (int i = 0; i < n; ++i) out[(size_t)b * n + i] = (float)z[i];
+  }
+}
+
+// ================================================================================================
+// extern "C"
+// ================================================================================================
+extern "C" {
+
+void xdtts_infer_opts_default(xdtts_infer_opts *o) {
+  if (!o) return;
+  o->gate_threshold = 0.6f;  // src/tacotron2/mod.rs:279
+  o->max_steps = 1000;       // src/tacotron2/mod.rs:280
+  o->fixed_steps = 0;
+  o->dropout_mode = 1;
+  o->dropout_seed = 0;
+  o->max_chunk = 100;  // src/tacotron2/mod.rs:363,369-371,399
+  o->item_base = 0;
+  o->reserved = 0;
+}
+
+const char *xdtts_last_error(void) { return g_last_error.c_str(); }
+
+int32_t xdtts_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+void xdtts_free(void *p) {
+  if (p) (void)hipHostFree(p);
+}
+
+int32_t xdtts_tensor_count(void) { return (int32_t)tensor_table().size(); }
+const char *xdtts_tensor_name(int32_t i) {
+  return i >= 0 && i < xdtts_tensor_count() ? tensor_table()[i].name : nullptr;
+}
+int32_t xdtts_tensor_ndim(int32_t i) { return i >= 0 && i < xdtts_tensor_count() ? tensor_table()[i].ndim : 0; }
+int32_t xdtts_tensor_dim(int32_t i, int32_t d) {
+  return i >= 0 && i < xdtts_tensor_count() && d >= 0 && d < 3 ? tensor_table()[i].dims[d] : 0;
+}
+size_t xdtts_tensor_offset(int32_t i) { return i >= 0 && i < xdtts_tensor_count() ? tensor_table()[i].offset : 0; }
+size_t xdtts_tensor_total(void) { return tensor_total(); }
+
+static xdtts_status make_handle(std::vector<float> &&blob, int32_t device_id, xdtts_tacotron2 **out) {
+  return guard([&] {
+    if (!out) fail(XDTTS_ERR_BAD_ARG, "out handle pointer is null");
+    *out = nullptr;
+    auto h = std::make_unique<xdtts_tacotron2>();
+    h->blob = std::move(blob);
+    h->init(device_id);
+    *out = h.release();
+  });
+}
+
+xdtts_status xdtts_tacotron2_load(const char *dir, int32_t device_id, xdtts_tacotron2 **out) {
+  std::vector<float> blob;
+  xdtts_status st = guard([&] {
+    if (!dir) fail(XDTTS_ERR_BAD_ARG, "dir is null");
+    select_device(device_id);
+    load_container(dir, blob);
+  });
+  if (st != XDTTS_OK) return st;
+  return make_handle(std::move(blob), device_id, out);
+}
+
+xdtts_status xdtts_tacotron2_load_synthetic(uint32_t seed, float rec_scale, int32_t device_id,
+                                            xdtts_tacotron2 **out) {
+  std::vector<float> blob;
+  xdtts_status st = guard([&] {
+    select_device(device_id);
+    synthetic_blob(seed, rec_scale, blob);
+  });
+  if (st != XDTTS_OK) return st;
+  return make_handle(std::move(blob), device_id, out);
+}
+
+xdtts_status xdtts_tacotron2_load_blob(const float *blob, size_t n_floats, int32_t device_id,
+                                       xdtts_tacotron2 **out) {
+  std::vector<float> v;
+  xdtts_status st = guard([&] {
+    if (!blob) fail(XDTTS_ERR_BAD_ARG, "blob is null");
+    if (n_floats != tensor_total()) fail(XDTTS_ERR_BAD_ARG, "blob has %zu floats, expected %zu", n_floats, tensor_total());
+    select_device(device_id);
+    v.assign(blob, blob + n_floats);
+  });
+  if (st != XDTTS_OK) return st;
+  return make_handle(std::move(v), device_id, out);
+}
+
+xdtts_status xdtts_tacotron2_save(const xdtts_tacotron2 *h, const char *dir) {
+  return guard([&] {
+    if (!h || !dir) fail(XDTTS_ERR_BAD_ARG, "null argument");
+    save_container(dir, h->blob);
+  });
+}
+
+xdtts_status xdtts_tacotron2_get_tensor(const xdtts_tacotron2 *h, int32_t i, float *out) {
+  return guard([&] {
+    if (!h || !out || i < 0 || i >= xdtts_tensor_count()) fail(XDTTS_ERR_BAD_ARG, "bad tensor request");
+    const TensorInfo &t = tensor_table()[i];
+    std::memcpy(out, h->blob.data() + t.offset, t.numel * sizeof(float));
+  });
+}
+
+void xdtts_tacotron2_free(xdtts_tacotron2 *h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  delete h;
+}
+
+xdtts_status xdtts_tacotron2_sync(xdtts_tacotron2 *h) {
+  return guard([&] {
+    if (!h) fail(XDTTS_ERR_BAD_ARG, "null handle");
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+  });
+}
+
+static xdtts_infer_opts resolve_opts(const xdtts_infer_opts *opts) {
+  xdtts_infer_opts o;
+  xdtts_infer_opts_default(&o);
+  if (opts) o = *opts;
+  if (o.max_chunk <= 0) o.max_chunk = 100;
+  return o;
+}
+
+xdtts_status xdtts_tacotron2_infer_ids(xdtts_tacotron2 *h, const int64_t *ids, size_t n, const size_t *splits,
+                                       size_t n_splits, const xdtts_infer_opts *opts, float **mel,
+                                       size_t *n_frames) {
+  return guard([&] {
+    if (!h || !mel || !n_frames) fail(XDTTS_ERR_BAD_ARG, "null argument");
+    *mel = nullptr;
+    *n_frames = 0;
+    std::lock_guard<std::mutex> lk(h->mu);
+    const xdtts_infer_opts o = resolve_opts(opts);
+    std::vector<int64_t> padded;
+    std::vector<int> lens;
+    chunks_from_splits(ids, n, splits, n_splits, o.max_chunk, padded, lens);
+    int total = 0;
+    h->infer_batch_device(padded.data(), lens.data(), (int)lens.size(), o.max_chunk, o, nullptr, &total);
+    float *host = pinned_alloc((size_t)N_MEL * total);
+    hipError_t e = hipMemcpyAsync(host, h->mel_dev.p, (size_t)N_MEL * total * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+    if (e != hipSuccess) {
+      xdtts_free(host);
+      HIP_CHECK(e);
+    }
+    h->finish_timings();
+    *mel = host;
+    *n_frames = (size_t)total;
+  });
+}
+
+xdtts_status xdtts_tacotron2_infer_batch(xdtts_tacotron2 *h, const int64_t *ids, const int32_t *lens, int32_t B,
+                                         int32_t t_stride, const xdtts_infer_opts *opts,
+                                         const int32_t *fixed_steps_per_item, float **mels, size_t *n_frames) {
+  return guard([&] {
+    if (!h || !ids || !lens || !mels || !n_frames) fail(XDTTS_ERR_BAD_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    const xdtts_infer_opts o = resolve_opts(opts);
+    if (B <= 0) fail(XDTTS_ERR_BAD_ARG, "batch %d out of range", B);
+    for (int b = 0; b < B; ++b) mels[b] = nullptr;
+    const int T = o.max_chunk;
+    if (t_stride <= 0) fail(XDTTS_ERR_BAD_ARG, "t_stride must be positive");
+    std::vector<int64_t> padded((size_t)B * T, 0);
+    for (int b = 0; b < B; ++b) {
+      if (lens[b] > T) fail(XDTTS_ERR_TOO_LONG, "chunk %d has %d ids, window is %d", b, lens[b], T);
+      if (lens[b] > t_stride || lens[b] <= 0) fail(XDTTS_ERR_BAD_ARG, "chunk %d: bad length %d", b, lens[b]);
+      std::copy(ids + (size_t)b * t_stride, ids + (size_t)b * t_stride + lens[b], padded.begin() + (size_t)b * T);
+    }
+    int total = 0;
+    std::vector<int> F = h->infer_batch_device(padded.data(), lens, B, T, o, fixed_steps_per_item, &total);
+    std::vector<float> all((size_t)N_MEL * total);
+    HIP_CHECK(hipMemcpyAsync(all.data(), h->mel_dev.p, all.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    h->finish_timings();
+    int off = 0;
+    for (int b = 0; b < B; ++b) {
+      float *m = pinned_alloc((size_t)N_MEL * F[b]);
+      for (int r = 0; r < N_MEL; ++r)
+        std::memcpy(m + (size_t)r * F[b], all.data() + (size_t)r * total + off, sizeof(float) * F[b]);
+      mels[b] = m;
+      n_frames[b] = (size_t)F[b];
+      off += F[b];
+    }
+  });
+}
+
+xdtts_status xdtts_tacotron2_encoder(xdtts_tacotron2 *h, const int64_t *ids, int32_t T, float *memory,
+                                     float *processed_memory) {
+  return guard([&] {
+    if (!h || !ids || !memory || !processed_memory) fail(XDTTS_ERR_BAD_ARG, "null argument");
+    if (T <= 0 || T > T_MAX) fail(XDTTS_ERR_BAD_ARG, "T %d out of range", T);
+    for (int t = 0; t < T; ++t)
+      if (ids[t] < 0 || ids[t] >= N_SYMBOLS) fail(XDTTS_ERR_BAD_ARG, "id out of range");
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIP_CHECK(hipSetDevice(h->device));
+    h->ids.upload(ids, T, h->stream);
+    h->run_encoder(1, T);
+    HIP_CHECK(hipMemcpyAsync(memory, h->memory.p, (size_t)T * EMB * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipMemcpyAsync(processed_memory, h->pmem.p, (size_t)T * ATT_DIM * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+  });
+}
+
+xdtts_status xdtts_tacotron2_decoder(xdtts_tacotron2 *h, const float *memory, const float *processed_memory,
+                                     int32_t T, int32_t n_valid, const xdtts_infer_opts *opts, float *frames,
+                                     float *gates, size_t *n_frames) {
+  return guard([&] {
+    if (!h || !memory || !processed_memory || !frames || !n_frames) fail(XDTTS_ERR_BAD_ARG, "null argument");
+    if (T <= 0 || T > T_MAX || n_valid <= 0 || n_valid > T) fail(XDTTS_ERR_BAD_ARG, "bad T/n_valid");
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIP_CHECK(hipSetDevice(h->device));
+    const xdtts_infer_opts o = resolve_opts(opts);
+    h->memory.upload(memory, (size_t)T * EMB, h->stream);
+    h->pmem.upload(processed_memory, (size_t)T * ATT_DIM, h->stream);
+    int nv = n_valid;
+    h->n_valid.upload(&nv, 1, h->stream);
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    DecoderBufs d = h->decoder_bufs(1, T, h->memory.p, h->pmem.p, o);
+    std::vector<int> lim(1, std::min(o.fixed_steps > 0 ? o.fixed_steps : o.max_steps, o.max_steps));
+    HIP_CHECK(hipEventRecord(h->ev.e[0], h->stream));
+    HIP_CHECK(hipEventRecord(h->ev.e[1], h->stream));
+    h->last_steps = h->run_decoder(d, lim);
+    HIP_CHECK(hipEventRecord(h->ev.e[2], h->stream));
+    HIP_CHECK(hipEventRecord(h->ev.e[3], h->stream));
+    const int F = h->host_ctl[2];
+    HIP_CHECK(hipMemcpyAsync(frames, d.frames, (size_t)F * N_MEL * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    if (gates) HIP_CHECK(hipMemcpyAsync(gates, d.gates, (size_t)F * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    h->finish_timings();
+    *n_frames = (size_t)F;
+  });
+}
+
+xdtts_status xdtts_tacotron2_postnet(xdtts_tacotron2 *h, const float *frames, int32_t F, float *mel_out) {
+  return guard([&] {
+    if (!h || !frames || !mel_out || F <= 0) fail(XDTTS_ERR_BAD_ARG, "bad argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIP_CHECK(hipSetDevice(h->device));
+    h->frames.upload(frames, (size_t)F * N_MEL, h->stream);
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->mel_dev.alloc((size_t)N_MEL * F);
+    h->run_postnet(h->frames.p, F, h->mel_dev.p, F);
+    HIP_CHECK(hipMemcpyAsync(mel_out, h->mel_dev.p, (size_t)N_MEL * F * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(hipStreamSynchronize(h->stream));
+  });
+}
+
+xdtts_status xdtts_tacotron2_last_timings(const xdtts_tacotron2 *h, float ms[4], int32_t *steps) {
+  return guard([&] {
+    if (!h || !ms) fail(XDTTS_ERR_BAD_ARG, "null argument");
+    for (int i = 0; i < 4; ++i) ms[i] = h->last_ms[i];
+    if (steps) *steps = h->last_steps;
+  });
+}
+
+// ---- Griffin-Lim ---------------------------------------------------------------------------------
+
+xdtts_status xdtts_mel_filter_bank(float sample_rate, size_t n_fft, size_t n_mels, float fmin, float fmax_or_nan,
+                                   float *out) {
+  return guard([&] {
+    if (!out || n_fft < 2 || n_mels == 0 || !(sample_rate > 0)) fail(XDTTS_ERR_BAD_ARG, "bad filter bank request");
+    const double sr = sample_rate;
+    const double fmax = std::isnan(fmax_or_nan) ? sr / 2.0 : (double)fmax_or_nan;  // Option<f32>::None
+    const int nb = (int)(n_fft / 2 + 1), nm = (int)n_mels;
+    std::vector<double> mel_f(nm + 2);
+    const double m0 = hz_to_mel(fmin), m1 = hz_to_mel(fmax);
+    for (int i = 0; i < nm + 2; ++i) mel_f[i] = mel_to_hz(m0 + (m1 - m0) * i / (nm + 1));
+    for (int i = 0; i < nm; ++i) {
+      const double enorm = 2.0 / (mel_f[i + 2] - mel_f[i]);
+      for (int b = 0; b < nb; ++b) {
+        const double f = (sr / 2.0) * b / (nb - 1);
+        const double lower = (f - mel_f[i]) / (mel_f[i + 1] - mel_f[i]);
+        const double upper = (mel_f[i + 2] - f) / (mel_f[i + 2] - mel_f[i + 1]);
+        const double wv = std::min(lower, upper);
+        out[(size_t)i * nb + b] = (float)((wv > 0 ? wv : 0) * enorm);
+      }
+    }
+  });
+}
+
+xdtts_status xdtts_griffinlim_new(const float *mel_basis, size_t n_mels, size_t n_bins, size_t noverlap, float power,
+                                  size_t iters, float momentum, int32_t device_id, xdtts_griffinlim **out) {
+  return guard([&] {
+    if (!out) fail(XDTTS_ERR_BAD_ARG, "out handle pointer is null");
+    *out = nullptr;
+    if (!mel_basis || n_mels == 0 || n_bins < 2) fail(XDTTS_ERR_BAD_ARG, "bad mel basis");
+    const size_t n_fft = 2 * (n_bins - 1);
+    if (n_fft != 1024) fail(XDTTS_ERR_BAD_ARG, "n_fft %zu unsupported: the framed-FFT kernel is built for 1024", n_fft);
+    if (noverlap >= n_fft) fail(XDTTS_ERR_BAD_ARG, "noverlap %zu must be < n_fft %zu", noverlap, n_fft);
+    if (n_mels % 16 != 0) fail(XDTTS_ERR_BAD_ARG, "n_mels %zu must be a multiple of 16", n_mels);
+    if (!(power > 0) || momentum < 0) fail(XDTTS_ERR_BAD_ARG, "bad power/momentum");
+    select_device(device_id);
+    auto g = std::make_unique<xdtts_griffinlim>();
+    g->device = device_id;
+    g->n_mels = (int)n_mels;
+    g->nb = (int)n_bins;
+    g->n_fft = (int)n_fft;
+    g->hop = (int)(n_fft - noverlap);
+    g->iters = (int)iters;
+    g->power = power;
+    g->momentum = momentum;
+    HIP_CHECK(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+    g->ev.create();
+    std::vector<float> pinv;
+    host_pinv(mel_basis, (int)n_mels, (int)n_bins, pinv);
+    g->pinv.upload(pinv.data(), pinv.size(), g->stream);
+    std::vector<float2> tw(n_fft);
+    std::vector<float> win(n_fft);
+    const double PI = 3.14159265358979323846;
+    for (size_t k = 0; k < n_fft; ++k) {
+      tw[k] = make_float2((float)std::cos(2.0 * PI * k / n_fft), (float)(-std::sin(2.0 * PI * k / n_fft)));
+      win[k] = (float)(0.5 - 0.5 * std::cos(2.0 * PI * k / n_fft));  // periodic hann
+    }
+    g->tw.upload(tw.data(), tw.size(), g->stream);
+    g->win.upload(win.data(), win.size(), g->stream);
+    HIP_CHECK(hipStreamSynchronize(g->stream));
+    *out = g.release();
+  });
+}
+
+xdtts_status xdtts_griffinlim_set_seed(xdtts_griffinlim *g, uint32_t seed) {
+  return guard([&] {
+    if (!g) fail(XDTTS_ERR_BAD_ARG, "null handle");
+    g->seed = seed;
+  });
+}
+
+static void gl_fetch_audio(xdtts_griffinlim *g, int F, float **audio, size_t *n_samples) {
+  const size_t N = (size_t)g->hop * (size_t)(F - 1);
+  float *host = pinned_alloc(N);
+  hipError_t e = hipMemcpyAsync(host, g->audio.p, N * sizeof(float), hipMemcpyDeviceToHost, g->stream);
+  if (e != hipSuccess) {
+    xdtts_free(host);
+    HIP_CHECK(e);
+  }
+  g->finish_timings();
+  *audio = host;
+  *n_samples = N;
+}
+
+static void gl_run_from_device_mel(xdtts_griffinlim *g, const float *mel_dev_ptr, int F) {
+  GlBufs b = g->bufs(F);
+  HIP_CHECK(hipEventRecord(g->ev.e[0], g->stream));
+  g->mel_to_linear(mel_dev_ptr, F);
+  HIP_CHECK(hipEventRecord(g->ev.e[1], g->stream));
+  g->iterate(b, nullptr, g->iters);
+  HIP_CHECK(hipEventRecord(g->ev.e[2], g->stream));
+}
+
+xdtts_status xdtts_griffinlim_infer(xdtts_griffinlim *g, const float *mel, size_t n_mels, size_t n_frames,
+                                    float **audio, size_t *n_samples) {
+  return guard([&] {
+    if (!g || !mel || !audio || !n_samples) fail(XDTTS_ERR_BAD_ARG, "null argument");
+    *audio = nullptr;
+    *n_samples = 0;
+    if ((int)n_mels != g->n_mels) fail(XDTTS_ERR_BAD_ARG, "mel has %zu rows, basis has %d", n_mels, g->n_mels);
+    if (n_frames < 2) fail(XDTTS_ERR_BAD_ARG, "need at least 2 frames, got %zu", n_frames);
+    std::lock_guard<std::mutex> lk(g->mu);
+    HIP_CHECK(hipSetDevice(g->device));
+    g->mel_in.upload(mel, n_mels * n_frames, g->stream);
+    HIP_CHECK(hipStreamSynchronize(g->stream));
+    gl_run_from_device_mel(g, g->mel_in.p, (int)n_frames);
+    gl_fetch_audio(g, (int)n_frames, audio, n_samples);
+  });
+}
+
+xdtts_status xdtts_griffinlim_mel_to_linear(xdtts_griffinlim *g, const float *mel, size_t n_mels, size_t n_frames,
+                                            float *S_out) {
+  return guard([&] {
+    if (!g || !mel || !S_out || n_frames == 0) fail(XDTTS_ERR_BAD_ARG, "bad argument");
+    if ((int)n_mels != g->n_mels) fail(XDTTS_ERR_BAD_ARG, "mel has %zu rows, basis has %d", n_mels, g->n_mels);
+    std::lock_guard<std::mutex> lk(g->mu);
+    HIP_CHECK(hipSetDevice(g->device));
+    const int F = (int)n_frames;
+    g->mel_in.upload(mel, n_mels * n_frames, g->stream);
+    HIP_CHECK(hipStreamSynchronize(g->stream));
+    g->bufs(F);
+    g->mel_to_linear(g->mel_in.p, F);
+    // S is [F][nb] on the device; the boundary layout is the crate's (nb x F)
+    g->frames.alloc((size_t)F * g->n_fft);
+    launch_transpose(g->S.p, g->frames.p, F, g->nb, g->stream);
+    HIP_CHECK(hipMemcpyAsync(S_out, g->frames.p, (size_t)F * g->nb * sizeof(float), hipMemcpyDeviceToHost, g->stream));
+    HIP_CHECK(hipStreamSynchronize(g->stream));
+  });
+}
+
+xdtts_status xdtts_griffinlim_infer_linear(xdtts_griffinlim *g, const float *S, const float *phase0, size_t n_frames,
+                                           size_t iters, float **audio, size_t *n_samples) {
+  return guard([&] {
+    if (!g || !S || !audio || !n_samples) fail(XDTTS_ERR_BAD_ARG, "null argument");
+    *audio = nullptr;
+    *n_samples = 0;
+    if (n_frames < 2) fail(XDTTS_ERR_BAD_ARG, "need at least 2 frames, got %zu", n_frames);
+    std::lock_guard<std::mutex> lk(g->mu);
+    HIP_CHECK(hipSetDevice(g->device));
+    const int F = (int)n_frames;
+    GlBufs b = g->bufs(F);
+    // boundary layout (nb x F) -> device layout [F][nb]
+    g->frames.upload(S, (size_t)F * g->nb, g->stream);
+    launch_transpose(g->frames.p, g->S.p, g->nb, F, g->stream);
+    const float *p0 = nullptr;
+    if (phase0) {
+      g->phase0.upload(phase0, (size_t)F * g->nb * 2, g->stream);
+      p0 = g->phase0.p;
+    }
+    HIP_CHECK(hipStreamSynchronize(g->stream));
+    HIP_CHECK(hipEventRecord(g->ev.e[0], g->stream));
+    HIP_CHECK(hipEventRecord(g->ev.e[1], g->stream));
+    g->iterate(b, p0, iters ? (int)iters : g->iters);
+    HIP_CHECK(hipEventRecord(g->ev.e[2], g->stream));
+    gl_fetch_audio(g, F, audio, n_samples);
+  });
+}
+
+xdtts_status xdtts_griffinlim_last_timings(const xdtts_griffinlim *g, float ms[3]) {
+  return guard([&] {
+    if (!g || !ms) fail(XDTTS_ERR_BAD_ARG, "null argument");
+    for (int i = 0; i < 3; ++i) ms[i] = g->last_ms[i];
+  });
+}
+
+void xdtts_griffinlim_free(xdtts_griffinlim *g) {
+  if (!g) return;
+  (void)hipSetDevice(g->device);
+  if (g->stream) (void)hipStreamSynchronize(g->stream);
+  delete g;
+}
+
+// ---- XdTts::infer (src/lib.rs:110-159) --------------------------------------------------------------
+
+xdtts_status xdtts_synthesize_ids(xdtts_tacotron2 *h, xdtts_griffinlim *g, const int64_t *ids, size_t n,
+                                  const size_t *splits, size_t n_splits, const xdtts_infer_opts *opts, float **mel,
+                                  size_t *n_frames, float **audio, size_t *n_samples) {
+  return guard([&] {
+    if (!h || !g || !mel || !n_frames || !audio || !n_samples) fail(XDTTS_ERR_BAD_ARG, "null argument");
+    if (h->device != g->device) fail(XDTTS_ERR_BAD_ARG, "tacotron2 and griffin-lim handles live on different devices");
+    *mel = nullptr;
+    *audio = nullptr;
+    *n_frames = *n_samples = 0;
+    std::lock_guard<std::mutex> lk(h->mu);
+    std::lock_guard<std::mutex> lk2(g->mu);
+    const xdtts_infer_opts o = resolve_opts(opts);
+    std::vector<int64_t> padded;
+    std::vector<int> lens;
+    chunks_from_splits(ids, n, splits, n_splits, o.max_chunk, padded, lens);
+    int total = 0;
+    h->infer_batch_device(padded.data(), lens.data(), (int)lens.size(), o.max_chunk, o, nullptr, &total);
+    if (total < 2) fail(XDTTS_ERR_BAD_ARG, "mel has %d frame(s); the vocoder needs at least 2", total);
+    float *mel_host = pinned_alloc((size_t)N_MEL * total);
+    HIP_CHECK(hipMemcpyAsync(mel_host, h->mel_dev.p, (size_t)N_MEL * total * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    h->finish_timings();  // stream sync: the mel is complete in HBM before the vocoder stream reads it
+    gl_run_from_device_mel(g, h->mel_dev.p, total);
+    gl_fetch_audio(g, total, audio, n_samples);
+    *mel = mel_host;
+    *n_frames = (size_t)total;
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,98 @@
+// common.h -- shared declarations of libxdtts_hip.so (MI355X / gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/xdtts.h"
+
+namespace xdtts {
+
+// ---- model constants: src/tacotron2/mod.rs:205-208 + NVIDIA Tacotron2 defaults ------------
+constexpr int N_SYMBOLS = 148;  // mod.rs:90-122
+constexpr int EMB = 512;        // encoder_embedding_dim, mod.rs:207
+constexpr int ENC_CONVS = 3;
+constexpr int ENC_K = 5;
+constexpr int ENC_H = 256;      // BiLSTM hidden per direction
+constexpr int N_MEL = 80;       // mod.rs:208
+constexpr int PRENET = 256;
+constexpr int ATT_RNN = 1024;   // mod.rs:205
+constexpr int DEC_RNN = 1024;   // mod.rs:206
+constexpr int ATT_DIM = 128;
+constexpr int LOC_F = 32;
+constexpr int LOC_K = 31;
+constexpr int POST_CONVS = 5;
+constexpr int POST_CH = 512;
+constexpr int POST_K = 5;
+constexpr int T_MAX = 512;      // attention kernel LDS budget
+constexpr int ATT_IN = PRENET + EMB;              // 768
+constexpr int ATT_COLS = ATT_IN + ATT_RNN;        // 1792 packed columns [W_ih | W_hh]
+constexpr int DEC_IN = ATT_RNN + EMB;             // 1536
+constexpr int DEC_COLS = DEC_IN + DEC_RNN;        // 2560
+constexpr int PROJ_IN = DEC_RNN + EMB;            // 1536
+
+// ---- error plumbing -----------------------------------------------------------------------
+struct Error : std::runtime_error {
+  xdtts_status code;
+  Error(xdtts_status c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+void set_last_error(const char *msg);
+[[noreturn]] void fail(xdtts_status code, const char *fmt, ...);
+
+#define HIP_CHECK(expr)                                                                       \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      ::xdtts::fail(e_ == hipErrorOutOfMemory ? XDTTS_ERR_OOM : XDTTS_ERR_HIP, "%s: %s (%s:%d)", \
+                    #expr, hipGetErrorString(e_), __FILE__, __LINE__);                        \
+  } while (0)
+
+// ---- counter-based RNG (specification shared with oracle/, implemented independently) ----
+__host__ __device__ inline uint32_t mix32(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x7feb352dU;
+  x ^= x >> 15;
+  x *= 0x846ca68bU;
+  x ^= x >> 16;
+  return x;
+}
+__host__ __device__ inline uint32_t rng_u32(uint32_t seed, uint32_t stream, uint32_t idx) {
+  return mix32(mix32(mix32(seed ^ 0x9E3779B9U) + stream) + idx);
+}
+__host__ __device__ inline float rng_uniform(uint32_t seed, uint32_t stream, uint32_t idx) {
+  return (float)(rng_u32(seed, stream, idx) >> 8) * (1.0f / 16777216.0f);
+}
+
+// ---- device memory helper -------------------------------------------------------------------
+template <class T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  void alloc(size_t count) {
+    if (count <= n) return;
+    release();
+    HIP_CHECK(hipMalloc((void **)&p, count * sizeof(T)));
+    n = count;
+  }
+  void upload(const T *src, size_t count, hipStream_t s) {
+    alloc(count);
+    HIP_CHECK(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, s));
+  }
+};
+
+}  // namespace xdtts

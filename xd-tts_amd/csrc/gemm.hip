@@ -1,0 +1,184 @@
+// gemm.hip -- C = act(A W^T + bias) (+R) in exact fp32 on the gfx950 matrix cores
+// (v_mfma_f32_16x16x4_f32: f32 in, f32 accumulate, bit-equal to an fmaf chain).
+//
+// Every dense contraction off the per-frame critical path goes through this one kernel:
+//   * post-net conv1d x5 (src/tacotron2/mod.rs:347, graph postnet.onnx) and encoder conv1d x3
+//     (mod.rs:379): with time-major activations [T][C] and weights re-laid as [co][k][ci] a conv
+//     row is one contiguous window of the zero-padded input, i.e. a GEMM whose A rows overlap
+//     (lda = C instead of k*C) -- implicit GEMM with no im2col buffer;
+//   * BiLSTM input projections, the attention memory layer, and the Griffin-Lim mel->linear
+//     product (pinv(mel_basis) . exp(mel)).
+// Tile: 64x64 per 256-thread block (4 waves as 2x2, 32x32 per wave = 2x2 MFMA tiles), K-slab 16
+// staged through LDS with a register prefetch of the next slab.  Within a slab the contraction
+// index is permuted (k = 4*(lane>>4) + kk) so each lane fetches its four K values of a tile row
+// with one ds_read_b128.
+#include "kernels.h"
+
+namespace xdtts {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 64, BN = 64, BK = 16, LDS_LD = 20;  // 80-byte rows: 16-B aligned float4 reads
+
+__global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float As[BM * LDS_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[BN * LDS_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN, z = blockIdx.z;
+  const float *A = g.A + (size_t)z * g.strideA;
+  float *C = g.C + (size_t)z * g.strideC;
+  const float *R = g.R ? g.R + (size_t)z * g.strideR : nullptr;
+
+  // global -> LDS assignment: thread loads one float4 of A and one of W per slab
+  const int lr = tid >> 2, lc = (tid & 3) * 4;
+  const bool a_ok = m0 + lr < g.M, b_ok = n0 + lr < g.N;
+  const float *a_src = A + (size_t)(m0 + lr) * g.lda + lc;
+  const float *b_src = g.W + (size_t)(n0 + lr) * g.K + lc;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float4 pa = a_ok ? *reinterpret_cast<const float4 *>(a_src) : zero4;
+  float4 pb = b_ok ? *reinterpret_cast<const float4 *>(b_src) : zero4;
+  const int fi = lane & 15, fg = lane >> 4;
+  for (int k0 = 0; k0 < g.K; k0 += BK) {
+    __syncthreads();  // previous slab fully consumed
+    *reinterpret_cast<float4 *>(&As[lr * LDS_LD + lc]) = pa;
+    *reinterpret_cast<float4 *>(&Bs[lr * LDS_LD + lc]) = pb;
+    __syncthreads();
+    if (k0 + BK < g.K) {  // prefetch the next slab while this one is multiplied
+      pa = a_ok ? *reinterpret_cast<const float4 *>(a_src + k0 + BK) : zero4;
+      pb = b_ok ? *reinterpret_cast<const float4 *>(b_src + k0 + BK) : zero4;
+    }
+    float4 af[2], bf[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      af[i] = *reinterpret_cast<const float4 *>(&As[(wm * 32 + i * 16 + fi) * LDS_LD + fg * 4]);
+      bf[i] = *reinterpret_cast<const float4 *>(&Bs[(wn * 32 + i * 16 + fi) * LDS_LD + fg * 4]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+      }
+  }
+  // epilogue: D register r of lane l holds row (l>>4)*4 + r, column l&15 of its 16x16 tile
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn * 32 + j * 16 + fi;
+      if (n >= g.N) continue;
+      const float bz = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * 32 + i * 16 + fg * 4 + r;
+        if (m >= g.M) continue;
+        float v = acc[i][j][r] + bz;
+        if (g.act == 1) v = fmaxf(v, 0.f);
+        else if (g.act == 2) v = tanhf(v);
+        else if (g.act == 3) v = powf(fmaxf(v, 0.f), g.p);
+        if (R) v += R[(size_t)m * g.ldr + n];
+        if (g.transpose_out) C[(size_t)n * g.ldc + m] = v;
+        else C[(size_t)m * g.ldc + n] = v;
+      }
+    }
+}
+
+// ids -> embedding rows, written into the interior of the zero-padded conv input
+__global__ void k_embed(const int64_t *ids, const float *__restrict__ emb, float *xpad, int T, int pad) {
+  const int t = blockIdx.x, b = blockIdx.y;
+  const int id = (int)ids[(size_t)b * T + t];
+  const float4 *src = reinterpret_cast<const float4 *>(emb + (size_t)id * EMB);
+  float4 *dst = reinterpret_cast<float4 *>(xpad + ((size_t)b * (T + 2 * pad) + pad + t) * EMB);
+  for (int i = threadIdx.x; i < EMB / 4; i += blockDim.x) dst[i] = src[i];
+}
+
+__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// Encoder BiLSTM recurrence.  One block per (direction, chunk); thread r owns gate row r of the
+// 1024 (i,f,g,o x 256); W_hh is stored transposed so the 1024 threads read consecutive floats.
+// The input projection W_ih x + b was hoisted out as one GEMM over all T.
+__global__ __launch_bounds__(1024) void k_bilstm(const float *__restrict__ xproj,
+                                                 const float *__restrict__ whhT_f,
+                                                 const float *__restrict__ whhT_b, float *memory, int B,
+                                                 int T) {
+  const int dir = blockIdx.x, b = blockIdx.y, r = threadIdx.x;
+  const float *whhT = dir ? whhT_b : whhT_f;
+  const float *xp = xproj + ((size_t)dir * B + b) * T * (4 * ENC_H);
+  __shared__ float h[ENC_H], gates[4 * ENC_H];
+  float c = 0.f;
+  if (r < ENC_H) h[r] = 0.f;
+  __syncthreads();
+  for (int s = 0; s < T; ++s) {
+    const int t = dir ? T - 1 - s : s;
+    float a0 = xp[(size_t)t * (4 * ENC_H) + r], a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 8
+    for (int j = 0; j < ENC_H; j += 4) {
+      a0 = fmaf(whhT[(size_t)(j + 0) * (4 * ENC_H) + r], h[j + 0], a0);
+      a1 = fmaf(whhT[(size_t)(j + 1) * (4 * ENC_H) + r], h[j + 1], a1);
+      a2 = fmaf(whhT[(size_t)(j + 2) * (4 * ENC_H) + r], h[j + 2], a2);
+      a3 = fmaf(whhT[(size_t)(j + 3) * (4 * ENC_H) + r], h[j + 3], a3);
+    }
+    gates[r] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (r < ENC_H) {
+      const float ig = sigm(gates[r]), fg = sigm(gates[ENC_H + r]);
+      const float gg = tanhf(gates[2 * ENC_H + r]), og = sigm(gates[3 * ENC_H + r]);
+      c = fmaf(fg, c, ig * gg);
+      const float hn = og * tanhf(c);
+      h[r] = hn;
+      memory[((size_t)b * T + t) * EMB + dir * ENC_H + r] = hn;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void k_transpose(const float *in, float *out, int rows, int cols) {
+  __shared__ float tile[32][33];
+  const int x = blockIdx.x * 32 + threadIdx.x, y0 = blockIdx.y * 32;
+  for (int j = threadIdx.y; j < 32; j += blockDim.y)
+    if (x < cols && y0 + j < rows) tile[j][threadIdx.x] = in[(size_t)(y0 + j) * cols + x];
+  __syncthreads();
+  const int ox = blockIdx.y * 32 + threadIdx.x, oy0 = blockIdx.x * 32;
+  for (int j = threadIdx.y; j < 32; j += blockDim.y)
+    if (ox < rows && oy0 + j < cols) out[(size_t)(oy0 + j) * rows + ox] = tile[threadIdx.x][j];
+}
+
+}  // namespace
+
+void launch_gemm_nt(const GemmArgs &g, hipStream_t s) {
+  if (g.K % BK != 0 || g.lda % 4 != 0) fail(XDTTS_ERR_BAD_ARG, "gemm: K=%d lda=%ld not supported", g.K, g.lda);
+  dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.batch);
+  hipLaunchKernelGGL(k_gemm_nt, grid, dim3(256), 0, s, g);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_embed(const int64_t *ids, const float *emb, float *xpad, int B, int T, int pad, hipStream_t s) {
+  hipLaunchKernelGGL(k_embed, dim3(T, B), dim3(128), 0, s, ids, emb, xpad, T, pad);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_bilstm(const float *xproj, const float *whhT_fwd, const float *whhT_bwd, float *memory, int B,
+                   int T, hipStream_t s) {
+  hipLaunchKernelGGL(k_bilstm, dim3(2, B), dim3(1024), 0, s, xproj, whhT_fwd, whhT_bwd, memory, B, T);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_transpose(const float *in, float *out, int rows, int cols, hipStream_t s) {
+  hipLaunchKernelGGL(k_transpose, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, s, in, out, rows, cols);
+  HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace xdtts

@@ -1,0 +1,255 @@
+// griffinlim.hip -- Griffin-Lim phase recovery as HIP kernels for gfx950.
+//
+// Replaces GriffinLim::infer of the un-vendored `griffin-lim` crate (called at src/lib.rs:141,
+// parameters fixed at src/tacotron2/mod.rs:453-456: n_fft 1024, hop 256, 30 iterations, momentum
+// 0.99).  One iteration is  inverse = ISTFT(S*angles); rebuilt = STFT(inverse);
+// angles = normalise(rebuilt - m/(1+m) * previous rebuilt).
+//
+// Framed FFTs: one 64-lane wavefront per frame.  A 1024-point real transform is done as a
+// 512-point complex Stockham FFT, radix 8 x 3 passes, 8 points per lane held in registers, with
+// LDS used only for the two inter-pass exchanges (conflict-free: lanes touch consecutive float2).
+// The real<->complex split/merge twiddle step is fused into the first/last pass, the synthesis
+// and analysis windows and the magnitude projection are fused into the loads/stores, so one
+// iteration touches S, angles, the previous rebuilt spectrum and the signal exactly once each.
+#include "kernels.h"
+
+namespace xdtts {
+
+namespace {
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+  return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
+}
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
+__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }  // * (-i)
+
+// forward 8-point DFT, natural-order output
+__device__ __forceinline__ void fft8(float2 (&v)[8]) {
+  const float h = 0.70710678118654752440f;
+  float2 b0 = cadd(v[0], v[4]), b4 = csub(v[0], v[4]);
+  float2 b1 = cadd(v[1], v[5]), b5 = csub(v[1], v[5]);
+  float2 b2 = cadd(v[2], v[6]), b6 = csub(v[2], v[6]);
+  float2 b3 = cadd(v[3], v[7]), b7 = csub(v[3], v[7]);
+  b5 = make_float2(h * (b5.x + b5.y), h * (b5.y - b5.x));   // * (1-i)/sqrt2
+  b6 = mul_mi(b6);                                           // * (-i)
+  b7 = make_float2(h * (b7.y - b7.x), -h * (b7.x + b7.y));  // * (-1-i)/sqrt2
+  float2 d0 = cadd(b0, b2), d1 = csub(b0, b2), d2 = cadd(b1, b3), d3 = mul_mi(csub(b1, b3));
+  v[0] = cadd(d0, d2);
+  v[4] = csub(d0, d2);
+  v[2] = cadd(d1, d3);
+  v[6] = csub(d1, d3);
+  d0 = cadd(b4, b6);
+  d1 = csub(b4, b6);
+  d2 = cadd(b5, b7);
+  d3 = mul_mi(csub(b5, b7));
+  v[1] = cadd(d0, d2);
+  v[5] = csub(d0, d2);
+  v[3] = cadd(d1, d3);
+  v[7] = csub(d1, d3);
+}
+
+// 512-point forward complex FFT of one wave.  In: v[r] = x[lane + 64 r].  Runs Stockham passes
+// Ns = 1 and 8 through `buf` (512 float2 of LDS owned by this wave) and the twiddle + butterfly
+// of pass Ns = 64; on return v[r] = X[lane + 64 r] (natural order), nothing left in LDS.
+// Must be called by all waves of the block (contains __syncthreads()).
+__device__ __forceinline__ void fft512(float2 (&v)[8], float2 *buf, const float2 *__restrict__ tw, int lane) {
+  // pass Ns = 1: no twiddles; out[8 j + r]
+  fft8(v);
+#pragma unroll
+  for (int r = 0; r < 8; ++r) buf[8 * lane + r] = v[r];
+  __syncthreads();
+  // pass Ns = 8: twiddle e^{-2 pi i r k / 64}, k = j & 7 -> table index r*k*16
+  {
+    const int k = lane & 7;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = buf[lane + 64 * r];
+#pragma unroll
+    for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], tw[r * k * 16]);
+    fft8(v);
+    __syncthreads();
+    const int j0 = (lane >> 3) * 64 + k;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) buf[j0 + 8 * r] = v[r];
+  }
+  __syncthreads();
+  // pass Ns = 64: twiddle e^{-2 pi i r k / 512}, k = j -> table index r*k*2; out[j + 64 r]
+#pragma unroll
+  for (int r = 0; r < 8; ++r) v[r] = buf[lane + 64 * r];
+#pragma unroll
+  for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], tw[r * lane * 2]);
+  fft8(v);
+}
+
+constexpr int FRAMES_PER_BLOCK = 4;  // one wave per frame
+
+// ISTFT, per-frame half: X = S * angles (513 bins) -> irfft(1024) -> synthesis window ->
+// frames[f][1024].  The Hermitian merge (X -> packed 512-point spectrum) is fused into the loads.
+__global__ __launch_bounds__(256) void k_istft_frames(GlBufs g) {
+  __shared__ float2 lds[FRAMES_PER_BLOCK][512];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = blockIdx.x * FRAMES_PER_BLOCK + wave;
+  const bool ok = fr < g.F;
+  const int f = ok ? fr : g.F - 1;
+  const float *S = g.S + (size_t)f * g.nb;
+  const float2 *A = g.ang + (size_t)f * g.nb;
+  float2 v[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int k = lane + 64 * r, kc = 512 - k;
+    float2 xk = A[k], xc = A[kc];
+    const float sk = S[k], sc = S[kc];
+    xk = make_float2(xk.x * sk, xk.y * sk);
+    xc = make_float2(xc.x * sc, xc.y * sc);
+    if (k == 0) {  // irfft ignores the imaginary part of DC and Nyquist
+      xk.y = 0.f;
+      xc.y = 0.f;
+    }
+    const float2 e = make_float2(0.5f * (xk.x + xc.x), 0.5f * (xk.y - xc.y));   // (X[k] + conj X[512-k]) / 2
+    const float2 d = make_float2(0.5f * (xk.x - xc.x), 0.5f * (xk.y + xc.y));   // (X[k] - conj X[512-k]) / 2
+    const float2 o = cmul(d, cconj(g.tw[k]));                                   // * e^{+2 pi i k / 1024}
+    // Z = E + i O ; feed conj(Z) to the forward FFT (inverse = conj(FFT(conj Z)) / 512)
+    v[r] = make_float2(e.x - o.y, -(e.y + o.x));
+  }
+  fft512(v, lds[wave], g.tw, lane);
+  if (!ok) return;
+  float2 *out = reinterpret_cast<float2 *>(g.frames + (size_t)f * g.n_fft);
+  const float2 *win = reinterpret_cast<const float2 *>(g.win);
+  const float sc = 1.0f / 512.0f;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int m = lane + 64 * r;
+    const float2 w = win[m];
+    out[m] = make_float2(v[r].x * sc * w.x, -v[r].y * sc * w.y);  // x[2m] = Re z, x[2m+1] = Im z
+  }
+}
+
+// Overlap-add + window sum-of-squares normalisation + centre trim:
+//   y[n] = sum_j frames[j][n + 512 - 256 j] / sum_j win^2[n + 512 - 256 j],  n in [0, hop (F-1))
+__global__ void k_overlap_add(GlBufs g, float *y) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const int N = g.hop * (g.F - 1);
+  if (n >= N) return;
+  const int p = n + g.n_fft / 2;
+  int j1 = p / g.hop;
+  if (j1 > g.F - 1) j1 = g.F - 1;
+  int j0 = (p - g.n_fft + g.hop) / g.hop;  // ceil((p - (n_fft-1)) / hop)
+  if (p - g.n_fft + 1 <= 0) j0 = 0;
+  float acc = 0.f, wss = 0.f;
+  for (int j = j0; j <= j1; ++j) {
+    const int i = p - j * g.hop;
+    const float w = g.win[i];
+    acc += g.frames[(size_t)j * g.n_fft + i];
+    wss = fmaf(w, w, wss);
+  }
+  y[n] = wss > 1.17549435e-38f ? acc / wss : acc;
+}
+
+// STFT + phase update, one wave per frame: reflect-padded gather of y, analysis window,
+// rfft(1024), then  a = rebuilt - alpha * tprev;  tprev = rebuilt;  angles = a / (|a| + 1e-16).
+__global__ __launch_bounds__(256) void k_stft_update(GlBufs g, float alpha) {
+  __shared__ float2 lds[FRAMES_PER_BLOCK][512];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = blockIdx.x * FRAMES_PER_BLOCK + wave;
+  const bool ok = fr < g.F;
+  const int f = ok ? fr : g.F - 1;
+  const int N = g.hop * (g.F - 1);
+  const float2 *win = reinterpret_cast<const float2 *>(g.win);
+  float2 v[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int m = lane + 64 * r;
+    int p0 = f * g.hop + 2 * m - g.n_fft / 2, p1 = p0 + 1;
+    p0 = p0 < 0 ? -p0 : p0;
+    p1 = p1 < 0 ? -p1 : p1;
+    p0 = p0 >= N ? 2 * (N - 1) - p0 : p0;
+    p1 = p1 >= N ? 2 * (N - 1) - p1 : p1;
+    const float2 w = win[m];
+    v[r] = make_float2(g.y[p0] * w.x, g.y[p1] * w.y);
+  }
+  float2 *buf = lds[wave];
+  fft512(v, buf, g.tw, lane);
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 8; ++r) buf[lane + 64 * r] = v[r];
+  __syncthreads();
+  if (!ok) return;
+  float2 *ang = g.ang + (size_t)f * g.nb;
+  float2 *tp = g.tprev + (size_t)f * g.nb;
+#pragma unroll
+  for (int r = 0; r <= 8; ++r) {
+    const int k = lane + 64 * r;
+    if (r == 8 && lane != 0) break;
+    const float2 zk = buf[k & 511], zc = buf[(512 - k) & 511];
+    const float2 e = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));  // (Z[k] + conj Z[512-k]) / 2
+    const float2 o = make_float2(0.5f * (zk.y + zc.y), 0.5f * (zc.x - zk.x));  // (Z[k] - conj Z[512-k]) / (2i)
+    const float2 twk = k == 512 ? make_float2(-1.f, 0.f) : g.tw[k];
+    const float2 x = cadd(e, cmul(twk, o));
+    const float2 pv = tp[k];
+    tp[k] = x;
+    const float2 a = make_float2(fmaf(-alpha, pv.x, x.x), fmaf(-alpha, pv.y, x.y));
+    const float mag = sqrtf(fmaf(a.x, a.x, a.y * a.y)) + 1e-16f;
+    ang[k] = make_float2(a.x / mag, a.y / mag);
+  }
+}
+
+// angles = exp(2 pi i u), u from the counter RNG keyed (seed, frame*nb + bin); or a caller-supplied
+// phase0 [nb][F][2].  Also clears tprev (rebuilt = 0 before the first iteration).
+__global__ void k_phase_init(GlBufs g, uint32_t seed, const float *phase0) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= g.F * g.nb) return;
+  const int f = i / g.nb, k = i % g.nb;
+  float2 a;
+  if (phase0) {
+    a = make_float2(phase0[((size_t)k * g.F + f) * 2], phase0[((size_t)k * g.F + f) * 2 + 1]);
+  } else {
+    const float u = rng_uniform(seed, 0x47u, (uint32_t)i);
+    float sn, cs;
+    sincospif(2.0f * u, &sn, &cs);
+    a = make_float2(cs, sn);
+  }
+  g.ang[i] = a;
+  g.tprev[i] = make_float2(0.f, 0.f);
+}
+
+// exp-decompress the natural-log mel and transpose (80 x F) -> (F x 80) for the pinv GEMM
+__global__ void k_exp_transpose(const float *mel, float *out, int n_mels, int F) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_mels * F) return;
+  const int f = i / n_mels, m = i % n_mels;
+  out[i] = expf(mel[(size_t)m * F + f]);
+}
+
+}  // namespace
+
+void launch_gl_exp_transpose(const float *mel_80xF, float *out_Fx80, int n_mels, int F, hipStream_t s) {
+  const int n = n_mels * F;
+  hipLaunchKernelGGL(k_exp_transpose, dim3((n + 255) / 256), dim3(256), 0, s, mel_80xF, out_Fx80, n_mels, F);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_gl_phase_init(const GlBufs &g, uint32_t seed, const float *phase0_dev, hipStream_t s) {
+  const int n = g.F * g.nb;
+  hipLaunchKernelGGL(k_phase_init, dim3((n + 255) / 256), dim3(256), 0, s, g, seed, phase0_dev);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_gl_iteration(const GlBufs &g, float alpha, hipStream_t s) {
+  const int nblk = (g.F + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK;
+  const int N = g.hop * (g.F - 1);
+  hipLaunchKernelGGL(k_istft_frames, dim3(nblk), dim3(256), 0, s, g);
+  hipLaunchKernelGGL(k_overlap_add, dim3((N + 255) / 256), dim3(256), 0, s, g, g.y);
+  hipLaunchKernelGGL(k_stft_update, dim3(nblk), dim3(256), 0, s, g, alpha);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_gl_final(const GlBufs &g, float *audio, hipStream_t s) {
+  const int nblk = (g.F + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK;
+  const int N = g.hop * (g.F - 1);
+  hipLaunchKernelGGL(k_istft_frames, dim3(nblk), dim3(256), 0, s, g);
+  hipLaunchKernelGGL(k_overlap_add, dim3((N + 255) / 256), dim3(256), 0, s, g, audio);
+  HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace xdtts

@@ -1,0 +1,81 @@
+// kernels.h -- host-side launch interface of the HIP kernels (gfx950).
+#pragma once
+#include "common.h"
+#include "weights.h"
+
+namespace xdtts {
+
+// ---- decoder loop (src/tacotron2/mod.rs:272-342) ---------------------------------------------
+// Device-side state of B independent chunks decoded in lock-step.  One "step" = one
+// decoder_iter.onnx call of the reference (mod.rs:304) for every still-active chunk.
+struct DecoderBufs {
+  int B, T;
+  const float *memory;  // [B][T][512]   encoder output (mod.rs:382)
+  const float *pmem;    // [B][T][128]   processed_memory (mod.rs:383)
+  const int *n_valid;   // [B]           un-padded length -> mask (mod.rs:219-220)
+  float *att_h[2];      // [B][1024]     ping-pong by step parity
+  float *att_c;         // [B][1024]
+  float *dec_h[2];      // [B][1024]
+  float *dec_c;         // [B][1024]
+  float *aw, *awc;      // [B][T]        attention_weights, attention_weights_cum
+  float *ctx;           // [B][512]      attention_context
+  float *x;             // [B][256]      prenet output
+  float *q;             // [B][128]      processed query
+  float *frames;        // [B][max_steps][80]  decoder_output per step (time-major)
+  float *gates;         // [B][max_steps]      gate_prediction logits
+  int *nframes;         // [B] in: step limit; out: frames emitted (gate may lower it)
+  int *ctl;             // [0] step counter, [1] ticket
+  int max_steps;
+  int use_gate;
+  float gate_threshold;
+  int dropout_mode;
+  uint32_t dropout_seed, item_base;
+};
+
+// Enqueues `nsteps` decoder steps on `s` (6 kernels each).
+void launch_decoder_steps(const DecoderBufs &d, const DeviceWeights &w, int nsteps, hipStream_t s);
+// Zeroes the recurrent state (DecoderState::new, mod.rs:202-233) and sets the step limits.
+void launch_decoder_init(const DecoderBufs &d, const int *limits_dev, hipStream_t s);
+
+// ---- NT GEMM on the f32 MFMA: C = act(A W^T + bias) (+R) ---------------------------------------
+struct GemmArgs {
+  const float *A;
+  long lda, strideA;  // row m of item z starts at A + z*strideA + m*lda (rows may overlap: conv)
+  const float *W;     // [N][K], K contiguous
+  const float *bias;  // [N] or null
+  float *C;
+  long ldc, strideC;
+  const float *R;     // residual, indexed like an un-transposed C; or null
+  long ldr, strideR;
+  int M, N, K, batch;
+  int act;            // 0 none, 1 relu, 2 tanh, 3 pow(max(x,0), p)
+  int transpose_out;  // store C[n*ldc + m]
+  float p;
+};
+void launch_gemm_nt(const GemmArgs &g, hipStream_t s);
+
+// ---- encoder (encoder.onnx, mod.rs:379) ---------------------------------------------------------
+// ids [B][T] -> rows [pad, pad+T) of the zero-padded time-major buffer xpad [B][T+2*pad][512]
+void launch_embed(const int64_t *ids, const float *emb, float *xpad, int B, int T, int pad, hipStream_t s);
+// xproj [2][B][T][1024] (W_ih x + b), WhhT[dir] [256][1024] -> memory [B][T][512]
+void launch_bilstm(const float *xproj, const float *whhT_fwd, const float *whhT_bwd, float *memory,
+                   int B, int T, hipStream_t s);
+
+// ---- Griffin-Lim -------------------------------------------------------------------------------
+struct GlBufs {
+  int F, n_fft, hop, nb;   // frames, 1024, 256, 513
+  float *S;                // [F][nb]        linear magnitude
+  float2 *ang;             // [F][nb]        unit-modulus phase estimate
+  float2 *tprev;           // [F][nb]        previous rebuilt spectrum
+  float *frames;           // [F][n_fft]     windowed time frames
+  float *y;                // [hop*(F-1)]    overlap-added signal
+  const float2 *tw;        // [n_fft]        exp(-2*pi*i*k/n_fft)
+  const float *win;        // [n_fft]        periodic hann
+};
+void launch_gl_exp_transpose(const float *mel_80xF, float *out_Fx80, int n_mels, int F, hipStream_t s);
+void launch_gl_phase_init(const GlBufs &g, uint32_t seed, const float *phase0_dev, hipStream_t s);
+void launch_gl_iteration(const GlBufs &g, float alpha, hipStream_t s);   // istft -> stft -> update
+void launch_gl_final(const GlBufs &g, float *audio, hipStream_t s);      // istft of S*ang
+void launch_transpose(const float *in, float *out, int rows, int cols, hipStream_t s);
+
+}  // namespace xdtts

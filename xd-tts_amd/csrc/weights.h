@@ -1,0 +1,49 @@
+// weights.h -- canonical Tacotron2 tensor table, synthetic init, on-disk container and the
+// device-side packed layouts the kernels stream.
+#pragma once
+#include "common.h"
+
+namespace xdtts {
+
+struct TensorInfo {
+  char name[64];
+  int ndim;
+  int dims[3];
+  size_t numel, offset;
+  float bound;  // synthetic init: U(-bound, bound)
+  int kind;     // 0 plain, 1 bn.weight, 2 bn.bias, 3 bn.running_mean, 4 bn.running_var
+  int rec;      // recurrent matrix (scaled by rec_scale in synthetic init)
+};
+
+const std::vector<TensorInfo> &tensor_table();
+size_t tensor_total();
+int tensor_index(const char *name);
+
+// Canonical host blob (flat fp32, tensor_table() order).
+void synthetic_blob(uint32_t seed, float rec_scale, std::vector<float> &blob);
+void load_container(const std::string &dir, std::vector<float> &blob);
+void save_container(const std::string &dir, const std::vector<float> &blob);
+
+// One conv1d(+BN eval) layer lowered to an NT GEMM operand: W[co][k*ci] with BN folded in.
+struct ConvGemm {
+  DevBuf<float> w, b;
+  int co = 0, ci = 0, k = 0;
+};
+
+// Device-resident, kernel-ready weights.  Everything stays fp32 (parity bar 1e-4 RMS).
+struct DeviceWeights {
+  DevBuf<float> emb;                         // [148][512]
+  ConvGemm enc_conv[ENC_CONVS];              // [512][5*512]
+  DevBuf<float> enc_wih[2], enc_bias[2];     // [1024][512], b_ih+b_hh [1024]
+  DevBuf<float> enc_whhT[2];                 // [256][1024]  (transposed: coalesced over gate rows)
+  DevBuf<float> mem_w;                       // [128][512]
+  DevBuf<float> pre0T, pre1T;                // [80][256], [256][256] (transposed)
+  DevBuf<float> att_w, att_b;                // [1024 units][4 gates][1792], [1024][4]
+  DevBuf<float> q_w, v_w, loc_conv, loc_denseT;  // [128][1024], [128], [32][2][31], [32][128]
+  DevBuf<float> dec_w, dec_b;                // [1024][4][2560], [1024][4]
+  DevBuf<float> proj_w, proj_b;              // [81][1536] (row 80 = gate), [81]
+  ConvGemm post_conv[POST_CONVS];
+  void upload(const std::vector<float> &blob, hipStream_t s);
+};
+
+}  // namespace xdtts
