@@ -55,7 +55,8 @@ typedef struct {
   uint32_t dropout_seed;
   int32_t max_chunk;     /* encoder window; chunks are zero-padded to exactly this length */
   uint32_t item_base;    /* index of the first chunk in the dropout stream (batch sharding) */
-  uint32_t reserved;
+  float fixed_frames_per_id; /* >0 (and fixed_steps == 0): chunk of n ids emits round(n * this)
+                            frames -- deterministic work proportional to the chunk length */
 } xdtts_infer_opts;
 
 void xdtts_infer_opts_default(xdtts_infer_opts *opts);
@@ -172,6 +173,20 @@ xdtts_status xdtts_synthesize_ids(xdtts_tacotron2 *h, xdtts_griffinlim *g, const
                                   size_t n, const size_t *splits, size_t n_splits,
                                   const xdtts_infer_opts *opts, float **mel, size_t *n_frames,
                                   float **audio, size_t *n_samples);
+
+/* ---- host-side front of Tacotron2::infer (stays on the CPU side of the FFI) ---------------- */
+/* generate_id_list -- src/tacotron2/mod.rs:90-122: 148 symbols; token text of an id. */
+int32_t xdtts_symbol_count(void);
+const char *xdtts_symbol_token(int32_t id);
+/* Unit::from_str (src/phonemes.rs:450-487) + best_match_for_unit (src/phonemes.rs:627-660):
+ * id of a unit token ("IH0", " ", ".", "a"), or -1 where the reference drops the unit
+ * (src/tacotron2/mod.rs:403-406).  as_character != 0 looks the token up as Unit::Character. */
+int64_t xdtts_unit_id(const char *token, int32_t as_character);
+/* split_score -- src/phonemes.rs:663-671. */
+int32_t xdtts_split_score(int64_t id);
+/* find_splits(units, max_size) -- src/phonemes.rs:681-753, on the id sequence. */
+xdtts_status xdtts_find_splits(const int64_t *ids, size_t n, size_t max_size, size_t *out,
+                               size_t cap, size_t *n_out);
 
 /* ---- misc ------------------------------------------------------------------------------- */
 void xdtts_free(void *p);

@@ -46,7 +46,7 @@ class InferOpts(C.Structure):
         ("dropout_seed", C.c_uint32),
         ("max_chunk", C.c_int32),
         ("item_base", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("fixed_frames_per_id", C.c_float),
     ]
 
 
@@ -84,6 +84,11 @@ SYMBOLS = {
     "xdtts_griffinlim_last_timings": (_I32, [_VP, C.POINTER(C.c_float * 3)]),
     "xdtts_griffinlim_free": (None, [_VP]),
     "xdtts_synthesize_ids": (_I32, [_VP, _VP, _VP, _SZ, _VP, _SZ, C.POINTER(InferOpts), C.POINTER(_PF), C.POINTER(_SZ), C.POINTER(_PF), C.POINTER(_SZ)]),
+    "xdtts_symbol_count": (_I32, []),
+    "xdtts_symbol_token": (C.c_char_p, [_I32]),
+    "xdtts_unit_id": (C.c_int64, [C.c_char_p, _I32]),
+    "xdtts_split_score": (_I32, [C.c_int64]),
+    "xdtts_find_splits": (_I32, [_VP, _SZ, _SZ, _VP, _SZ, C.POINTER(_SZ)]),
     "xdtts_free": (None, [_VP]),
     "xdtts_last_error": (C.c_char_p, []),
     "xdtts_device_count": (_I32, []),
@@ -141,6 +146,32 @@ def _take(ptr, n, shape):
         return np.ctypeslib.as_array(ptr, shape=(max(n, 1),))[:n].reshape(shape).copy()
     finally:
         lib.xdtts_free(ptr)
+
+
+def generate_id_list():
+    """generate_id_list() -- src/tacotron2/mod.rs:90-122, as token strings."""
+    return [lib.xdtts_symbol_token(i).decode() for i in range(lib.xdtts_symbol_count())]
+
+
+def unit_id(token, as_character=False):
+    """Unit::from_str + best_match_for_unit (src/phonemes.rs:450-487,627-660); None if no id."""
+    i = lib.xdtts_unit_id(token.encode(), 1 if as_character else 0)
+    return None if i < 0 else int(i)
+
+
+def units_to_ids(tokens, as_character=False):
+    """The filter_map of src/tacotron2/mod.rs:403-406: units without an id are dropped."""
+    out = [unit_id(t, as_character) for t in tokens]
+    return np.array([i for i in out if i is not None], dtype=np.int64)
+
+
+def find_splits(ids, max_size=100):
+    """find_splits(units, max_size) -- src/phonemes.rs:681-753."""
+    ids = np.ascontiguousarray(ids, dtype=np.int64)
+    out = np.empty(max(ids.size, 1) + 2, dtype=np.uintp)
+    n = C.c_size_t()
+    _check(lib.xdtts_find_splits(_ptr(ids), ids.size, max_size, _ptr(out), out.size, C.byref(n)))
+    return out[: n.value].astype(np.int64)
 
 
 class Tacotron2:
@@ -205,6 +236,13 @@ class Tacotron2:
             )
         )
         return _take(mel, N_MEL * nf.value, (N_MEL, nf.value))
+
+    def infer_units(self, tokens, opts=None, as_character=False):
+        """Tacotron2::infer(&[Unit]) end to end (mod.rs:398-437): unit tokens -> ids (units with no
+        id dropped) -> find_splits(.., window) -> chunks -> mel."""
+        ids = units_to_ids(tokens, as_character)
+        window = opts.max_chunk if opts else 100
+        return self.infer(ids, splits=find_splits(ids, window), opts=opts)
 
     def infer_batch(self, ids_list, opts=None, fixed_steps=None):
         """B independent chunks (infer_chunk, mod.rs:361-393) decoded in lock-step."""

@@ -346,11 +346,14 @@ struct xdtts_tacotron2 {
     HIP_CHECK(hipEventRecord(ev.e[1], stream));
     std::vector<int> lim(B);
     for (int b = 0; b < B; ++b) {
-      int l = fixed_per_item ? fixed_per_item[b] : (o.fixed_steps > 0 ? o.fixed_steps : o.max_steps);
+      int l = o.max_steps;
+      if (fixed_per_item) l = fixed_per_item[b];
+      else if (o.fixed_steps > 0) l = o.fixed_steps;
+      else if (o.fixed_frames_per_id > 0.f) l = (int)std::lround((double)o.fixed_frames_per_id * lens[b]);
       lim[b] = std::min(std::max(l, 1), o.max_steps);
     }
     DecoderBufs d = decoder_bufs(B, T, memory.p, pmem.p, o);
-    if (fixed_per_item) d.use_gate = 0;
+    if (fixed_per_item || o.fixed_frames_per_id > 0.f) d.use_gate = 0;
     last_steps = run_decoder(d, lim);
     HIP_CHECK(hipEventRecord(ev.e[2], stream));
     std::vector<int> F(B);
@@ -538,7 +541,7 @@ void xdtts_infer_opts_default(xdtts_infer_opts *o) {
   o->dropout_seed = 0;
   o->max_chunk = 100;  // src/tacotron2/mod.rs:363,369-371,399
   o->item_base = 0;
-  o->reserved = 0;
+  o->fixed_frames_per_id = 0.f;
 }
 
 const char *xdtts_last_error(void) { return g_last_error.c_str(); }
