@@ -1,0 +1,20 @@
+"""Developer timing aid: per-kernel in-chain cost via XDTTS_DEBUG_MIX (results are garbage)."""
+import importlib, os, subprocess, sys, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+if len(sys.argv) > 1:
+    os.environ["XDTTS_DEBUG_MIX"] = sys.argv[1]
+    import numpy as np
+    pkg = importlib.import_module("xd-tts_amd")
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import synth_ids
+    ids = synth_ids(95)
+    m = pkg.Tacotron2.synthetic()
+    o = pkg.default_opts(fixed_steps=400)
+    for _ in range(3):
+        m.infer(ids, opts=o)
+    t = m.last_timings()
+    print("%-8s %.2f us/step (%d kernels/step -> %.2f us each)" % (sys.argv[1], t["decoder_ms"] * 1e3 / 400, len(sys.argv[1]), t["decoder_ms"] * 1e3 / 400 / len(sys.argv[1])))
+else:
+    for mix in ["paqsdj", "pppppp", "aaaaaa", "qqqqqq", "ssssss", "dddddd", "jjjjjj", "pqsj", "ad", "paqsd", "pa", "qs"]:
+        subprocess.call([sys.executable, __file__, mix])

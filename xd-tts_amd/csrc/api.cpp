@@ -84,7 +84,7 @@ struct xdtts_tacotron2 {
   DevBuf<int64_t> ids;
   DevBuf<int> n_valid, limits, nframes, ctl;
   DevBuf<float> xpadA, xpadB, xproj, memory, pmem;
-  DevBuf<float> att_h, att_c, dec_h, dec_c, aw, awc, ctx, x, q, frames, gates;
+  DevBuf<float> att_h, att_c, dec_h, dec_c, aw, awc, ctx, x, dec_in, loc, e_part, frames, gates;
   DevBuf<float> ppA, ppB, mel_dev;
   int *host_ctl = nullptr;  // pinned: [0..1] ctl, [2..] nframes
 
@@ -181,7 +181,9 @@ struct xdtts_tacotron2 {
     awc.alloc((size_t)B * T);
     ctx.alloc((size_t)B * EMB);
     x.alloc((size_t)B * PRENET);
-    q.alloc((size_t)B * ATT_DIM);
+    dec_in.alloc((size_t)B * N_MEL);
+    loc.alloc((size_t)B * T * ATT_DIM);
+    e_part.alloc((size_t)B * (ATT_DIM / 4) * T);
     frames.alloc((size_t)B * ms * N_MEL);
     gates.alloc((size_t)B * ms);
     nframes.alloc(B);
@@ -202,7 +204,9 @@ struct xdtts_tacotron2 {
     d.awc = awc.p;
     d.ctx = ctx.p;
     d.x = x.p;
-    d.q = q.p;
+    d.dec_in = dec_in.p;
+    d.loc = loc.p;
+    d.e_part = e_part.p;
     d.frames = frames.p;
     d.gates = gates.p;
     d.nframes = nframes.p;

@@ -6,12 +6,31 @@
 // is active at step s iff s < nframes[b].
 //
 // Per step, six kernels in stream order (each a grid-wide dependency of the next):
-//   k_prenet  -> k_lstm<ATT> -> k_query -> k_attention -> k_lstm<DEC> -> k_project
+//   k_prenet -> k_lstm<ATT> -> k_qenergy -> k_softmax_ctx
+//   -> k_lstm<DEC> (+ next step's location-feature blocks) -> k_project
 // The two LSTM GEMVs stream 71.3 MB of fp32 weights per step and are the HBM-bound part; rows
 // are packed [unit][gate][cols] so each wave reads one contiguous 4-row slab with 16-byte
 // lane-consecutive loads (1 KiB per wave instruction) and owns a hidden unit end-to-end, which
-// fuses the cell update into the GEMV.  Wavefront = 64 everywhere.
+// fuses the cell update into the GEMV.  Everything else is latency-bound glue, arranged so that
+// no single CU carries a long serial section: the location features (which depend only on the
+// previous step's weights) ride along as extra blocks of the previous decoder-LSTM launch, the
+// energies are spread over 32 blocks by attention dimension, softmax + context over 8.
+//
+// Latency discipline: a step is a chain of six dependent launches, so every kernel is written to
+// cost ONE memory round trip: all weight and activation loads are issued at kernel entry, before
+// anything that depends on the device-side step counter.  To make the activation addresses known
+// at entry, the ping-pong parity of the recurrent state is a kernel argument (`cur`, fixed per
+// graph node: replays always start on an even step) and the previous mel frame lives in a
+// fixed-address state buffer (dec_in, the reference's "decoder_input", mod.rs:285,332).  The step
+// counter / per-chunk activity is only consulted to gate the final stores.  Wavefront = 64.
+#include <cstdlib>
+#include <string>
+
 #include "kernels.h"
+
+#ifndef XDTTS_NT_MASK
+#define XDTTS_NT_MASK 3  // bit KIND set: that LSTM streams its weights with non-temporal loads
+#endif
 
 namespace xdtts {
 
@@ -41,11 +60,6 @@ __device__ __forceinline__ float gate_sigmoid(float x) {
   const float e = expf(x);
   return e / (1.0f + e);
 }
-__device__ __forceinline__ bool any_active(const DecoderBufs &d, int step) {
-  bool a = false;
-  for (int b = 0; b < d.B; ++b) a |= step < d.nframes[b];
-  return a;
-}
 
 // DecoderState::new (mod.rs:202-233): all recurrent state zero.
 __global__ void k_decoder_init(DecoderBufs d, const int *limits) {
@@ -63,6 +77,9 @@ __global__ void k_decoder_init(DecoderBufs d, const int *limits) {
     d.awc[b * d.T + i] = 0.f;
   }
   for (int i = threadIdx.x; i < EMB; i += blockDim.x) d.ctx[b * EMB + i] = 0.f;
+  for (int i = threadIdx.x; i < N_MEL; i += blockDim.x) d.dec_in[b * N_MEL + i] = 0.f;
+  // location features of step 0: conv/dense of all-zero attention weights
+  for (int i = threadIdx.x; i < d.T * ATT_DIM; i += blockDim.x) d.loc[(size_t)b * d.T * ATT_DIM + i] = 0.f;
   if (threadIdx.x == 0) {
     d.nframes[b] = limits[b];
     if (b == 0) {
@@ -72,44 +89,126 @@ __global__ void k_decoder_init(DecoderBufs d, const int *limits) {
   }
 }
 
-// D1 prenet: x = relu(W1 relu(W0 mel_prev) * m0 * 2) * m1 * 2, no bias, Bernoulli(0.5) masks from
-// the counter RNG (the exported graph keeps this dropout on at inference).  One block per chunk;
-// weights are stored transposed so lanes read consecutive addresses.
-__global__ __launch_bounds__(1024) void k_prenet(DecoderBufs d, const float *__restrict__ W0T,
-                                                 const float *__restrict__ W1T) {
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const int step = d.ctl[0];
-  if (step >= d.nframes[b]) return;
-  __shared__ float mel[N_MEL], part[4][PRENET], x1[PRENET];
-  if (tid < N_MEL)
-    mel[tid] = step == 0 ? 0.f : d.frames[((size_t)b * d.max_steps + (step - 1)) * N_MEL + tid];
-  __syncthreads();
-  const int p = tid >> 8, j = tid & 255;
-  const uint32_t item = d.item_base + (uint32_t)b;
-  float acc = 0.f;
-#pragma unroll 4
-  for (int i = p * (N_MEL / 4); i < (p + 1) * (N_MEL / 4); ++i) acc = fmaf(W0T[i * PRENET + j], mel[i], acc);
-  part[p][j] = acc;
-  __syncthreads();
-  if (tid < PRENET) {
-    float v = (part[0][j] + part[1][j]) + (part[2][j] + part[3][j]);
-    v = fmaxf(v, 0.f);
-    if (d.dropout_mode)
-      v = (rng_u32(d.dropout_seed, 0x1000u + 2u * item, (uint32_t)step * 256u + (uint32_t)j) >> 31) ? 0.f : 2.f * v;
-    x1[j] = v;
+// Location features of D3 for one (chunk, LOC_TT-step tile):
+//   loc[t][a] = Dense32->128(Conv1d(2->32, k=31, pad=15)([w_prev ; w_cum]))[t][a]
+// They depend only on the previous step's attention weights, so these blocks ride along in the
+// previous step's k_lstm<DEC> launch instead of sitting on the attention critical path.
+// loc_convT is the conv weight re-laid as [c][k][f] (filter index contiguous) so each thread pulls
+// its 62 taps with lane-consecutive loads and keeps them in registers; the zero-padded weight
+// windows are the only LDS operands of the conv.
+constexpr int LOC_TT = 8;  // time steps per location block
+
+__device__ __forceinline__ void location_role(const DecoderBufs &d, int b, int tile,
+                                              const float *__restrict__ loc_convT,
+                                              const float *__restrict__ loc_denseT) {
+  constexpr int TT = LOC_TT, PADK = (LOC_K - 1) / 2, WIN = TT + 2 * PADK;
+  const int t0 = tile * TT, tid = threadIdx.x;
+  __shared__ __attribute__((aligned(16))) float s_w[2][WIN + 2], s_lc[TT][LOC_F];
+  const int f = tid & 31, tl = tid >> 5;     // conv role: one (t, filter) output per thread
+  const int a = tid & 127, th = tid >> 7;    // dense role: attention dim a, 4 time steps
+  float cw[2 * LOC_K];
+#pragma unroll
+  for (int j = 0; j < 2 * LOC_K; ++j) cw[j] = loc_convT[j * LOC_F + f];
+  float wd[LOC_F];
+#pragma unroll
+  for (int g = 0; g < LOC_F; ++g) wd[g] = loc_denseT[g * ATT_DIM + a];
+  if (tid < 2 * WIN) {
+    const int c = tid / WIN, i = tid % WIN, t = t0 - PADK + i;
+    const float *src = c ? d.awc : d.aw;  // channel 0 = previous weights, 1 = cumulative
+    s_w[c][i] = (t >= 0 && t < d.T) ? src[b * d.T + t] : 0.f;
   }
   __syncthreads();
-  acc = 0.f;
-#pragma unroll 8
-  for (int i = p * (PRENET / 4); i < (p + 1) * (PRENET / 4); ++i) acc = fmaf(W1T[i * PRENET + j], x1[i], acc);
-  part[p][j] = acc;
+  {
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < LOC_K; ++k) acc = fmaf(cw[k], s_w[0][tl + k], acc);
+#pragma unroll
+    for (int k = 0; k < LOC_K; ++k) acc = fmaf(cw[LOC_K + k], s_w[1][tl + k], acc);
+    s_lc[tl][f] = acc;
+  }
   __syncthreads();
-  if (tid < PRENET) {
-    float v = (part[0][j] + part[1][j]) + (part[2][j] + part[3][j]);
-    v = fmaxf(v, 0.f);
+#pragma unroll
+  for (int q = 0; q < TT / 2; ++q) {
+    const int tloc = th * (TT / 2) + q, t = t0 + tloc;
+    if (t >= d.T) break;
+    float acc = 0.f;
+#pragma unroll
+    for (int g = 0; g < LOC_F; ++g) acc = fmaf(wd[g], s_lc[tloc][g], acc);
+    d.loc[((size_t)b * d.T + t) * ATT_DIM + a] = acc;
+  }
+}
+
+// D1 prenet: x = relu(W1 relu(W0 mel_prev) * m0 * 2) * m1 * 2, no bias, Bernoulli(0.5) masks from
+// the counter RNG (the exported graph keeps this dropout on at inference).  First kernel of a
+// step, spread over PRENET_BLOCKS blocks per chunk so no CU carries the 336 KB of weights alone:
+// every block recomputes layer 1 (80 KB, L2-resident) and owns 256/PRENET_BLOCKS output columns
+// of layer 2.
+constexpr int PRENET_BLOCKS = 16, PRENET_COLS = PRENET / PRENET_BLOCKS;
+
+__global__ __launch_bounds__(256) void k_prenet(DecoderBufs d, const float *__restrict__ W0T,
+                                                const float *__restrict__ W1T) {
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ __attribute__((aligned(16))) float s_mel[N_MEL], s_x1[PRENET], s_part[4][PRENET], s_out[4][PRENET_COLS];
+  // all weight loads first, 16 B per lane.  Layer 1: wave w covers inputs [20w, 20w+20) for the
+  // four output columns 4*lane..4*lane+3.  Layer-2 slice (PRENET_COLS = 16 columns of this block):
+  // thread (c4, ig) covers inputs ig, ig+64, ig+128, ig+192 for columns col0 + 4*c4 .. +3.
+  const float4 *W0 = reinterpret_cast<const float4 *>(W0T), *W1 = reinterpret_cast<const float4 *>(W1T);
+  constexpr int L1_PER_WAVE = N_MEL / 4;
+  float4 w0[L1_PER_WAVE];
+#pragma unroll
+  for (int k = 0; k < L1_PER_WAVE; ++k) w0[k] = W0[(wave * L1_PER_WAVE + k) * (PRENET / 4) + lane];
+  const int c4 = tid & 3, ig = tid >> 2, col0 = blockIdx.x * PRENET_COLS;
+  float4 w1[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) w1[k] = W1[((size_t)(ig + 64 * k) * PRENET + col0) / 4 + c4];
+  if (tid < N_MEL) s_mel[tid] = d.dec_in[b * N_MEL + tid];
+  const int step = d.ctl[0];
+  const int nf = d.nframes[b];
+  const uint32_t item = d.item_base + (uint32_t)b;
+  __syncthreads();
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int k = 0; k < L1_PER_WAVE; ++k) {
+    const float m = s_mel[wave * L1_PER_WAVE + k];
+    acc.x = fmaf(w0[k].x, m, acc.x);
+    acc.y = fmaf(w0[k].y, m, acc.y);
+    acc.z = fmaf(w0[k].z, m, acc.z);
+    acc.w = fmaf(w0[k].w, m, acc.w);
+  }
+  *reinterpret_cast<float4 *>(&s_part[wave][4 * lane]) = acc;
+  __syncthreads();
+  {
+    float v = fmaxf((s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid]), 0.f);
     if (d.dropout_mode)
-      v = (rng_u32(d.dropout_seed, 0x1001u + 2u * item, (uint32_t)step * 256u + (uint32_t)j) >> 31) ? 0.f : 2.f * v;
-    d.x[b * PRENET + j] = v;
+      v = (rng_u32(d.dropout_seed, 0x1000u + 2u * item, (uint32_t)step * 256u + (uint32_t)tid) >> 31) ? 0.f : 2.f * v;
+    s_x1[tid] = v;
+  }
+  __syncthreads();
+  acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float m = s_x1[ig + 64 * k];
+    acc.x = fmaf(w1[k].x, m, acc.x);
+    acc.y = fmaf(w1[k].y, m, acc.y);
+    acc.z = fmaf(w1[k].z, m, acc.z);
+    acc.w = fmaf(w1[k].w, m, acc.w);
+  }
+  // reduce over the 16 input groups held by lanes with equal c4 (lane bits 2..5), then over waves
+#pragma unroll
+  for (int o = 4; o < 64; o <<= 1) {
+    acc.x += __shfl_xor(acc.x, o, 64);
+    acc.y += __shfl_xor(acc.y, o, 64);
+    acc.z += __shfl_xor(acc.z, o, 64);
+    acc.w += __shfl_xor(acc.w, o, 64);
+  }
+  if (lane < 4) *reinterpret_cast<float4 *>(&s_out[wave][4 * lane]) = acc;
+  __syncthreads();
+  if (tid < PRENET_COLS && step < nf) {
+    float o = fmaxf((s_out[0][tid] + s_out[1][tid]) + (s_out[2][tid] + s_out[3][tid]), 0.f);
+    const int j = col0 + tid;
+    if (d.dropout_mode)
+      o = (rng_u32(d.dropout_seed, 0x1001u + 2u * item, (uint32_t)step * 256u + (uint32_t)j) >> 31) ? 0.f : 2.f * o;
+    d.x[b * PRENET + j] = o;
   }
 }
 
@@ -119,22 +218,48 @@ __global__ __launch_bounds__(1024) void k_prenet(DecoderBufs d, const float *__r
 // the batch, so HBM sees each weight once per step regardless of B.
 //   KIND 0: attention_rnn, input [prenet x (256) ; ctx_prev (512)] , hidden att_h   -> 1792 cols
 //   KIND 1: decoder_rnn,   input [att_h_new (1024) ; ctx (512)]    , hidden dec_h   -> 2560 cols
+// KIND 1 launches carry extra leading blocks in the location-feature role: they
+// compute the NEXT step's location features from the attention weights this step just produced,
+// hidden under the 42 MB weight stream instead of sitting on the next step's critical path.
 template <int NCOLS, int KIND>
-__global__ __launch_bounds__(256) void k_lstm(DecoderBufs d, const float4 *__restrict__ Wp,
-                                              const float *__restrict__ bias) {
+__global__ __launch_bounds__(256) void k_lstm(DecoderBufs d, int cur, const float4 *__restrict__ Wp,
+                                              const float *__restrict__ bias,
+                                              const float *__restrict__ loc_conv,
+                                              const float *__restrict__ loc_denseT) {
   constexpr int NCH = NCOLS / 256;
+  constexpr int N0 = KIND == 0 ? PRENET : ATT_RNN;  // first segment length
+  constexpr int N1 = EMB;
+  constexpr int HID = KIND == 0 ? ATT_RNN : DEC_RNN;
+  constexpr bool NT_WEIGHTS = XDTTS_NT_MASK & (1 << KIND);
+  int gemv_block = blockIdx.x;
+  if (KIND == 1) {  // the first tiles*B blocks take the location role (short; dispatched first)
+    const int tiles = (d.T + LOC_TT - 1) / LOC_TT, nloc = tiles * d.B;
+    if ((int)blockIdx.x < nloc) {
+      location_role(d, blockIdx.x / tiles, blockIdx.x % tiles, loc_conv, loc_denseT);
+      return;
+    }
+    gemv_block -= nloc;
+  }
+  (void)HID;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int unit = blockIdx.x * 4 + wave;
-  const int step = d.ctl[0], cur = step & 1;
-  if (!any_active(d, step)) return;
+  const int unit = gemv_block * 4 + wave;
   float4 w[4][NCH];
 #pragma unroll
   for (int g = 0; g < 4; ++g)
 #pragma unroll
-    for (int k = 0; k < NCH; ++k) w[g][k] = Wp[((size_t)(unit * 4 + g) * NCOLS) / 4 + lane + 64 * k];
+    for (int k = 0; k < NCH; ++k) {
+      const float4 *src = Wp + ((size_t)(unit * 4 + g) * NCOLS) / 4 + lane + 64 * k;
+      if (NT_WEIGHTS) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(src));
+        w[g][k] = make_float4(v.x, v.y, v.z, v.w);
+      } else {
+        w[g][k] = *src;
+      }
+    }
   const float4 bz = *reinterpret_cast<const float4 *>(bias + unit * 4);
+  const int step = d.ctl[0];
   for (int b = 0; b < d.B; ++b) {
-    if (step >= d.nframes[b]) continue;
     const float *seg0, *seg1, *seg2;
     float *h_out, *c;
     if (KIND == 0) {
@@ -150,117 +275,122 @@ __global__ __launch_bounds__(256) void k_lstm(DecoderBufs d, const float4 *__res
       h_out = d.dec_h[cur ^ 1] + b * DEC_RNN;
       c = d.dec_c + b * DEC_RNN;
     }
-    constexpr int N0 = KIND == 0 ? PRENET : ATT_RNN;  // first segment length
-    constexpr int N1 = EMB;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (b > 0 && step >= d.nframes[b]) continue;  // chunk 0's loads go out before the counter lands
+    float4 xv[NCH];
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
       const int col = 256 * k;  // wave-uniform segment choice: boundaries are multiples of 256
       const float *src = col < N0 ? seg0 + col : (col < N0 + N1 ? seg1 + (col - N0) : seg2 + (col - N0 - N1));
-      const float4 xv = *reinterpret_cast<const float4 *>(src + 4 * lane);
-      a0 = dot4(w[0][k], xv, a0);
-      a1 = dot4(w[1][k], xv, a1);
-      a2 = dot4(w[2][k], xv, a2);
-      a3 = dot4(w[3][k], xv, a3);
+      xv[k] = *reinterpret_cast<const float4 *>(src + 4 * lane);
+    }
+    const float c_old = c[unit];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+      a0 = dot4(w[0][k], xv[k], a0);
+      a1 = dot4(w[1][k], xv[k], a1);
+      a2 = dot4(w[2][k], xv[k], a2);
+      a3 = dot4(w[3][k], xv[k], a3);
     }
     a0 = wave_sum(a0);
     a1 = wave_sum(a1);
     a2 = wave_sum(a2);
     a3 = wave_sum(a3);
-    if (lane == 0) {
+    if (lane == 0 && step < d.nframes[b]) {
       const float ig = sigmoidf_(a0 + bz.x), fg = sigmoidf_(a1 + bz.y);
       const float gg = tanhf(a2 + bz.z), og = sigmoidf_(a3 + bz.w);
-      const float cn = fmaf(fg, c[unit], ig * gg);
+      const float cn = fmaf(fg, c_old, ig * gg);
       c[unit] = cn;
       h_out[unit] = og * tanhf(cn);
     }
   }
 }
 
-// D3a: processed query q = W_q att_h_new (128 x 1024, no bias); one wave per row.
-__global__ __launch_bounds__(256) void k_query(DecoderBufs d, const float4 *__restrict__ Wq) {
-  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int step = d.ctl[0], cur = step & 1;
-  if (!any_active(d, step)) return;
+// D3a: processed query q = W_q att_h_new (128 x 1024, no bias) and, fused, this block's share of
+// the energies.  Block `blk` owns attention dims a in [4 blk, 4 blk + 4): one wave per query row,
+// then the 256 threads each take a time step and emit
+//   e_part[blk][t] = sum_{a in block} v_a tanh(q_a + loc[t][a] + processed_memory[t][a]).
+// This spreads the 12.8k tanh of a step over 32 CUs instead of one.
+__global__ __launch_bounds__(256) void k_qenergy(DecoderBufs d, int cur, const float4 *__restrict__ Wq,
+                                                 const float *__restrict__ v_w) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, blk = blockIdx.x;
+  const int row = blk * 4 + wave;
   float4 w[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) w[k] = Wq[(size_t)row * (ATT_RNN / 4) + lane + 64 * k];
+  const float4 v4 = *reinterpret_cast<const float4 *>(v_w + blk * 4);
+  const int step = d.ctl[0];
+  __shared__ __attribute__((aligned(16))) float s_q[4];
   for (int b = 0; b < d.B; ++b) {
-    if (step >= d.nframes[b]) continue;
+    if (b > 0 && step >= d.nframes[b]) continue;
     const float *h = d.att_h[cur ^ 1] + b * ATT_RNN;
+    float4 hv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) hv[k] = *reinterpret_cast<const float4 *>(h + 256 * k + 4 * lane);
+    // first time step of this thread: loads do not depend on q, put them in flight now
+    const size_t o0 = ((size_t)b * d.T + (tid < d.T ? tid : 0)) * ATT_DIM + blk * 4;
+    float4 l4 = *reinterpret_cast<const float4 *>(d.loc + o0);
+    float4 p4 = *reinterpret_cast<const float4 *>(d.pmem + o0);
     float a = 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) a = dot4(w[k], *reinterpret_cast<const float4 *>(h + 256 * k + 4 * lane), a);
+    for (int k = 0; k < 4; ++k) a = dot4(w[k], hv[k], a);
     a = wave_sum(a);
-    if (lane == 0) d.q[b * ATT_DIM + row] = a;
+    if (lane == 0) s_q[wave] = a;
+    __syncthreads();
+    const float4 q4 = *reinterpret_cast<const float4 *>(s_q);
+    const bool act = step < d.nframes[b];
+    for (int t = tid; t < d.T; t += 256) {
+      if (t != tid) {
+        const size_t o = ((size_t)b * d.T + t) * ATT_DIM + blk * 4;
+        l4 = *reinterpret_cast<const float4 *>(d.loc + o);
+        p4 = *reinterpret_cast<const float4 *>(d.pmem + o);
+      }
+      float e = v4.x * tanhf(q4.x + l4.x + p4.x);
+      e = fmaf(v4.y, tanhf(q4.y + l4.y + p4.y), e);
+      e = fmaf(v4.z, tanhf(q4.z + l4.z + p4.z), e);
+      e = fmaf(v4.w, tanhf(q4.w + l4.w + p4.w), e);
+      if (act) d.e_part[((size_t)b * (ATT_DIM / 4) + blk) * d.T + t] = e;
+    }
+    __syncthreads();
   }
 }
 
-// D3b: location-sensitive attention for one chunk per block (16 waves):
-//   loc = Dense32->128(Conv1d(2->32,k=31,pad=15)([w_prev ; w_cum]))
-//   e_t = v . tanh(q + loc_t + processed_memory_t), -inf where t >= n_valid   (mask, mod.rs:219-220)
-//   w = softmax_t(e); ctx = sum_t w_t memory_t; w_cum += w
-// memory/processed_memory rows are read with lane-consecutive addresses; the weights, the
-// energies and the context partials live in LDS.
-__global__ __launch_bounds__(1024) void k_attention(DecoderBufs d, const float *__restrict__ v_w,
-                                                    const float *__restrict__ loc_conv,
-                                                    const float *__restrict__ loc_denseT) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int step = d.ctl[0];
-  if (step >= d.nframes[b]) return;
-  const int T = d.T, PADK = (LOC_K - 1) / 2, TP = T + 2 * PADK;
-  float *s_aw = smem;                     // [TP] zero-padded previous weights
-  float *s_awc = s_aw + TP;               // [TP] zero-padded cumulative weights
-  float *s_q = s_awc + TP;                // [128]
-  float *s_v = s_q + ATT_DIM;             // [128]
-  float *s_cw = s_v + ATT_DIM;            // [32*2*31]
-  float *s_wd = s_cw + LOC_F * 2 * LOC_K; // [32][128]
-  float *s_lc = s_wd + LOC_F * ATT_DIM;   // [T][33]
-  float *s_e = s_lc + T * (LOC_F + 1);    // [T]
-  float *s_part = s_e + T;                // [512]
-  for (int i = tid; i < TP; i += 1024) {
-    const int t = i - PADK;
-    const bool in = t >= 0 && t < T;
-    s_aw[i] = in ? d.aw[b * T + t] : 0.f;
-    s_awc[i] = in ? d.awc[b * T + t] : 0.f;
-  }
-  if (tid < ATT_DIM) {
-    s_q[tid] = d.q[b * ATT_DIM + tid];
-    s_v[tid] = v_w[tid];
-  }
-  for (int i = tid; i < LOC_F * 2 * LOC_K; i += 1024) s_cw[i] = loc_conv[i];
-  for (int i = tid; i < LOC_F * ATT_DIM; i += 1024) s_wd[i] = loc_denseT[i];
-  __syncthreads();
-  // location conv: (t, f) outputs; channel 0 = previous weights, channel 1 = cumulative
-  for (int o = tid; o < T * LOC_F; o += 1024) {
-    const int t = o / LOC_F, f = o % LOC_F;
-    float acc = 0.f;
+// D3b: e_t = sum of the 32 partial energies, -inf where t >= n_valid (mask, mod.rs:219-220);
+// w = softmax_t(e); w_cum += w; ctx = sum_t w_t memory_t.  CTX_BLOCKS blocks per chunk: each
+// recomputes the (tiny) softmax and owns 512/CTX_BLOCKS context columns, so the T x 2 KB read of
+// the encoder memory is spread over several CUs; it is issued as 16-byte lane-consecutive loads,
+// prefetched at kernel entry (addresses do not depend on the softmax).  Block 0 also stores the
+// new attention weights.
+constexpr int CTX_BLOCKS = 8, CTX_COLS = EMB / CTX_BLOCKS;
+
+__global__ __launch_bounds__(256) void k_softmax_ctx(DecoderBufs d) {
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int T = d.T;
+  constexpr int C4 = CTX_COLS / 4, TG = 256 / C4;  // 16 float4 columns x 16 time groups
+  constexpr int CTX_PF = 7;
+  __shared__ __attribute__((aligned(16))) float s_e[T_MAX], s_part[TG][CTX_COLS];
+  const int c4 = tid % C4, tg = tid / C4;
+  const float4 *mem = reinterpret_cast<const float4 *>(d.memory + (size_t)b * T * EMB) + blockIdx.x * C4;
+  float4 pf[CTX_PF];
 #pragma unroll
-    for (int k = 0; k < LOC_K; ++k) acc = fmaf(s_cw[(f * 2 + 0) * LOC_K + k], s_aw[t + k], acc);
-#pragma unroll
-    for (int k = 0; k < LOC_K; ++k) acc = fmaf(s_cw[(f * 2 + 1) * LOC_K + k], s_awc[t + k], acc);
-    s_lc[t * (LOC_F + 1) + f] = acc;
+  for (int u = 0; u < CTX_PF; ++u) {
+    const int t = tg + TG * u;
+    pf[u] = t < T ? mem[(size_t)t * (EMB / 4) + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  __syncthreads();
-  // energies: one wave per time step, lane covers attention dims lane and lane+64
   const int nv = d.n_valid[b];
-  const float *pm = d.pmem + (size_t)b * T * ATT_DIM;
-  for (int t = wave; t < T; t += 16) {
-    float l0 = 0.f, l1 = 0.f;
+  for (int t = tid; t < T; t += 256) {
+    const float *ep = d.e_part + (size_t)b * (ATT_DIM / 4) * T + t;
+    float ev[ATT_DIM / 4];
 #pragma unroll
-    for (int f = 0; f < LOC_F; ++f) {
-      const float c = s_lc[t * (LOC_F + 1) + f];
-      l0 = fmaf(s_wd[f * ATT_DIM + lane], c, l0);
-      l1 = fmaf(s_wd[f * ATT_DIM + lane + 64], c, l1);
-    }
-    float e = s_v[lane] * tanhf(s_q[lane] + l0 + pm[t * ATT_DIM + lane]) +
-              s_v[lane + 64] * tanhf(s_q[lane + 64] + l1 + pm[t * ATT_DIM + lane + 64]);
-    e = wave_sum(e);
-    if (lane == 0) s_e[t] = t >= nv ? -INFINITY : e;
+    for (int k = 0; k < ATT_DIM / 4; ++k) ev[k] = ep[(size_t)k * T];
+    float e = 0.f;
+#pragma unroll
+    for (int k = 0; k < ATT_DIM / 4; ++k) e += ev[k];
+    s_e[t] = t >= nv ? -INFINITY : e;
   }
+  const int step = d.ctl[0];
+  const bool act = step < d.nframes[b];
   __syncthreads();
-  // softmax over t by wave 0
   if (wave == 0) {
     float m = -INFINITY;
     for (int t = lane; t < T; t += 64) m = fmaxf(m, s_e[t]);
@@ -275,52 +405,71 @@ __global__ __launch_bounds__(1024) void k_attention(DecoderBufs d, const float *
     for (int t = lane; t < T; t += 64) s_e[t] = s_e[t] / sum;
   }
   __syncthreads();
-  for (int t = tid; t < T; t += 1024) {
-    const float wv = s_e[t];
-    d.aw[b * T + t] = wv;
-    d.awc[b * T + t] = s_awc[t + PADK] + wv;
+  if (act && blockIdx.x == 0)
+    for (int t = tid; t < T; t += 256) {
+      const float wv = s_e[t];
+      d.aw[b * T + t] = wv;
+      d.awc[b * T + t] += wv;
+    }
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  int k = 0;
+  for (int t0 = tg; t0 < T; t0 += TG * CTX_PF) {
+#pragma unroll
+    for (int u = 0; u < CTX_PF; ++u) {
+      const int t = t0 + TG * u;
+      const float wv = t < T ? s_e[t] : 0.f;
+      const float4 mv = k == 0 ? pf[u] : (t < T ? mem[(size_t)t * (EMB / 4) + c4] : make_float4(0.f, 0.f, 0.f, 0.f));
+      acc.x = fmaf(wv, mv.x, acc.x);
+      acc.y = fmaf(wv, mv.y, acc.y);
+      acc.z = fmaf(wv, mv.z, acc.z);
+      acc.w = fmaf(wv, mv.w, acc.w);
+    }
+    ++k;
   }
-  // context: thread (half, c) accumulates its half of the time axis for column c
-  const int c = tid & 511, half = tid >> 9;
-  const float *mem = d.memory + (size_t)b * T * EMB;
-  const int t0 = half ? (T + 1) / 2 : 0, t1 = half ? T : (T + 1) / 2;
-  float acc = 0.f;
-#pragma unroll 4
-  for (int t = t0; t < t1; ++t) acc = fmaf(s_e[t], mem[(size_t)t * EMB + c], acc);
-  if (half) s_part[c] = acc;
+  *reinterpret_cast<float4 *>(&s_part[tg][4 * c4]) = acc;
   __syncthreads();
-  if (!half) d.ctx[b * EMB + c] = acc + s_part[c];
+  if (tid < CTX_COLS && act) {
+    float v = 0.f;
+#pragma unroll
+    for (int g = 0; g < TG; ++g) v += s_part[g][tid];
+    d.ctx[b * EMB + blockIdx.x * CTX_COLS + tid] = v;
+  }
 }
 
 // D5 + D6: mel = W_p [dec_h ; ctx] + b_p (80 rows), gate = W_g [dec_h ; ctx] + b_g (row 80), and
 // the stop rule of mod.rs:319-324 (sigmoid(gate) > threshold, the tripping frame is kept) applied
-// on the device: the gate wave lowers nframes[b] to step+1.  The last block to finish advances
-// the step counter (all blocks have read it by then).
-__global__ __launch_bounds__(256) void k_project(DecoderBufs d, const float4 *__restrict__ Wp,
+// on the device: the gate wave lowers nframes[b] to step+1.  The frame is written both to the
+// output (frames[step]) and to the fixed-address decoder_input state.  The last block to finish
+// advances the step counter (all blocks have read it by then).
+__global__ __launch_bounds__(256) void k_project(DecoderBufs d, int cur, const float4 *__restrict__ Wp,
                                                  const float *__restrict__ bias) {
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int step = d.ctl[0], cur = step & 1;
-  if (row <= N_MEL && any_active(d, step)) {
-    float4 w[6];
+  const bool valid = row <= N_MEL;
+  const int r = valid ? row : N_MEL;
+  float4 w[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) w[k] = Wp[(size_t)row * (PROJ_IN / 4) + lane + 64 * k];
-    const float bz = bias[row];
-    for (int b = 0; b < d.B; ++b) {
-      if (step >= d.nframes[b]) continue;
-      const float *h = d.dec_h[cur ^ 1] + b * DEC_RNN, *cx = d.ctx + b * EMB;
-      float a = 0.f;
+  for (int k = 0; k < 6; ++k) w[k] = Wp[(size_t)r * (PROJ_IN / 4) + lane + 64 * k];
+  const float bz = bias[r];
+  const int step = d.ctl[0];
+  for (int b = 0; b < d.B; ++b) {
+    if (b > 0 && step >= d.nframes[b]) continue;
+    const float *h = d.dec_h[cur ^ 1] + b * DEC_RNN, *cx = d.ctx + b * EMB;
+    float4 xv[6];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) a = dot4(w[k], *reinterpret_cast<const float4 *>(h + 256 * k + 4 * lane), a);
+    for (int k = 0; k < 4; ++k) xv[k] = *reinterpret_cast<const float4 *>(h + 256 * k + 4 * lane);
 #pragma unroll
-      for (int k = 0; k < 2; ++k) a = dot4(w[4 + k], *reinterpret_cast<const float4 *>(cx + 256 * k + 4 * lane), a);
-      a = wave_sum(a) + bz;
-      if (lane == 0) {
-        if (row < N_MEL) {
-          d.frames[((size_t)b * d.max_steps + step) * N_MEL + row] = a;
-        } else {
-          d.gates[(size_t)b * d.max_steps + step] = a;
-          if (d.use_gate && gate_sigmoid(a) > d.gate_threshold) d.nframes[b] = step + 1;
-        }
+    for (int k = 0; k < 2; ++k) xv[4 + k] = *reinterpret_cast<const float4 *>(cx + 256 * k + 4 * lane);
+    float a = 0.f;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) a = dot4(w[k], xv[k], a);
+    a = wave_sum(a) + bz;
+    if (lane == 0 && valid && step < d.nframes[b]) {
+      if (row < N_MEL) {
+        d.frames[((size_t)b * d.max_steps + step) * N_MEL + row] = a;
+        d.dec_in[b * N_MEL + row] = a;
+      } else {
+        d.gates[(size_t)b * d.max_steps + step] = a;
+        if (d.use_gate && gate_sigmoid(a) > d.gate_threshold) d.nframes[b] = step + 1;
       }
     }
   }
@@ -337,28 +486,52 @@ __global__ __launch_bounds__(256) void k_project(DecoderBufs d, const float4 *__
 
 }  // namespace
 
-size_t attention_lds_bytes(int T) {
-  const int TP = T + (LOC_K - 1);
-  return sizeof(float) * (size_t)(2 * TP + 2 * ATT_DIM + LOC_F * 2 * LOC_K + LOC_F * ATT_DIM + T * (LOC_F + 1) + T + EMB);
-}
-
 void launch_decoder_init(const DecoderBufs &d, const int *limits_dev, hipStream_t s) {
   hipLaunchKernelGGL(k_decoder_init, dim3(d.B), dim3(256), 0, s, d, limits_dev);
   HIP_CHECK(hipGetLastError());
 }
 
+// Steps are enqueued in (even, odd) pairs: node i uses ping-pong parity i & 1, so a sequence must
+// start on an even step and nsteps must be even.
 void launch_decoder_steps(const DecoderBufs &d, const DeviceWeights &w, int nsteps, hipStream_t s) {
-  const size_t lds = attention_lds_bytes(d.T);
+  if (nsteps % 2 != 0) fail(XDTTS_ERR_BAD_ARG, "decoder steps are enqueued in even/odd pairs");
+  const int loc_tiles = (d.T + LOC_TT - 1) / LOC_TT;
+  const float4 *att_w = reinterpret_cast<const float4 *>(w.att_w.p);
+  const float4 *dec_w = reinterpret_cast<const float4 *>(w.dec_w.p);
+  // XDTTS_DEBUG_MIX (developer timing aid only; results are garbage when set): string over
+  // letters p,a,q,s,d,j selecting which kernels a step launches, e.g. "jjjjjj".
+  const char *mix = getenv("XDTTS_DEBUG_MIX");
+  const std::string order = mix ? mix : "paqsdj";
   for (int i = 0; i < nsteps; ++i) {
-    hipLaunchKernelGGL(k_prenet, dim3(d.B), dim3(1024), 0, s, d, w.pre0T.p, w.pre1T.p);
-    hipLaunchKernelGGL((k_lstm<ATT_COLS, 0>), dim3(ATT_RNN / 4), dim3(256), 0, s, d,
-                       reinterpret_cast<const float4 *>(w.att_w.p), w.att_b.p);
-    hipLaunchKernelGGL(k_query, dim3(ATT_DIM / 4), dim3(256), 0, s, d, reinterpret_cast<const float4 *>(w.q_w.p));
-    hipLaunchKernelGGL(k_attention, dim3(d.B), dim3(1024), lds, s, d, w.v_w.p, w.loc_conv.p, w.loc_denseT.p);
-    hipLaunchKernelGGL((k_lstm<DEC_COLS, 1>), dim3(DEC_RNN / 4), dim3(256), 0, s, d,
-                       reinterpret_cast<const float4 *>(w.dec_w.p), w.dec_b.p);
-    hipLaunchKernelGGL(k_project, dim3((N_MEL + 1 + 3) / 4), dim3(256), 0, s, d,
-                       reinterpret_cast<const float4 *>(w.proj_w.p), w.proj_b.p);
+    const int cur = i & 1;
+    for (char k : order) {
+      switch (k) {
+        case 'p':
+          hipLaunchKernelGGL(k_prenet, dim3(PRENET_BLOCKS, d.B), dim3(256), 0, s, d, w.pre0T.p, w.pre1T.p);
+          break;
+        case 'a':
+          hipLaunchKernelGGL((k_lstm<ATT_COLS, 0>), dim3(ATT_RNN / 4), dim3(256), 0, s, d, cur, att_w, w.att_b.p,
+                             w.loc_conv.p, w.loc_denseT.p);
+          break;
+        case 'q':
+          hipLaunchKernelGGL(k_qenergy, dim3(ATT_DIM / 4), dim3(256), 0, s, d, cur,
+                             reinterpret_cast<const float4 *>(w.q_w.p), w.v_w.p);
+          break;
+        case 's':
+          hipLaunchKernelGGL(k_softmax_ctx, dim3(CTX_BLOCKS, d.B), dim3(256), 0, s, d);
+          break;
+        case 'd':
+          hipLaunchKernelGGL((k_lstm<DEC_COLS, 1>), dim3(DEC_RNN / 4 + loc_tiles * d.B), dim3(256), 0, s, d, cur,
+                             dec_w, w.dec_b.p, w.loc_conv.p, w.loc_denseT.p);
+          break;
+        case 'j':
+          hipLaunchKernelGGL(k_project, dim3((N_MEL + 1 + 3) / 4), dim3(256), 0, s, d, cur,
+                             reinterpret_cast<const float4 *>(w.proj_w.p), w.proj_b.p);
+          break;
+        default:
+          break;
+      }
+    }
   }
   HIP_CHECK(hipGetLastError());
 }

@@ -20,7 +20,9 @@ struct DecoderBufs {
   float *aw, *awc;      // [B][T]        attention_weights, attention_weights_cum
   float *ctx;           // [B][512]      attention_context
   float *x;             // [B][256]      prenet output
-  float *q;             // [B][128]      processed query
+  float *dec_in;        // [B][80]       previous mel frame ("decoder_input", mod.rs:285,332)
+  float *loc;           // [B][T][128]   location features of the current step
+  float *e_part;        // [B][32][T]    per-block partial energies
   float *frames;        // [B][max_steps][80]  decoder_output per step (time-major)
   float *gates;         // [B][max_steps]      gate_prediction logits
   int *nframes;         // [B] in: step limit; out: frames emitted (gate may lower it)

@@ -257,7 +257,7 @@ void DeviceWeights::upload(const std::vector<float> &blob, hipStream_t s) {
   pack_lstm(blob, "attention_rnn", ATT_RNN, ATT_IN, att_w, att_b, s);
   q_w.upload(T(blob, "attention.query_layer.weight"), (size_t)ATT_DIM * ATT_RNN, s);
   v_w.upload(T(blob, "attention.v.weight"), ATT_DIM, s);
-  loc_conv.upload(T(blob, "attention.location_conv.weight"), (size_t)LOC_F * 2 * LOC_K, s);
+  upload_transposed(T(blob, "attention.location_conv.weight"), LOC_F, 2 * LOC_K, loc_conv, s);  // -> [c][k][f]
   upload_transposed(T(blob, "attention.location_dense.weight"), ATT_DIM, LOC_F, loc_denseT, s);
   pack_lstm(blob, "decoder_rnn", DEC_RNN, DEC_IN, dec_w, dec_b, s);
   {
