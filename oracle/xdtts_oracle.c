@@ -680,9 +680,17 @@ void orc_stft(const real *y, int n, int n_fft, int hop, real *out, int F) {
   hann_periodic(n_fft, win);
   for (int t = 0; t < F; ++t) {
     for (int i = 0; i < n_fft; ++i) {
+      /* numpy "reflect" padding: mirror without repeating the edge sample, period 2(n-1)
+       * (a single mirror for the usual n > n_fft/2; folds repeatedly for very short signals) */
       int p = t * hop + i - half; /* index into the un-padded signal */
-      if (p < 0) p = -p;
-      if (p >= n) p = 2 * (n - 1) - p;
+      const int period = 2 * (n - 1);
+      if (period > 0) {
+        p %= period;
+        if (p < 0) p += period;
+        if (p >= n) p = period - p;
+      } else {
+        p = 0;
+      }
       re[i] = y[p] * win[i];
       im[i] = 0;
     }

@@ -1,0 +1,161 @@
+"""CPU-only checks of the drop-in boundary: libxdtts_hip.so loads, exports every symbol that
+include/xdtts.h declares, refuses to run without a GPU (no CPU fallback), and its host-side front
+end reproduces the reference's known-answer tests (src/tacotron2/mod.rs:465-508,
+src/phonemes.rs:785-811)."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KATS = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_kats.json")))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "xdtts.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(xdtts_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    names = declared_symbols()
+    assert len(names) >= 35
+    raw = C.CDLL(pkg.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), "libxdtts_hip.so does not export %s" % n
+    # and the Python binding lists exactly the declared set
+    assert sorted(pkg.SYMBOLS) == names
+
+
+def test_no_gpu_means_error_not_fallback(pkg):
+    if pkg.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(pkg.XdttsError) as e:
+        pkg.Tacotron2.synthetic()
+    assert e.value.status == pkg.XDTTS_ERR_NO_DEVICE
+    with pytest.raises(pkg.XdttsError) as e:
+        pkg.create_griffin_lim()
+    assert e.value.status == pkg.XDTTS_ERR_NO_DEVICE
+
+
+def test_default_opts_are_the_reference_constants(pkg):
+    o = pkg.default_opts()
+    assert abs(o.gate_threshold - 0.6) < 1e-7 and o.max_steps == 1000  # mod.rs:279-280
+    assert o.max_chunk == 100  # mod.rs:363,369-371,399
+    assert o.fixed_steps == 0 and o.dropout_mode == 1
+
+
+def test_tensor_table_matches_oracle(pkg, orc):
+    ours = pkg.tensor_table()
+    theirs = orc.tensor_table()
+    assert [(n, s, o) for n, s, o in ours] == [(n, s, o) for n, s, o, _ in theirs]
+    assert pkg.lib.xdtts_tensor_total() == 28_200_481
+
+
+def test_symbol_table(pkg):
+    syms = pkg.generate_id_list()
+    assert len(syms) == 148  # mod.rs:90-122
+    assert syms[0] == "<PAD>" and syms[11] == " " and syms[7] == "." and syms[12] == "A" and syms[38] == "a"
+    assert syms[64] == "AA" and syms[-1] == "ZH"
+
+
+def test_reference_id_known_answers(pkg):
+    k = KATS["correct_phoneme_id_output"]  # mod.rs:465-492
+    assert [pkg.unit_id(u) for u in k["units"]] == k["expected"]
+    k = KATS["correct_char_id_output"]  # mod.rs:494-508
+    ids = [pkg.unit_id(c, as_character=(c not in "!")) for c in k["text"]]
+    assert ids == k["expected"]
+
+
+def test_unit_lookup_edge_cases(pkg):
+    assert pkg.unit_id("AA3") == pkg.unit_id("AA")  # unknown stress mark: first entry of that phone (phonemes.rs:627-660)
+    assert pkg.unit_id("B") == 88  # ARPAbet wins over the character 'B' (phonemes.rs:469-482)
+    assert pkg.unit_id("B", as_character=True) == 13
+    assert pkg.unit_id("<UNK>") is None and pkg.unit_id("%") is None  # dropped (mod.rs:403-406)
+    assert pkg.unit_id("<PAD>") == 0 and pkg.unit_id(" ") == 11
+    assert list(pkg.units_to_ids(["HH", "%", "AH0", " "])) == [106, 73, 11]
+
+
+def test_find_splits_reference_kat(pkg):
+    k = KATS["split_units"]  # phonemes.rs:785-811
+    text = k["text"]
+    ids = np.array([pkg.unit_id(c) if c in ".," else pkg.unit_id(c, True) for c in text])
+    assert len(ids) == len(text)
+    sp = list(pkg.find_splits(ids, k["max_size"]))
+    assert len(sp) == 3
+    assert text[sp[0]] == "." and text[sp[1]] == "." and sp[0] < sp[1]
+    assert sp[1] < sp[2] < sp[1] + 11 and text[sp[2]] == " "
+
+
+def find_splits_py(scores, n, max_size):
+    """The chunking heuristic of src/phonemes.rs:681-753 restated independently in Python (scores =
+    split_score per position) -- the cross-check for the C++ host implementation."""
+    marks = [(i, s) for i, s in enumerate(scores) if s > 0]
+    results = [0] + [i for i, s in marks if s > 2]
+    threshold, scan, fresh = 1, True, []
+    while scan:
+        scan = False
+        last_ref = n
+        for index in reversed(results):
+            if last_ref - index > max_size:
+                scan = True
+                fresh += [i for i, s in marks if i < last_ref and i > index + 1 and s > threshold]
+            last_ref = index
+        if scan:
+            results = sorted(results + fresh)
+            fresh = []
+        if threshold > 0:
+            threshold -= 1
+        else:
+            scan = False
+    merged, running, last_insert = [], 0, 0
+    for i in results:
+        if (i - last_insert) + running > max_size:
+            merged.append(last_insert)
+            running = i - last_insert
+        else:
+            running += i - last_insert
+        last_insert = i
+    if running + (n - last_insert) > max_size and results:
+        merged.append(results[-1])
+    out = []
+    for m in merged:  # Vec::dedup
+        if not out or out[-1] != m:
+            out.append(m)
+    return out
+
+
+def test_find_splits_matches_independent_restatement(pkg):
+    rng = np.random.default_rng(0)
+    for trial in range(60):
+        n = int(rng.integers(1, 400))
+        window = int(rng.choice([10, 25, 100]))
+        ids = 64 + rng.integers(0, 84, size=n)
+        ids[rng.random(n) < 0.18] = 11
+        ids[rng.random(n) < 0.04] = 7
+        ids[rng.random(n) < 0.03] = 6
+        ids[rng.random(n) < 0.01] = 10
+        scores = [pkg.lib.xdtts_split_score(int(i)) for i in ids]
+        sp = list(pkg.find_splits(ids, window))
+        assert sp == find_splits_py(scores, n, window), (trial, n, window)
+        assert all(0 <= s <= n for s in sp) and sp == sorted(sp)
+        if n <= window:
+            assert sp == []
+    assert [pkg.lib.xdtts_split_score(i) for i in (7, 10, 2, 0, 6, 9, 11, 8, 1, 64)] == [3, 3, 3, 3, 2, 2, 1, 0, 0, 0]  # phonemes.rs:663-671
+
+
+def test_bench_utterance_chunks(pkg):
+    from conftest import synth_ids
+
+    ids = synth_ids(120)
+    assert list(pkg.find_splits(ids, 100)) == [95]  # 95 + 25 ids
+
+
+def test_mel_filter_bank_is_host_side_and_bit_exact(pkg, orc):
+    B = pkg.create_mel_filter_bank(22050.0, 1024, 80, 0.0, 8000.0)
+    assert np.array_equal(B, orc.mel_filter_bank(22050.0, 1024, 80, 0.0, 8000.0))
+    # fmax = None -> sr / 2
+    assert np.array_equal(pkg.create_mel_filter_bank(16000.0, 512, 40, 0.0, None), orc.mel_filter_bank(16000.0, 512, 40, 0.0, 8000.0))

@@ -1,0 +1,109 @@
+"""GPU parity, vocoder: golden fixture, full GriffinLim::infer path (mel -> linear -> phase
+recovery), edge sizes, the BASELINE Griffin-Lim-only config and size-independent properties."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import rms
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def voc(pkg):
+    if pkg.device_count() < 1:
+        pytest.skip("no HIP device")
+    v = pkg.create_griffin_lim(iters=30, seed=3)  # create_griffin_lim(), src/tacotron2/mod.rs:441-458
+    yield v
+    v.close()
+
+
+def chirps(n):
+    """BASELINE.md config-5 signal: five linear chirps 100 Hz - 7 kHz plus a little noise."""
+    t = np.arange(n) / 22050.0
+    rng = np.random.default_rng(3)
+    y = sum(0.15 * np.sin(2 * np.pi * (f0 + 0.5 * (f1 - f0) * t / t[-1]) * t) for f0, f1 in ((100, 900), (400, 2500), (1200, 4000), (3000, 5500), (5000, 7000)))
+    return (y + 0.01 * rng.standard_normal(n)).astype(np.float32)
+
+
+def test_golden_fixture_on_gpu(voc):
+    g = np.load(os.path.join(G, "griffinlim_small.npz"))
+    voc.set_seed(int(g["phase_seed"]))
+    a = voc.infer_linear(g["S"], iters=int(g["iters"]))
+    assert rms(a, g["audio"]) <= 1e-4 and rms(a, g["audio_f64"]) <= 1e-4
+
+
+def test_full_infer_from_mel(pkg, voc, orc):
+    """GriffinLim::infer(&mel) (src/lib.rs:141): ln-mel -> exp -> NNLS(=clipped pinv) -> ^(1/1.7)
+    -> 30 iterations, against the oracle chain."""
+    rng = np.random.default_rng(11)
+    F = 40
+    mel = (rng.uniform(-7.0, -1.0, size=(80, F)) + 2.0 * np.sin(np.arange(F) / 5.0)[None, :]).astype(np.float32)
+    voc.set_seed(5)
+    audio = voc.infer(mel)
+    S = orc.mel_to_linear(orc.pinv(orc.mel_filter_bank()), mel, power=1.7)
+    ref = orc.griffinlim(S, seed=5, iters=30)
+    assert audio.shape == ref.shape == (256 * (F - 1),)
+    assert rms(audio, ref) <= 1e-4
+    t = voc.last_timings()
+    assert t["total_ms"] > 0 and t["iterations_ms"] > 0
+
+
+def test_edge_sizes(voc, orc):
+    rng = np.random.default_rng(2)
+    for F in (2, 3, 4, 5, 9):
+        S = np.abs(rng.standard_normal((513, F))).astype(np.float32)
+        voc.set_seed(1)
+        a = voc.infer_linear(S, iters=4)
+        ref = orc.griffinlim(S, seed=1, iters=4)
+        assert a.shape == ref.shape == (256 * (F - 1),)
+        assert rms(a, ref) <= 1e-4 * max(1.0, float(np.abs(ref).max())), F
+
+
+def test_errors(pkg, voc):
+    with pytest.raises(pkg.XdttsError) as e:
+        voc.infer(np.zeros((79, 10), dtype=np.float32))
+    assert e.value.status == pkg.XDTTS_ERR_BAD_ARG
+    with pytest.raises(pkg.XdttsError) as e:
+        voc.infer(np.zeros((80, 1), dtype=np.float32))
+    assert e.value.status == pkg.XDTTS_ERR_BAD_ARG
+    with pytest.raises(pkg.XdttsError) as e:  # n_fft inferred from the basis must be 1024
+        pkg.GriffinLim(np.ones((80, 257), dtype=np.float32), 192, 1.7, 30, 0.99)
+    assert e.value.status == pkg.XDTTS_ERR_BAD_ARG
+
+
+def test_parity_200_frames_60_iterations(voc, orc):
+    F = 200
+    sig = chirps(256 * (F - 1))
+    spec = orc.stft(sig)
+    S = np.hypot(spec[..., 0], spec[..., 1]).astype(np.float32)
+    voc.set_seed(3)
+    a = voc.infer_linear(S, iters=60)
+    ref = orc.griffinlim(S, seed=3, iters=60)
+    assert rms(a, ref) <= 1e-4
+
+
+def test_config5_full_size_properties(voc, orc):
+    """BASELINE.json configs[4]: 1000-frame input, 30/60/120 iterations.  Checked through
+    size-independent properties: length, finiteness, scale equivariance, determinism, and
+    monotone improvement of spectral consistency with the iteration count."""
+    F = 1000
+    sig = chirps(256 * (F - 1))
+    spec = orc.stft(sig)
+    S = np.hypot(spec[..., 0], spec[..., 1]).astype(np.float32)
+    voc.set_seed(3)
+    out = {it: voc.infer_linear(S, iters=it) for it in (2, 30, 60, 120)}
+    for it, a in out.items():
+        assert a.shape == (255744,) and np.all(np.isfinite(a))
+
+    def inconsistency(y):
+        r = orc.stft(y)
+        return float(np.linalg.norm(np.hypot(r[..., 0], r[..., 1]) - S) / np.linalg.norm(S))
+
+    errs = [inconsistency(out[it]) for it in (2, 30, 60, 120)]
+    assert errs[0] > errs[1] > errs[2] > errs[3]
+    assert np.array_equal(voc.infer_linear(S, iters=30), out[30])  # deterministic
+    scaled = voc.infer_linear(2.0 * S, iters=30)
+    assert rms(scaled, 2.0 * out[30]) <= 1e-5 * max(1.0, float(np.abs(out[30]).max()))

@@ -1,0 +1,174 @@
+"""GPU parity, second slice: stop rule, batches/chunks, error behaviour, weight container, golden
+fixtures and the full-size BASELINE config -- all through the C ABI against the CPU oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import rms, synth_ids
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+LOGIT_06 = 0.4054651  # ln(0.6 / 0.4): the gate threshold of src/tacotron2/mod.rs:279 as a logit
+
+
+def rigged_gate_blob(orc, blob, mem, pm, n_valid, seed, kth, gain=-40.0):
+    """Make the synthetic gate informative: scale (and flip) gate_layer.weight so the logit drifts
+    upward from step to step, then set the bias so that the k-th largest of the first 60 logits
+    crosses sigmoid(gate) > 0.6 by a 2e-3 margin -- the loop then ends well inside the 60 steps."""
+    rig = blob.copy()
+    tab = {t[0]: t for t in orc.tensor_table()}
+    _n, _s, woff, wn = tab["gate_layer.weight"]
+    rig[woff : woff + wn] *= np.float32(gain)
+    boff = tab["gate_layer.bias"][2]
+    rig[boff] = 0.0
+    _f, gates = orc.run_decoder(rig, mem, pm, n_valid, orc.default_opts(fixed_steps=60, dropout_seed=seed))
+    rig[boff] = np.float32(LOGIT_06 - float(np.sort(gates)[-kth]) + 2e-3)
+    return rig
+
+
+def test_gate_stop_rule_matches_oracle(pkg, orc, blob):
+    """mod.rs:302-342: the frame whose sigmoid(gate) > 0.6 is kept and ends the loop, on the device."""
+    ids = np.zeros(100, dtype=np.int64)
+    ids[:33] = synth_ids(33)
+    mem, pm = orc.encoder(blob, ids)
+    for kth in (20, 45):
+        rig = rigged_gate_blob(orc, blob, mem, pm, 33, 21, kth)
+        rframes, rgates = orc.run_decoder(rig, mem, pm, 33, orc.default_opts(dropout_seed=21))
+        assert 1 <= len(rframes) < 60
+        m = pkg.Tacotron2.from_blob(rig)
+        frames, gates = m.decoder(mem, pm, 33, pkg.default_opts(dropout_seed=21))
+        assert frames.shape == rframes.shape  # identical frame count
+        assert rms(frames, rframes) <= 1e-5 and np.abs(gates - rgates).max() <= 1e-5
+        assert gates[-1] > LOGIT_06 and np.all(gates[:-1] <= LOGIT_06)
+        m.close()
+
+
+def test_max_steps_cap_and_threshold_option(pkg, model, orc, blob):
+    ids = np.zeros(100, dtype=np.int64)
+    ids[:20] = synth_ids(20)
+    mem, pm = orc.encoder(blob, ids)
+    frames, gates = model.decoder(mem, pm, 20, pkg.default_opts(max_steps=37, dropout_seed=1))
+    assert len(frames) == 37  # synthetic gate never fires: i + 1 == max_decoder_steps (mod.rs:320)
+    # a low threshold stops at the first step (every logit's sigmoid is ~0.5 > 0.3)
+    f1, _ = model.decoder(mem, pm, 20, pkg.default_opts(gate_threshold=0.3, dropout_seed=1))
+    assert len(f1) == 1 and np.allclose(f1[0], frames[0], atol=1e-6)
+
+
+def test_infer_ids_with_splits_equals_chunkwise_oracle(pkg, model, orc, blob):
+    """Tacotron2::infer (mod.rs:398-437): chunks run independently and are concatenated in time."""
+    ids = synth_ids(120)
+    splits = pkg.find_splits(ids, 100)
+    assert list(splits) == [95]
+    o = pkg.default_opts(fixed_frames_per_id=0.5, dropout_seed=13)
+    mel = model.infer(ids, splits=splits, opts=o)
+    parts = []
+    for item, (a, b) in enumerate(((0, 95), (95, 120))):
+        steps = int(np.floor(0.5 * (b - a) + 0.5))  # lround, as the library rounds fixed_frames_per_id * n
+        parts.append(orc.infer_chunk(blob, ids[a:b], orc.default_opts(fixed_steps=steps, dropout_seed=13, item=item)))
+    ref = np.concatenate(parts, axis=1)
+    assert mel.shape == ref.shape == (80, 48 + 13)
+    assert rms(mel, ref) <= 1e-5
+    # the Unit-level front door gives the same result
+    toks = [pkg.generate_id_list()[i] for i in ids]
+    mel2 = model.infer_units(toks, opts=o)
+    assert np.array_equal(mel2, mel)
+
+
+def test_batch_of_variable_length_chunks(pkg, model, orc, blob):
+    """BASELINE.json configs[2] in small: variable-length chunks in one lock-step batch, per-chunk
+    mask (mod.rs:219-220), per-chunk stop; each must equal the oracle run on its own."""
+    rng = np.random.Generator(np.random.PCG64(2))
+    lens = [int(x) for x in rng.integers(10, 101, size=5)]
+    ids_list = [synth_ids(n, seed=10 + i) for i, n in enumerate(lens)]
+    steps = [12, 30, 7, 22, 16]
+    mels = model.infer_batch(ids_list, opts=pkg.default_opts(dropout_seed=3, item_base=40), fixed_steps=steps)
+    for b, (ids, st) in enumerate(zip(ids_list, steps)):
+        ref = orc.infer_chunk(blob, ids, orc.default_opts(fixed_steps=st, dropout_seed=3, item=40 + b))
+        assert mels[b].shape == (80, st)
+        assert rms(mels[b], ref) <= 1e-5, b
+
+
+def test_batch_with_gate_stops_each_chunk_on_its_own(pkg, orc, blob):
+    ids_list = [synth_ids(30, seed=5), synth_ids(55, seed=6), synth_ids(18, seed=7)]
+    padded = np.zeros(100, dtype=np.int64)
+    padded[:30] = ids_list[0]
+    mem, pm = orc.encoder(blob, padded)
+    rig = rigged_gate_blob(orc, blob, mem, pm, 30, 8, 40)
+    m = pkg.Tacotron2.from_blob(rig)
+    mels = m.infer_batch(ids_list, opts=pkg.default_opts(dropout_seed=8, max_steps=80))
+    counts = []
+    for b, ids in enumerate(ids_list):
+        ref = orc.infer_chunk(rig, ids, orc.default_opts(dropout_seed=8, max_steps=80, item=b))
+        counts.append(ref.shape[1])
+        assert mels[b].shape == ref.shape, (b, mels[b].shape, ref.shape)
+        assert rms(mels[b], ref) <= 1e-5
+    assert len(set(counts)) > 1  # the chunks really stop at different steps
+    m.close()
+
+
+def test_error_behaviour(pkg, model):
+    with pytest.raises(pkg.XdttsError) as e:  # the reference's assert!(units_len <= 100), mod.rs:363
+        model.infer(synth_ids(101))
+    assert e.value.status == pkg.XDTTS_ERR_TOO_LONG
+    with pytest.raises(pkg.XdttsError) as e:
+        model.infer(np.array([5, 148], dtype=np.int64))
+    assert e.value.status == pkg.XDTTS_ERR_BAD_ARG
+    with pytest.raises(pkg.XdttsError) as e:
+        model.infer(np.array([], dtype=np.int64))
+    assert e.value.status == pkg.XDTTS_ERR_BAD_ARG
+    with pytest.raises(pkg.XdttsError) as e:
+        pkg.Tacotron2.synthetic(device_id=99)
+    assert e.value.status == pkg.XDTTS_ERR_BAD_ARG
+    # a single 'a' works, like the reference's tacotron_sanity_test (mod.rs:511-522): 80 rows, >0 cols
+    spec = model.infer_units(["a"], opts=pkg.default_opts(max_steps=6), as_character=True)
+    assert spec.shape[0] == 80 and spec.shape[1] > 0
+
+
+def test_weight_container_round_trip(pkg, model, orc, blob, tmp_path):
+    model.save(str(tmp_path))
+    assert os.path.getsize(tmp_path / "tacotron2.xdtw") > blob.nbytes
+    m2 = pkg.Tacotron2.load(str(tmp_path))  # Tacotron2::load(path), mod.rs:242
+    ids = synth_ids(17)
+    o = pkg.default_opts(fixed_steps=9, dropout_seed=2)
+    assert np.array_equal(m2.infer(ids, opts=o), model.infer(ids, opts=o))
+    assert np.array_equal(m2.get_tensor("decoder_rnn.weight_hh"), orc.tensor(blob, "decoder_rnn.weight_hh"))
+    m2.close()
+    with pytest.raises(pkg.XdttsError) as e:  # the anyhow context of mod.rs:249
+        pkg.Tacotron2.load(str(tmp_path / "missing"))
+    assert e.value.status == pkg.XDTTS_ERR_IO
+    raw = open(tmp_path / "tacotron2.xdtw", "rb").read()
+    bad = tmp_path / "bad"
+    bad.mkdir()
+    open(bad / "tacotron2.xdtw", "wb").write(raw[: len(raw) // 2])
+    with pytest.raises(pkg.XdttsError) as e:
+        pkg.Tacotron2.load(str(bad))
+    assert e.value.status == pkg.XDTTS_ERR_IO
+
+
+def test_golden_fixture_on_gpu(pkg, model):
+    g = np.load(os.path.join(G, "tacotron2_small.npz"))
+    ids, steps, dseed = g["ids"], int(g["steps"]), int(g["dropout_seed"])
+    padded = np.zeros(100, dtype=np.int64)
+    padded[: len(ids)] = ids
+    mem, pm = model.encoder(padded)
+    assert np.abs(mem[:, ::32] - g["memory_cols"]).max() <= 1e-5
+    assert np.abs(pm[:, ::8] - g["pmem_cols"]).max() <= 1e-5
+    mel = model.infer(ids, opts=pkg.default_opts(fixed_steps=steps, dropout_seed=dseed))
+    assert rms(mel, g["mel"]) <= 1e-5 and rms(mel, g["mel_f64"]) <= 1e-5
+
+
+def test_full_size_config2_mel_parity(pkg, model, orc, blob):
+    """BASELINE.json configs[1] at full size: 120 ids -> chunks 95 + 25 -> 800 frames, vs the oracle."""
+    ids = synth_ids(120)
+    splits = pkg.find_splits(ids, 100)
+    o = pkg.default_opts(fixed_frames_per_id=800 / 120.0, dropout_seed=0)
+    mel = model.infer(ids, splits=splits, opts=o)
+    assert mel.shape == (80, 800)
+    parts = [orc.infer_chunk(blob, ids[a:b], orc.default_opts(fixed_steps=int(round(800 / 120.0 * (b - a))), dropout_seed=0, item=i)) for i, (a, b) in enumerate(((0, 95), (95, 120)))]
+    ref = np.concatenate(parts, axis=1)
+    err = rms(mel, ref)
+    assert err <= 1e-4, err  # the north-star tolerance
+    assert err <= 1e-3 * float(np.sqrt(np.mean(ref.astype(np.float64) ** 2)))  # and relative to the signal
+    t = model.last_timings()
+    assert t["steps"] == 633  # lock-step: max(633, 167) iterations for 800 frames

@@ -160,11 +160,15 @@ __global__ __launch_bounds__(256) void k_stft_update(GlBufs g, float alpha) {
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
     const int m = lane + 64 * r;
+    // "reflect" padding with period 2(N-1): one mirror normally, repeated folds for tiny signals
     int p0 = f * g.hop + 2 * m - g.n_fft / 2, p1 = p0 + 1;
-    p0 = p0 < 0 ? -p0 : p0;
-    p1 = p1 < 0 ? -p1 : p1;
-    p0 = p0 >= N ? 2 * (N - 1) - p0 : p0;
-    p1 = p1 >= N ? 2 * (N - 1) - p1 : p1;
+    const int period = 2 * (N - 1);
+    p0 %= period;
+    p1 %= period;
+    p0 = p0 < 0 ? p0 + period : p0;
+    p1 = p1 < 0 ? p1 + period : p1;
+    p0 = p0 >= N ? period - p0 : p0;
+    p1 = p1 >= N ? period - p1 : p1;
     const float2 w = win[m];
     v[r] = make_float2(g.y[p0] * w.x, g.y[p1] * w.y);
   }
