@@ -43,6 +43,17 @@ def per_item_bytes(T):
     return T * (512 + 128) * 4 + 2 * (4 * 1024 + 2 * T + 512 + 80) * 4
 
 
+def pmc_traffic():
+    """HBM bytes per decoder step from the committed rocprofv3 PMC passes of this same command
+    (profiles/): counters cannot be read from inside the process, so the figure is the profiled one."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
+    if not files:
+        return None
+    return json.load(open(files[-1])).get("decoder_step_traffic_bytes")
+
+
 def synth_ids(n, seed=1):
     rng = np.random.Generator(np.random.PCG64(seed))
     ids = 64 + rng.integers(0, 84, size=n)
@@ -118,7 +129,7 @@ def main():
         splits.append(len(ids))          # src/tacotron2/mod.rs:412-414
     lens = np.diff([0] + splits)
     fpi = TOTAL_FRAMES / float(N_IDS)
-    chunk_steps = [int(round(fpi * n)) for n in lens]
+    chunk_steps = [int(np.floor(fpi * n + 0.5)) for n in lens]   # lround, as the library does
 
     model = pkg.Tacotron2.synthetic(seed=WEIGHT_SEED, rec_scale=1.0, device_id=local_rank)
     vocoder = pkg.create_griffin_lim(device_id=local_rank, iters=GL_ITERS, seed=0)
@@ -198,13 +209,13 @@ def main():
             "griffinlim_iterations": gl_ms / K,
         },
         "roofline": {
-            "kernel": "decoder step (k_prenet, k_lstm<att>, k_query, k_attention, k_lstm<dec>, k_project)",
+            "kernel": "decoder step (k_prenet, k_lstm<ATT>, k_qenergy, k_softmax_ctx, k_lstm<DEC>, k_project)",
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": pmc_traffic(),
             "us_per_launch": step_us,
             "algorithmic_bytes_per_launch": bytes_per_utt / steps_per_utt,
             "launches_per_utterance": steps_per_utt,

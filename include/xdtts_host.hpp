@@ -1,0 +1,139 @@
+// xdtts_host.hpp -- header-only C++ mirror of the reference's Rust surface for the hot path, over
+// the C ABI of include/xdtts.h.  (The reference's host language is Rust; this image has no Rust
+// toolchain, so the host-side mirror is C++.  INTEGRATION.md holds the equivalent Rust shim.)
+//
+//   xdtts::Tacotron2::load(path)            -- Tacotron2::load,  src/tacotron2/mod.rs:242
+//   xdtts::Tacotron2::infer(units)          -- Tacotron2::infer, src/tacotron2/mod.rs:398
+//   xdtts::create_mel_filter_bank(...)      -- griffin_lim::mel, src/tacotron2/mod.rs:453
+//   xdtts::GriffinLim(basis, noverlap, power, iter, momentum) / infer(mel)
+//                                           -- src/tacotron2/mod.rs:456, src/lib.rs:141
+//   xdtts::create_griffin_lim()             -- src/tacotron2/mod.rs:441-458
+// Errors become xdtts::Error (the shim's anyhow::Error); nothing here computes on the CPU.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "xdtts.h"
+
+namespace xdtts {
+
+struct Error : std::runtime_error {
+  xdtts_status status;
+  Error(xdtts_status s, const char *what) : std::runtime_error(what), status(s) {}
+};
+inline void check(xdtts_status s) {
+  if (s != XDTTS_OK) throw Error(s, xdtts_last_error());
+}
+
+// Array2<f32> stand-in: row-major (rows x cols)
+struct Array2 {
+  size_t rows = 0, cols = 0;
+  std::vector<float> data;
+  float &operator()(size_t r, size_t c) { return data[r * cols + c]; }
+  float operator()(size_t r, size_t c) const { return data[r * cols + c]; }
+};
+
+// A unit is carried as its token text ("IH0", " ", ".", "a"), i.e. Unit::from_str's input.
+struct Unit {
+  std::string token;
+  bool is_character = false;  // Unit::Character(c) built directly (grapheme input)
+};
+
+class Tacotron2 {
+ public:
+  static Tacotron2 load(const std::string &path, int device_id = 0) {
+    xdtts_tacotron2 *h = nullptr;
+    check(xdtts_tacotron2_load(path.c_str(), device_id, &h));
+    return Tacotron2(h);
+  }
+  static Tacotron2 synthetic(uint32_t seed = 20240327u, float rec_scale = 1.0f, int device_id = 0) {
+    xdtts_tacotron2 *h = nullptr;
+    check(xdtts_tacotron2_load_synthetic(seed, rec_scale, device_id, &h));
+    return Tacotron2(h);
+  }
+  Tacotron2(Tacotron2 &&o) noexcept : h_(std::exchange(o.h_, nullptr)) {}
+  Tacotron2 &operator=(Tacotron2 &&o) noexcept {
+    std::swap(h_, o.h_);
+    return *this;
+  }
+  Tacotron2(const Tacotron2 &) = delete;
+  Tacotron2 &operator=(const Tacotron2 &) = delete;
+  ~Tacotron2() { xdtts_tacotron2_free(h_); }
+
+  // src/tacotron2/mod.rs:398-437: find_splits(units, 100); units with no id are dropped (:403-406);
+  // chunks are inferred independently and concatenated on the time axis.
+  Array2 infer(const std::vector<Unit> &units, const xdtts_infer_opts *opts = nullptr) const {
+    std::vector<int64_t> ids;
+    for (const Unit &u : units) {
+      const int64_t id = xdtts_unit_id(u.token.c_str(), u.is_character ? 1 : 0);
+      if (id >= 0) ids.push_back(id);
+    }
+    xdtts_infer_opts o;
+    xdtts_infer_opts_default(&o);
+    if (opts) o = *opts;
+    std::vector<size_t> splits(ids.size() + 2);
+    size_t n_splits = 0;
+    check(xdtts_find_splits(ids.data(), ids.size(), (size_t)o.max_chunk, splits.data(), splits.size(), &n_splits));
+    float *mel = nullptr;
+    size_t frames = 0;
+    check(xdtts_tacotron2_infer_ids(h_, ids.data(), ids.size(), splits.data(), n_splits, &o, &mel, &frames));
+    Array2 out;
+    out.rows = 80;
+    out.cols = frames;
+    out.data.assign(mel, mel + 80 * frames);
+    xdtts_free(mel);
+    return out;
+  }
+  xdtts_tacotron2 *raw() const { return h_; }
+
+ private:
+  explicit Tacotron2(xdtts_tacotron2 *h) : h_(h) {}
+  xdtts_tacotron2 *h_ = nullptr;
+};
+
+// create_mel_filter_bank(sample_rate, n_fft, n_mels, fmin, fmax: Option<f32>); NaN = None
+inline Array2 create_mel_filter_bank(float sample_rate, size_t n_fft, size_t n_mels, float fmin, float fmax = NAN) {
+  Array2 b;
+  b.rows = n_mels;
+  b.cols = n_fft / 2 + 1;
+  b.data.resize(b.rows * b.cols);
+  check(xdtts_mel_filter_bank(sample_rate, n_fft, n_mels, fmin, fmax, b.data.data()));
+  return b;
+}
+
+class GriffinLim {
+ public:
+  GriffinLim(const Array2 &mel_basis, size_t noverlap, float power, size_t iter, float momentum, int device_id = 0) {
+    check(xdtts_griffinlim_new(mel_basis.data.data(), mel_basis.rows, mel_basis.cols, noverlap, power, iter, momentum,
+                               device_id, &g_));
+  }
+  GriffinLim(GriffinLim &&o) noexcept : g_(std::exchange(o.g_, nullptr)) {}
+  GriffinLim(const GriffinLim &) = delete;
+  GriffinLim &operator=(const GriffinLim &) = delete;
+  ~GriffinLim() { xdtts_griffinlim_free(g_); }
+
+  std::vector<float> infer(const Array2 &mel) const {
+    float *audio = nullptr;
+    size_t n = 0;
+    check(xdtts_griffinlim_infer(g_, mel.data.data(), mel.rows, mel.cols, &audio, &n));
+    std::vector<float> out(audio, audio + n);
+    xdtts_free(audio);
+    return out;
+  }
+  xdtts_griffinlim *raw() const { return g_; }
+
+ private:
+  xdtts_griffinlim *g_ = nullptr;
+};
+
+// src/tacotron2/mod.rs:441-458
+inline GriffinLim create_griffin_lim(int device_id = 0) {
+  const Array2 mel_basis = create_mel_filter_bank(22050.0f, 1024, 80, 0.0f, 8000.0f);
+  return GriffinLim(mel_basis, 1024 - 256, 1.7f, 30, 0.99f, device_id);
+}
+
+}  // namespace xdtts

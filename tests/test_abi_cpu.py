@@ -159,3 +159,33 @@ def test_mel_filter_bank_is_host_side_and_bit_exact(pkg, orc):
     assert np.array_equal(B, orc.mel_filter_bank(22050.0, 1024, 80, 0.0, 8000.0))
     # fmax = None -> sr / 2
     assert np.array_equal(pkg.create_mel_filter_bank(16000.0, 512, 40, 0.0, None), orc.mel_filter_bank(16000.0, 512, 40, 0.0, 8000.0))
+
+
+def _build_host_smoke(pkg, tmp_path):
+    import subprocess
+
+    exe = str(tmp_path / "host_smoke")
+    libdir = os.path.dirname(pkg.LIB_PATH)
+    subprocess.check_call(
+        ["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "host_smoke.cpp"), "-o", exe,
+         "-L", libdir, "-lxdtts_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"]
+    )
+    return subprocess.check_output([exe]).decode().splitlines()
+
+
+def test_cpp_host_mirror_links_with_plain_gxx(pkg, tmp_path):
+    """include/xdtts_host.hpp (the C++ mirror of Tacotron2::load/infer, GriffinLim::new/infer) builds
+    with plain g++ against the C ABI -- no HIP headers, no torch."""
+    lines = _build_host_smoke(pkg, tmp_path)
+    assert lines[0].split() == [str(x) for x in KATS["correct_char_id_output"]["expected"]]
+    if pkg.device_count() == 0:
+        assert lines[1] == "no device: status %d" % pkg.XDTTS_ERR_NO_DEVICE
+
+
+@pytest.mark.gpu
+def test_cpp_host_mirror_sanity_on_gpu(pkg, tmp_path):
+    """The reference's tacotron_sanity_test (mod.rs:511-522) through the C++ mirror: 80 rows, >0 cols."""
+    lines = _build_host_smoke(pkg, tmp_path)
+    rows, _x, cols = lines[1].split()[1:]
+    assert int(rows) == 80 and int(cols) > 0
+    assert int(lines[2].split()[1]) == 256 * (int(cols) - 1)
