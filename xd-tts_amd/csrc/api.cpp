@@ -3,6 +3,7 @@
 // device every entry point fails with XDTTS_ERR_NO_DEVICE.
 #include <algorithm>
 #include <cmath>
+#include <map>
 #include <memory>
 #include <mutex>
 
@@ -46,11 +47,66 @@ static void select_device(int device_id) {
   HIP_CHECK(hipSetDevice(device_id));
 }
 
-static float *pinned_alloc(size_t n_floats) {
-  float *p = nullptr;
-  HIP_CHECK(hipHostMalloc((void **)&p, std::max<size_t>(n_floats, 1) * sizeof(float), hipHostMallocDefault));
-  return p;
+// Pinned host buffers handed to the caller.  hipHostMalloc/hipHostFree cost hundreds of
+// microseconds (page pinning), comparable to a whole vocoder run, so released buffers are kept in
+// a small size-classed pool and reused by later calls.
+namespace {
+struct PinnedPool {
+  std::mutex mu;
+  std::map<void *, size_t> live;                     // buffer -> capacity (bytes)
+  std::multimap<size_t, void *> spare;               // capacity -> buffer
+  size_t spare_bytes = 0;
+  static constexpr size_t MAX_SPARE = 256u << 20;
+  static size_t size_class(size_t bytes) {
+    size_t c = 4096;
+    while (c < bytes) c <<= 1;
+    return c;
+  }
+  float *get(size_t bytes) {
+    const size_t cap = size_class(bytes);
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      auto it = spare.find(cap);
+      if (it != spare.end()) {
+        void *p = it->second;
+        spare.erase(it);
+        spare_bytes -= cap;
+        live[p] = cap;
+        return (float *)p;
+      }
+    }
+    void *p = nullptr;
+    HIP_CHECK(hipHostMalloc(&p, cap, hipHostMallocDefault));
+    std::lock_guard<std::mutex> lk(mu);
+    live[p] = cap;
+    return (float *)p;
+  }
+  void put(void *p) {
+    std::unique_lock<std::mutex> lk(mu);
+    auto it = live.find(p);
+    if (it == live.end()) {  // not ours (or already released): leave it to the runtime
+      lk.unlock();
+      (void)hipHostFree(p);
+      return;
+    }
+    const size_t cap = it->second;
+    live.erase(it);
+    if (spare_bytes + cap <= MAX_SPARE) {
+      spare.emplace(cap, p);
+      spare_bytes += cap;
+      return;
+    }
+    lk.unlock();
+    (void)hipHostFree(p);
+  }
+};
+PinnedPool &pinned_pool() {
+  static PinnedPool *pool = new PinnedPool();  // intentionally leaked: outlives static destruction order
+  return *pool;
 }
+}  // namespace
+
+static float *pinned_alloc(size_t n_floats) { return pinned_pool().get(std::max<size_t>(n_floats, 1) * sizeof(float)); }
 
 struct Events {
   hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -84,6 +140,9 @@ struct xdtts_tacotron2 {
   DevBuf<int64_t> ids;
   DevBuf<int> n_valid, limits, nframes, ctl;
   DevBuf<float> xpadA, xpadB, xproj, memory, pmem;
+  DevBuf<unsigned long long> enc_exchange;
+  DevBuf<int> enc_err;
+  static constexpr int COOP_MAX_B = 16;  // 8*B blocks of 1024 threads must be co-resident
   DevBuf<float> att_h, att_c, dec_h, dec_c, aw, awc, ctx, x, dec_in, loc, e_part, frames, gates;
   DevBuf<float> ppA, ppB, mel_dev;
   int *host_ctl = nullptr;  // pinned: [0..1] ctl, [2..] nframes
@@ -105,6 +164,8 @@ struct xdtts_tacotron2 {
     HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     ev.create();
     HIP_CHECK(hipHostMalloc((void **)&host_ctl, sizeof(int) * (2 + 4096), hipHostMallocDefault));
+    enc_err.alloc(1);
+    HIP_CHECK(hipMemsetAsync(enc_err.p, 0, sizeof(int), stream));
     w.upload(blob, stream);
   }
 
@@ -155,7 +216,12 @@ struct xdtts_tacotron2 {
       g.batch = B;
       launch_gemm_nt(g, stream);
     }
-    launch_bilstm(xproj.p, w.enc_whhT[0].p, w.enc_whhT[1].p, memory.p, B, T, stream);
+    if (B <= COOP_MAX_B) {
+      enc_exchange.alloc(bilstm_coop_exchange_words(B));
+      launch_bilstm_coop(xproj.p, w.enc_whhT[0].p, w.enc_whhT[1].p, memory.p, enc_exchange.p, enc_err.p, B, T, stream);
+    } else {
+      launch_bilstm(xproj.p, w.enc_whhT[0].p, w.enc_whhT[1].p, memory.p, B, T, stream);
+    }
     GemmArgs g{};  // processed_memory = memory_layer(memory)
     g.A = memory.p;
     g.lda = EMB;
@@ -359,6 +425,7 @@ struct xdtts_tacotron2 {
     DecoderBufs d = decoder_bufs(B, T, memory.p, pmem.p, o);
     if (fixed_per_item || o.fixed_frames_per_id > 0.f) d.use_gate = 0;
     last_steps = run_decoder(d, lim);
+    check_encoder_exchange();
     HIP_CHECK(hipEventRecord(ev.e[2], stream));
     std::vector<int> F(B);
     int total = 0;
@@ -375,6 +442,17 @@ struct xdtts_tacotron2 {
     HIP_CHECK(hipEventRecord(ev.e[3], stream));
     *F_total = total;
     return F;
+  }
+
+  // the cooperative BiLSTM bounds its spins; a timeout there must not pass silently
+  void check_encoder_exchange() {
+    int e = 0;
+    HIP_CHECK(hipMemcpyAsync(&e, enc_err.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    if (e) {
+      HIP_CHECK(hipMemsetAsync(enc_err.p, 0, sizeof(int), stream));
+      fail(XDTTS_ERR_HIP, "encoder BiLSTM hidden-state exchange timed out");
+    }
   }
 
   void finish_timings() {
@@ -416,10 +494,16 @@ struct xdtts_griffinlim {
   uint32_t seed = 0;
   Events ev;
   float last_ms[3] = {0, 0, 0};
-  DevBuf<float> pinv, win, S, melT, mel_in, frames, y, audio, phase0;
+  DevBuf<float> pinv, win, S, melT, mel_in, frames, wss_inv, audio, phase0;
+  hipGraphExec_t graph = nullptr;  // n_iter x (istft, stft) + final ISTFT for the cached (buffers, F, iterations)
+  GlBufs graph_key{};
+  int graph_iters = -1;
+  float graph_alpha = 0.f;
+  const float *graph_audio = nullptr;
   DevBuf<float2> tw, ang, tprev;
 
   ~xdtts_griffinlim() {
+    if (graph) (void)hipGraphExecDestroy(graph);
     if (stream) (void)hipStreamDestroy(stream);
   }
 
@@ -428,7 +512,7 @@ struct xdtts_griffinlim {
     ang.alloc((size_t)F * nb);
     tprev.alloc((size_t)F * nb);
     frames.alloc((size_t)F * n_fft);
-    y.alloc((size_t)std::max(1, hop * (F - 1)));
+    wss_inv.alloc((size_t)std::max(1, hop * (F - 1)));
     audio.alloc((size_t)std::max(1, hop * (F - 1)));
     GlBufs g{};
     g.F = F;
@@ -439,7 +523,7 @@ struct xdtts_griffinlim {
     g.ang = ang.p;
     g.tprev = tprev.p;
     g.frames = frames.p;
-    g.y = y.p;
+    g.wss_inv = wss_inv.p;
     g.tw = tw.p;
     g.win = win.p;
     return g;
@@ -467,9 +551,35 @@ struct xdtts_griffinlim {
   // phase init + iterations + final ISTFT; S already in place.  Result in audio (device).
   void iterate(const GlBufs &g, const float *phase0_dev, int n_iter) {
     launch_gl_phase_init(g, seed, phase0_dev, stream);
+    launch_gl_prepare(g, stream);
     const float alpha = momentum / (1.0f + momentum);
-    for (int i = 0; i < n_iter; ++i) launch_gl_iteration(g, alpha, stream);
-    launch_gl_final(g, audio.p, stream);
+    // the iteration loop is launch-bound (2 short kernels per iteration): replay it as one hipGraph
+    if (!graph || std::memcmp(&graph_key, &g, sizeof g) != 0 || graph_iters != n_iter || graph_alpha != alpha ||
+        graph_audio != audio.p) {
+      if (graph) {
+        (void)hipGraphExecDestroy(graph);
+        graph = nullptr;
+      }
+      hipGraph_t gr = nullptr;
+      HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+      try {
+        for (int i = 0; i < n_iter; ++i) launch_gl_iteration(g, alpha, stream);
+        launch_gl_final(g, audio.p, stream);
+      } catch (...) {
+        (void)hipStreamEndCapture(stream, &gr);
+        if (gr) (void)hipGraphDestroy(gr);
+        throw;
+      }
+      HIP_CHECK(hipStreamEndCapture(stream, &gr));
+      hipError_t e = hipGraphInstantiate(&graph, gr, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(gr);
+      HIP_CHECK(e);
+      graph_key = g;
+      graph_iters = n_iter;
+      graph_alpha = alpha;
+      graph_audio = audio.p;
+    }
+    HIP_CHECK(hipGraphLaunch(graph, stream));
   }
 
   void finish_timings() {
@@ -557,7 +667,7 @@ int32_t xdtts_device_count(void) {
 }
 
 void xdtts_free(void *p) {
-  if (p) (void)hipHostFree(p);
+  if (p) pinned_pool().put(p);
 }
 
 int32_t xdtts_tensor_count(void) { return (int32_t)tensor_table().size(); }
@@ -728,6 +838,7 @@ xdtts_status xdtts_tacotron2_encoder(xdtts_tacotron2 *h, const int64_t *ids, int
     HIP_CHECK(hipMemcpyAsync(memory, h->memory.p, (size_t)T * EMB * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipMemcpyAsync(processed_memory, h->pmem.p, (size_t)T * ATT_DIM * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->check_encoder_exchange();
   });
 }
 
@@ -816,6 +927,8 @@ xdtts_status xdtts_griffinlim_new(const float *mel_basis, size_t n_mels, size_t 
     const size_t n_fft = 2 * (n_bins - 1);
     if (n_fft != 1024) fail(XDTTS_ERR_BAD_ARG, "n_fft %zu unsupported: the framed-FFT kernel is built for 1024", n_fft);
     if (noverlap >= n_fft) fail(XDTTS_ERR_BAD_ARG, "noverlap %zu must be < n_fft %zu", noverlap, n_fft);
+    if (n_fft - noverlap != n_fft / 4)
+      fail(XDTTS_ERR_BAD_ARG, "hop %zu unsupported: the framed-FFT kernels are built for hop = n_fft/4 = 256 (mod.rs:456)", n_fft - noverlap);
     if (n_mels % 16 != 0) fail(XDTTS_ERR_BAD_ARG, "n_mels %zu must be a multiple of 16", n_mels);
     if (!(power > 0) || momentum < 0) fail(XDTTS_ERR_BAD_ARG, "bad power/momentum");
     select_device(device_id);

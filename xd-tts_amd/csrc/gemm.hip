@@ -8,8 +8,8 @@
 //     (lda = C instead of k*C) -- implicit GEMM with no im2col buffer;
 //   * BiLSTM input projections, the attention memory layer, and the Griffin-Lim mel->linear
 //     product (pinv(mel_basis) . exp(mel)).
-// Tile: 64x64 per 256-thread block (4 waves as 2x2, 32x32 per wave = 2x2 MFMA tiles), K-slab 16
-// staged through LDS with a register prefetch of the next slab.  Within a slab the contraction
+// Tile: 32x32 per 256-thread block (one 16x16 MFMA tile per wave), K-slab 32 staged through LDS
+// with a register prefetch of the next slab.  Within a slab the contraction
 // index is permuted (k = 4*(lane>>4) + kk) so each lane fetches its four K values of a tile row
 // with one ds_read_b128.
 #include "kernels.h"
@@ -20,7 +20,10 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 64, BN = 64, BK = 16, LDS_LD = 20;  // 80-byte rows: 16-B aligned float4 reads
+// 32x32 output tile per 256-thread block (one 16x16 MFMA tile per wave), K-slab 32.  The f32 MFMA
+// issues at 32 cycles per instruction per SIMD, so a block's time is its MFMA count: small tiles
+// put every GEMM of this path (M = 100..800 rows) on 64..400 blocks instead of 16..80.
+constexpr int BM = 32, BN = 32, BK = 32, LDS_LD = 36;  // 144-byte rows: 16-B aligned float4 reads
 
 __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float As[BM * LDS_LD];
@@ -33,67 +36,54 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs g) {
   const float *R = g.R ? g.R + (size_t)z * g.strideR : nullptr;
 
   // global -> LDS assignment: thread loads one float4 of A and one of W per slab
-  const int lr = tid >> 2, lc = (tid & 3) * 4;
+  const int lr = tid >> 3, lc = (tid & 7) * 4;
   const bool a_ok = m0 + lr < g.M, b_ok = n0 + lr < g.N;
   const float *a_src = A + (size_t)(m0 + lr) * g.lda + lc;
   const float *b_src = g.W + (size_t)(n0 + lr) * g.K + lc;
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  f32x4 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  float4 pa = a_ok ? *reinterpret_cast<const float4 *>(a_src) : zero4;
-  float4 pb = b_ok ? *reinterpret_cast<const float4 *>(b_src) : zero4;
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // K is a multiple of 16 but not always of 32: the slab's upper half is zero-filled past K
+  float4 pa = (a_ok && lc < g.K) ? *reinterpret_cast<const float4 *>(a_src) : zero4;
+  float4 pb = (b_ok && lc < g.K) ? *reinterpret_cast<const float4 *>(b_src) : zero4;
   const int fi = lane & 15, fg = lane >> 4;
   for (int k0 = 0; k0 < g.K; k0 += BK) {
     __syncthreads();  // previous slab fully consumed
     *reinterpret_cast<float4 *>(&As[lr * LDS_LD + lc]) = pa;
     *reinterpret_cast<float4 *>(&Bs[lr * LDS_LD + lc]) = pb;
     __syncthreads();
+    const int kn = k0 + BK + lc;
     if (k0 + BK < g.K) {  // prefetch the next slab while this one is multiplied
-      pa = a_ok ? *reinterpret_cast<const float4 *>(a_src + k0 + BK) : zero4;
-      pb = b_ok ? *reinterpret_cast<const float4 *>(b_src + k0 + BK) : zero4;
-    }
-    float4 af[2], bf[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      af[i] = *reinterpret_cast<const float4 *>(&As[(wm * 32 + i * 16 + fi) * LDS_LD + fg * 4]);
-      bf[i] = *reinterpret_cast<const float4 *>(&Bs[(wn * 32 + i * 16 + fi) * LDS_LD + fg * 4]);
+      pa = (a_ok && kn < g.K) ? *reinterpret_cast<const float4 *>(a_src + k0 + BK) : zero4;
+      pb = (b_ok && kn < g.K) ? *reinterpret_cast<const float4 *>(b_src + k0 + BK) : zero4;
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-      }
+    for (int kg = 0; kg < BK / 16; ++kg) {
+      const float4 af = *reinterpret_cast<const float4 *>(&As[(wm * 16 + fi) * LDS_LD + kg * 16 + fg * 4]);
+      const float4 bf = *reinterpret_cast<const float4 *>(&Bs[(wn * 16 + fi) * LDS_LD + kg * 16 + fg * 4]);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bf.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bf.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bf.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bf.w, acc, 0, 0, 0);
+    }
   }
   // epilogue: D register r of lane l holds row (l>>4)*4 + r, column l&15 of its 16x16 tile
+  const int n = n0 + wn * 16 + fi;
+  if (n < g.N) {
+    const float bz = g.bias ? g.bias[n] : 0.f;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + wn * 32 + j * 16 + fi;
-      if (n >= g.N) continue;
-      const float bz = g.bias ? g.bias[n] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wm * 32 + i * 16 + fg * 4 + r;
-        if (m >= g.M) continue;
-        float v = acc[i][j][r] + bz;
-        if (g.act == 1) v = fmaxf(v, 0.f);
-        else if (g.act == 2) v = tanhf(v);
-        else if (g.act == 3) v = powf(fmaxf(v, 0.f), g.p);
-        if (R) v += R[(size_t)m * g.ldr + n];
-        if (g.transpose_out) C[(size_t)n * g.ldc + m] = v;
-        else C[(size_t)m * g.ldc + n] = v;
-      }
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + wm * 16 + fg * 4 + r;
+      if (m >= g.M) continue;
+      float v = acc[r] + bz;
+      if (g.act == 1) v = fmaxf(v, 0.f);
+      else if (g.act == 2) v = tanhf(v);
+      else if (g.act == 3) v = powf(fmaxf(v, 0.f), g.p);
+      if (R) v += R[(size_t)m * g.ldr + n];
+      if (g.transpose_out) C[(size_t)n * g.ldc + m] = v;
+      else C[(size_t)m * g.ldc + n] = v;
     }
+  }
 }
 
 // ids -> embedding rows, written into the interior of the zero-padded conv input
@@ -110,26 +100,72 @@ __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x))
 // Encoder BiLSTM recurrence.  One block per (direction, chunk); thread r owns gate row r of the
 // 1024 (i,f,g,o x 256); W_hh is stored transposed so the 1024 threads read consecutive floats.
 // The input projection W_ih x + b was hoisted out as one GEMM over all T.
+// The recurrence is 100 dependent steps on one CU, so what matters is how much of the 1 MB W_hh
+// has to come through the CU's L2 port every step: each row keeps its first BL_REG weights in
+// registers and the next BL_LDS in LDS (147 KB of the CU's 160 KB) for the whole sequence; only
+// the remaining 156 columns (624 KB) are re-read from L2 per step, BL_CHUNK loads in flight per
+// thread (the 128-VGPR budget of a 1024-thread block bounds BL_REG + BL_CHUNK).
+constexpr int BL_REG = 64, BL_LDS = 36, BL_GLB = ENC_H - BL_REG - BL_LDS, BL_CHUNK = 12;
+static_assert(BL_GLB % BL_CHUNK == 0 && BL_REG % 4 == 0 && BL_LDS % 4 == 0 && BL_CHUNK % 4 == 0, "bilstm column split");
+
 __global__ __launch_bounds__(1024) void k_bilstm(const float *__restrict__ xproj,
                                                  const float *__restrict__ whhT_f,
                                                  const float *__restrict__ whhT_b, float *memory, int B,
                                                  int T) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *h = smem;                       // [256]
+  float *gates = h + ENC_H;              // [1024]
+  float *wl = gates + 4 * ENC_H;         // [BL_LDS][1024]
   const int dir = blockIdx.x, b = blockIdx.y, r = threadIdx.x;
   const float *whhT = dir ? whhT_b : whhT_f;
   const float *xp = xproj + ((size_t)dir * B + b) * T * (4 * ENC_H);
-  __shared__ float h[ENC_H], gates[4 * ENC_H];
+  float wreg[BL_REG];
+#pragma unroll
+  for (int j = 0; j < BL_REG; ++j) wreg[j] = whhT[(size_t)j * (4 * ENC_H) + r];
+  for (int j = 0; j < BL_LDS; ++j) wl[j * (4 * ENC_H) + r] = whhT[(size_t)(BL_REG + j) * (4 * ENC_H) + r];
+  const float *wg = whhT + (size_t)(BL_REG + BL_LDS) * (4 * ENC_H) + r;
   float c = 0.f;
   if (r < ENC_H) h[r] = 0.f;
   __syncthreads();
   for (int s = 0; s < T; ++s) {
     const int t = dir ? T - 1 - s : s;
+    // first chunk of the L2-served columns goes out before the register/LDS part
+    float gv[BL_CHUNK];
+#pragma unroll
+    for (int j = 0; j < BL_CHUNK; ++j) gv[j] = wg[(size_t)j * (4 * ENC_H)];
     float a0 = xp[(size_t)t * (4 * ENC_H) + r], a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll 8
-    for (int j = 0; j < ENC_H; j += 4) {
-      a0 = fmaf(whhT[(size_t)(j + 0) * (4 * ENC_H) + r], h[j + 0], a0);
-      a1 = fmaf(whhT[(size_t)(j + 1) * (4 * ENC_H) + r], h[j + 1], a1);
-      a2 = fmaf(whhT[(size_t)(j + 2) * (4 * ENC_H) + r], h[j + 2], a2);
-      a3 = fmaf(whhT[(size_t)(j + 3) * (4 * ENC_H) + r], h[j + 3], a3);
+#pragma unroll
+    for (int j = 0; j < BL_REG; j += 4) {
+      a0 = fmaf(wreg[j + 0], h[j + 0], a0);
+      a1 = fmaf(wreg[j + 1], h[j + 1], a1);
+      a2 = fmaf(wreg[j + 2], h[j + 2], a2);
+      a3 = fmaf(wreg[j + 3], h[j + 3], a3);
+    }
+#pragma unroll
+    for (int j = 0; j < BL_LDS; j += 4) {
+      a0 = fmaf(wl[(j + 0) * (4 * ENC_H) + r], h[BL_REG + j + 0], a0);
+      a1 = fmaf(wl[(j + 1) * (4 * ENC_H) + r], h[BL_REG + j + 1], a1);
+      a2 = fmaf(wl[(j + 2) * (4 * ENC_H) + r], h[BL_REG + j + 2], a2);
+      a3 = fmaf(wl[(j + 3) * (4 * ENC_H) + r], h[BL_REG + j + 3], a3);
+    }
+#pragma unroll 1
+    for (int j0 = 0; j0 < BL_GLB; j0 += BL_CHUNK) {
+      float nx[BL_CHUNK];
+      if (j0 + BL_CHUNK < BL_GLB) {
+#pragma unroll
+        for (int j = 0; j < BL_CHUNK; ++j) nx[j] = wg[(size_t)(j0 + BL_CHUNK + j) * (4 * ENC_H)];
+      }
+#pragma unroll
+      for (int j = 0; j < BL_CHUNK; j += 4) {
+        a0 = fmaf(gv[j + 0], h[BL_REG + BL_LDS + j0 + j + 0], a0);
+        a1 = fmaf(gv[j + 1], h[BL_REG + BL_LDS + j0 + j + 1], a1);
+        a2 = fmaf(gv[j + 2], h[BL_REG + BL_LDS + j0 + j + 2], a2);
+        a3 = fmaf(gv[j + 3], h[BL_REG + BL_LDS + j0 + j + 3], a3);
+      }
+      if (j0 + BL_CHUNK < BL_GLB) {
+#pragma unroll
+        for (int j = 0; j < BL_CHUNK; ++j) gv[j] = nx[j];
+      }
     }
     gates[r] = (a0 + a1) + (a2 + a3);
     __syncthreads();
@@ -159,7 +195,7 @@ __global__ void k_transpose(const float *in, float *out, int rows, int cols) {
 }  // namespace
 
 void launch_gemm_nt(const GemmArgs &g, hipStream_t s) {
-  if (g.K % BK != 0 || g.lda % 4 != 0) fail(XDTTS_ERR_BAD_ARG, "gemm: K=%d lda=%ld not supported", g.K, g.lda);
+  if (g.K % 16 != 0 || g.lda % 4 != 0) fail(XDTTS_ERR_BAD_ARG, "gemm: K=%d lda=%ld not supported", g.K, g.lda);
   dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.batch);
   hipLaunchKernelGGL(k_gemm_nt, grid, dim3(256), 0, s, g);
   HIP_CHECK(hipGetLastError());
@@ -172,7 +208,13 @@ void launch_embed(const int64_t *ids, const float *emb, float *xpad, int B, int 
 
 void launch_bilstm(const float *xproj, const float *whhT_fwd, const float *whhT_bwd, float *memory, int B,
                    int T, hipStream_t s) {
-  hipLaunchKernelGGL(k_bilstm, dim3(2, B), dim3(1024), 0, s, xproj, whhT_fwd, whhT_bwd, memory, B, T);
+  const size_t lds = sizeof(float) * (ENC_H + 4 * ENC_H + (size_t)BL_LDS * 4 * ENC_H);
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bilstm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_bilstm, dim3(2, B), dim3(1024), lds, s, xproj, whhT_fwd, whhT_bwd, memory, B, T);
   HIP_CHECK(hipGetLastError());
 }
 

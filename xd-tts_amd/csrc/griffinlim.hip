@@ -10,7 +10,9 @@
 // LDS used only for the two inter-pass exchanges (conflict-free: lanes touch consecutive float2).
 // The real<->complex split/merge twiddle step is fused into the first/last pass, the synthesis
 // and analysis windows and the magnitude projection are fused into the loads/stores, so one
-// iteration touches S, angles, the previous rebuilt spectrum and the signal exactly once each.
+// iteration touches S, angles and the previous rebuilt spectrum exactly once each; the overlap-add
+// is folded into the STFT's gather (four L2-resident frame reads per sample), so an iteration is
+// two kernels: k_istft_frames -> k_stft_update.
 #include "kernels.h"
 
 namespace xdtts {
@@ -50,23 +52,40 @@ __device__ __forceinline__ void fft8(float2 (&v)[8]) {
   v[7] = csub(d1, d3);
 }
 
+// Per-lane twiddles of the two twiddled passes, pulled from the table once at kernel entry (in
+// the same memory round trip as the frame's data) so the FFT itself never waits on global memory.
+struct Twiddles {
+  float2 p8[7];   // pass Ns = 8 : e^{-2 pi i r k / 64},  k = lane & 7  -> table index r*k*16
+  float2 p64[7];  // pass Ns = 64: e^{-2 pi i r k / 512}, k = lane      -> table index r*k*2
+};
+__device__ __forceinline__ Twiddles load_twiddles(const float2 *__restrict__ tw, int lane) {
+  Twiddles t;
+  const int k = lane & 7;
+#pragma unroll
+  for (int r = 1; r < 8; ++r) {
+    t.p8[r - 1] = tw[r * k * 16];
+    t.p64[r - 1] = tw[r * lane * 2];
+  }
+  return t;
+}
+
 // 512-point forward complex FFT of one wave.  In: v[r] = x[lane + 64 r].  Runs Stockham passes
 // Ns = 1 and 8 through `buf` (512 float2 of LDS owned by this wave) and the twiddle + butterfly
 // of pass Ns = 64; on return v[r] = X[lane + 64 r] (natural order), nothing left in LDS.
 // Must be called by all waves of the block (contains __syncthreads()).
-__device__ __forceinline__ void fft512(float2 (&v)[8], float2 *buf, const float2 *__restrict__ tw, int lane) {
+__device__ __forceinline__ void fft512(float2 (&v)[8], float2 *buf, const Twiddles &t, int lane) {
   // pass Ns = 1: no twiddles; out[8 j + r]
   fft8(v);
 #pragma unroll
   for (int r = 0; r < 8; ++r) buf[8 * lane + r] = v[r];
   __syncthreads();
-  // pass Ns = 8: twiddle e^{-2 pi i r k / 64}, k = j & 7 -> table index r*k*16
+  // pass Ns = 8
   {
     const int k = lane & 7;
 #pragma unroll
     for (int r = 0; r < 8; ++r) v[r] = buf[lane + 64 * r];
 #pragma unroll
-    for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], tw[r * k * 16]);
+    for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], t.p8[r - 1]);
     fft8(v);
     __syncthreads();
     const int j0 = (lane >> 3) * 64 + k;
@@ -74,11 +93,11 @@ __device__ __forceinline__ void fft512(float2 (&v)[8], float2 *buf, const float2
     for (int r = 0; r < 8; ++r) buf[j0 + 8 * r] = v[r];
   }
   __syncthreads();
-  // pass Ns = 64: twiddle e^{-2 pi i r k / 512}, k = j -> table index r*k*2; out[j + 64 r]
+  // pass Ns = 64; out[j + 64 r]
 #pragma unroll
   for (int r = 0; r < 8; ++r) v[r] = buf[lane + 64 * r];
 #pragma unroll
-  for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], tw[r * lane * 2]);
+  for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], t.p64[r - 1]);
   fft8(v);
 }
 
@@ -94,6 +113,7 @@ __global__ __launch_bounds__(256) void k_istft_frames(GlBufs g) {
   const int f = ok ? fr : g.F - 1;
   const float *S = g.S + (size_t)f * g.nb;
   const float2 *A = g.ang + (size_t)f * g.nb;
+  const Twiddles tws = load_twiddles(g.tw, lane);
   float2 v[8];
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
@@ -112,7 +132,7 @@ __global__ __launch_bounds__(256) void k_istft_frames(GlBufs g) {
     // Z = E + i O ; feed conj(Z) to the forward FFT (inverse = conj(FFT(conj Z)) / 512)
     v[r] = make_float2(e.x - o.y, -(e.y + o.x));
   }
-  fft512(v, lds[wave], g.tw, lane);
+  fft512(v, lds[wave], tws, lane);
   if (!ok) return;
   float2 *out = reinterpret_cast<float2 *>(g.frames + (size_t)f * g.n_fft);
   const float2 *win = reinterpret_cast<const float2 *>(g.win);
@@ -125,29 +145,55 @@ __global__ __launch_bounds__(256) void k_istft_frames(GlBufs g) {
   }
 }
 
-// Overlap-add + window sum-of-squares normalisation + centre trim:
-//   y[n] = sum_j frames[j][n + 512 - 256 j] / sum_j win^2[n + 512 - 256 j],  n in [0, hop (F-1))
-__global__ void k_overlap_add(GlBufs g, float *y) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  const int N = g.hop * (g.F - 1);
-  if (n >= N) return;
-  const int p = n + g.n_fft / 2;
-  int j1 = p / g.hop;
-  if (j1 > g.F - 1) j1 = g.F - 1;
-  int j0 = (p - g.n_fft + g.hop) / g.hop;  // ceil((p - (n_fft-1)) / hop)
-  if (p - g.n_fft + 1 <= 0) j0 = 0;
-  float acc = 0.f, wss = 0.f;
-  for (int j = j0; j <= j1; ++j) {
-    const int i = p - j * g.hop;
-    const float w = g.win[i];
-    acc += g.frames[(size_t)j * g.n_fft + i];
-    wss = fmaf(w, w, wss);
+// One sample of the ISTFT output (overlap-add of the windowed frames, window-sum-square
+// normalised, centre-trimmed) gathered straight from the per-frame buffer: at hop = n_fft/4 four
+// frames cover a sample.  wss_inv is precomputed per F.
+constexpr int NFFT = 1024, HOP = 256;  // the reference's vocoder geometry (mod.rs:453-456); checked at GriffinLim::new
+
+__device__ __forceinline__ float ola_sample(const GlBufs &g, int n) {
+  // hop = n_fft/4: sample q of the un-trimmed signal lies in frames jb-3..jb at offsets
+  // (q mod hop) + k*hop; frames outside [0, F) contribute nothing.  Branch-free: four independent
+  // loads so a lane's 16 samples keep 64 loads in flight.  Shifts, not divisions.
+  const int q = n + NFFT / 2;
+  const int jb = q >> 8, r = q & (HOP - 1);
+  float v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int j = jb - k;
+    const bool in = j >= 0 && j < g.F;
+    v[k] = g.frames[(size_t)(in ? j : 0) * NFFT + r + k * HOP];
+    v[k] = in ? v[k] : 0.f;
   }
-  y[n] = wss > 1.17549435e-38f ? acc / wss : acc;
+  // ascending frame order and a true division, like the CPU path, so rounding matches it
+  return (((v[3] + v[2]) + v[1]) + v[0]) / g.wss_inv[n];
 }
 
-// STFT + phase update, one wave per frame: reflect-padded gather of y, analysis window,
-// rfft(1024), then  a = rebuilt - alpha * tprev;  tprev = rebuilt;  angles = a / (|a| + 1e-16).
+// numpy "reflect" padding index: mirror without repeating the edge sample; one fold for normal
+// sizes, a few for signals shorter than the pad
+__device__ __forceinline__ int reflect_index(int p, int N) {
+  while (p < 0 || p >= N) p = p < 0 ? -p : 2 * (N - 1) - p;
+  return p;
+}
+
+// window sum-of-squares divisor per output sample (1 where the sum is below tiny, like librosa)
+__global__ void k_wss_inv(GlBufs g) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= g.hop * (g.F - 1)) return;
+  const int q = n + NFFT / 2;
+  const int jb = q >> 8, r = q & (HOP - 1);
+  float wss = 0.f;
+#pragma unroll
+  for (int k = 3; k >= 0; --k) {
+    const int j = jb - k;
+    const float w = g.win[r + k * HOP];
+    wss = (j >= 0 && j < g.F) ? wss + w * w : wss;
+  }
+  g.wss_inv[n] = wss > 1.17549435e-38f ? wss : 1.0f;  // the divisor (1 where the sum is below tiny)
+}
+
+// STFT + phase update, one wave per frame: the frame's 1024 samples are gathered from the
+// overlap-added ISTFT frames (reflect padding at the ends), analysis window, rfft(1024), then
+//   a = rebuilt - alpha * tprev;  tprev = rebuilt;  angles = a / (|a| + 1e-16).
 __global__ __launch_bounds__(256) void k_stft_update(GlBufs g, float alpha) {
   __shared__ float2 lds[FRAMES_PER_BLOCK][512];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -156,24 +202,18 @@ __global__ __launch_bounds__(256) void k_stft_update(GlBufs g, float alpha) {
   const int f = ok ? fr : g.F - 1;
   const int N = g.hop * (g.F - 1);
   const float2 *win = reinterpret_cast<const float2 *>(g.win);
+  const Twiddles tws = load_twiddles(g.tw, lane);
   float2 v[8];
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
     const int m = lane + 64 * r;
-    // "reflect" padding with period 2(N-1): one mirror normally, repeated folds for tiny signals
-    int p0 = f * g.hop + 2 * m - g.n_fft / 2, p1 = p0 + 1;
-    const int period = 2 * (N - 1);
-    p0 %= period;
-    p1 %= period;
-    p0 = p0 < 0 ? p0 + period : p0;
-    p1 = p1 < 0 ? p1 + period : p1;
-    p0 = p0 >= N ? period - p0 : p0;
-    p1 = p1 >= N ? period - p1 : p1;
+    const int base = f * HOP + 2 * m - NFFT / 2;
+    const int p0 = reflect_index(base, N), p1 = reflect_index(base + 1, N);
     const float2 w = win[m];
-    v[r] = make_float2(g.y[p0] * w.x, g.y[p1] * w.y);
+    v[r] = make_float2(ola_sample(g, p0) * w.x, ola_sample(g, p1) * w.y);
   }
   float2 *buf = lds[wave];
-  fft512(v, buf, g.tw, lane);
+  fft512(v, buf, tws, lane);
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < 8; ++r) buf[lane + 64 * r] = v[r];
@@ -196,6 +236,13 @@ __global__ __launch_bounds__(256) void k_stft_update(GlBufs g, float alpha) {
     const float mag = sqrtf(fmaf(a.x, a.x, a.y * a.y)) + 1e-16f;
     ang[k] = make_float2(a.x / mag, a.y / mag);
   }
+}
+
+// Final ISTFT output: overlap-add + normalisation + centre trim for every sample.
+__global__ void k_overlap_add(GlBufs g, float *y) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= g.hop * (g.F - 1)) return;
+  y[n] = ola_sample(g, n);
 }
 
 // angles = exp(2 pi i u), u from the counter RNG keyed (seed, frame*nb + bin); or a caller-supplied
@@ -239,11 +286,15 @@ void launch_gl_phase_init(const GlBufs &g, uint32_t seed, const float *phase0_de
   HIP_CHECK(hipGetLastError());
 }
 
+void launch_gl_prepare(const GlBufs &g, hipStream_t s) {
+  const int N = g.hop * (g.F - 1);
+  hipLaunchKernelGGL(k_wss_inv, dim3((N + 255) / 256), dim3(256), 0, s, g);
+  HIP_CHECK(hipGetLastError());
+}
+
 void launch_gl_iteration(const GlBufs &g, float alpha, hipStream_t s) {
   const int nblk = (g.F + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK;
-  const int N = g.hop * (g.F - 1);
   hipLaunchKernelGGL(k_istft_frames, dim3(nblk), dim3(256), 0, s, g);
-  hipLaunchKernelGGL(k_overlap_add, dim3((N + 255) / 256), dim3(256), 0, s, g, g.y);
   hipLaunchKernelGGL(k_stft_update, dim3(nblk), dim3(256), 0, s, g, alpha);
   HIP_CHECK(hipGetLastError());
 }

@@ -63,6 +63,12 @@ void launch_embed(const int64_t *ids, const float *emb, float *xpad, int B, int 
 void launch_bilstm(const float *xproj, const float *whhT_fwd, const float *whhT_bwd, float *memory,
                    int B, int T, hipStream_t s);
 
+// Same recurrence spread over 4 CUs per (direction, chunk) with W_hh resident in registers and a
+// tagged-granule exchange of the hidden state (encoder.hip).  Needs all 8*B blocks co-resident.
+size_t bilstm_coop_exchange_words(int B);
+void launch_bilstm_coop(const float *xproj, const float *whhT_fwd, const float *whhT_bwd, float *memory,
+                        unsigned long long *exchange, int *err, int B, int T, hipStream_t s);
+
 // ---- Griffin-Lim -------------------------------------------------------------------------------
 struct GlBufs {
   int F, n_fft, hop, nb;   // frames, 1024, 256, 513
@@ -70,13 +76,14 @@ struct GlBufs {
   float2 *ang;             // [F][nb]        unit-modulus phase estimate
   float2 *tprev;           // [F][nb]        previous rebuilt spectrum
   float *frames;           // [F][n_fft]     windowed time frames
-  float *y;                // [hop*(F-1)]    overlap-added signal
+  float *wss_inv;          // [hop*(F-1)]    window sum-of-squares divisor per output sample
   const float2 *tw;        // [n_fft]        exp(-2*pi*i*k/n_fft)
   const float *win;        // [n_fft]        periodic hann
 };
 void launch_gl_exp_transpose(const float *mel_80xF, float *out_Fx80, int n_mels, int F, hipStream_t s);
 void launch_gl_phase_init(const GlBufs &g, uint32_t seed, const float *phase0_dev, hipStream_t s);
-void launch_gl_iteration(const GlBufs &g, float alpha, hipStream_t s);   // istft -> stft -> update
+void launch_gl_prepare(const GlBufs &g, hipStream_t s);                  // wss_inv for this F
+void launch_gl_iteration(const GlBufs &g, float alpha, hipStream_t s);   // istft -> stft (+OLA gather) + update
 void launch_gl_final(const GlBufs &g, float *audio, hipStream_t s);      // istft of S*ang
 void launch_transpose(const float *in, float *out, int rows, int cols, hipStream_t s);
 
