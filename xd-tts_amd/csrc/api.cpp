@@ -143,7 +143,7 @@ struct xdtts_tacotron2 {
   DevBuf<unsigned long long> enc_exchange;
   DevBuf<int> enc_err;
   static constexpr int COOP_MAX_B = 16;  // 8*B blocks of 1024 threads must be co-resident
-  DevBuf<float> att_h, att_c, dec_h, dec_c, aw, awc, ctx, x, dec_in, loc, e_part, frames, gates;
+  DevBuf<float> att_h, att_c, dec_h, dec_c, aw, awc, ctx, x, loc, e_part, pmel, frames, gates;
   DevBuf<float> ppA, ppB, mel_dev;
   int *host_ctl = nullptr;  // pinned: [0..1] ctl, [2..] nframes
 
@@ -247,9 +247,9 @@ struct xdtts_tacotron2 {
     awc.alloc((size_t)B * T);
     ctx.alloc((size_t)B * EMB);
     x.alloc((size_t)B * PRENET);
-    dec_in.alloc((size_t)B * N_MEL);
     loc.alloc((size_t)B * T * ATT_DIM);
     e_part.alloc((size_t)B * (ATT_DIM / 4) * T);
+    pmel.alloc(decoder_pmel_floats(B));
     frames.alloc((size_t)B * ms * N_MEL);
     gates.alloc((size_t)B * ms);
     nframes.alloc(B);
@@ -270,9 +270,9 @@ struct xdtts_tacotron2 {
     d.awc = awc.p;
     d.ctx = ctx.p;
     d.x = x.p;
-    d.dec_in = dec_in.p;
     d.loc = loc.p;
     d.e_part = e_part.p;
+    d.pmel = pmel.p;
     d.frames = frames.p;
     d.gates = gates.p;
     d.nframes = nframes.p;
@@ -329,6 +329,7 @@ struct xdtts_tacotron2 {
         replay_steps(d);
         launched += GRAPH_STEPS;
       }
+      launch_decoder_flush(d, w, stream);
       fetch();
     } else {
       const int check_every = 3 * GRAPH_STEPS;
@@ -342,6 +343,9 @@ struct xdtts_tacotron2 {
         for (int b = 0; b < d.B; ++b) need = std::max(need, host_ctl[2 + b]);
         if (host_ctl[0] >= need || launched >= max_lim) break;
       }
+      // the projection of step s is completed by the first kernel of step s+1: finish the last one
+      launch_decoder_flush(d, w, stream);
+      fetch();
     }
     int steps = 0;
     for (int b = 0; b < d.B; ++b) steps = std::max(steps, host_ctl[2 + b]);

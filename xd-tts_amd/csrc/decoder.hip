@@ -5,46 +5,71 @@
 // device here so the host is out of the loop.  B independent chunks advance in lock-step; a chunk
 // is active at step s iff s < nframes[b].
 //
-// Per step, six kernels in stream order (each a grid-wide dependency of the next):
-//   k_prenet -> k_lstm<ATT> -> k_qenergy -> k_softmax_ctx
-//   -> k_lstm<DEC> (+ next step's location-feature blocks) -> k_project
-// The two LSTM GEMVs stream 71.3 MB of fp32 weights per step and are the HBM-bound part; rows
-// are packed [unit][gate][cols] so each wave reads one contiguous 4-row slab with 16-byte
-// lane-consecutive loads (1 KiB per wave instruction) and owns a hidden unit end-to-end, which
-// fuses the cell update into the GEMV.  Everything else is latency-bound glue, arranged so that
-// no single CU carries a long serial section: the location features (which depend only on the
-// previous step's weights) ride along as extra blocks of the previous decoder-LSTM launch, the
-// energies are spread over 32 blocks by attention dimension, softmax + context over 8.
+// A step is a chain of dependent launches, and on this chip a dependent launch costs ~1.6 us before
+// it does anything (tools/ubench_chain.hip), so the design minimises the number of grid-wide
+// dependencies without serialising work onto few CUs.  The textbook chain has six stages (prenet,
+// attention LSTM, query+energies, softmax/context, decoder LSTM, projection); the projection
+// needs ALL of h_dec and ctx, which is what makes it a stage.  Here the producers of h_dec and ctx
+// emit, in their epilogue, the partial products of their own hidden units / context columns with
+// the matching columns of W_p, and the FIRST kernel of the next step sums the 264 partial vectors
+// in a fixed order -- the projection stage disappears:
 //
-// Latency discipline: a step is a chain of six dependent launches, so every kernel is written to
-// cost ONE memory round trip: all weight and activation loads are issued at kernel entry, before
-// anything that depends on the device-side step counter.  To make the activation addresses known
-// at entry, the ping-pong parity of the recurrent state is a kernel argument (`cur`, fixed per
-// graph node: replays always start on an even step) and the previous mel frame lives in a
-// fixed-address state buffer (dec_in, the reference's "decoder_input", mod.rs:285,332).  The step
-// counter / per-chunk activity is only consulted to gate the final stores.  Wavefront = 64.
+//   k_prenet      mel(s-1) = b + sum of partials -> frames[s-1], gate, stop rule; prenet -> x
+//   k_lstm<ATT>   attention LSTM cell (29.4 MB weight stream)
+//   k_qenergy     query rows + partial energies, spread over 32 blocks by attention dimension
+//   k_softmax_ctx masked softmax, context (8 blocks), partial mel of the context columns
+//   k_lstm<DEC>   decoder LSTM cell (42 MB weight stream) + partial mel of its hidden units;
+//                 leading blocks compute the NEXT step's location features
+// (The same trick for the query -- partial q from the attention-LSTM blocks, energies + softmax +
+// context merged into one launch -- was built and measured: the merged kernel computes all 12.8k
+// tanh terms redundantly in each of its 8 blocks and took 7.9 us against 2.4 + 3.3 us for the two
+// distributed launches, so the query stage stays.)
+//
+// The LSTM GEMVs stream 71.3 MB of fp32 weights per step and are the HBM-bound part; rows are
+// packed [unit][gate][cols] so each wave reads one contiguous 4-row slab with 16-byte
+// lane-consecutive non-temporal loads (1 KiB per wave instruction) and owns a hidden unit
+// end-to-end, which fuses the cell update into the GEMV.
+//
+// Latency discipline: every kernel costs ONE memory round trip: all weight and activation loads
+// are issued at kernel entry.  The ping-pong parity of the recurrent state and the position `i`
+// of the step inside the replayed graph are kernel arguments; the absolute step is ctl[0] + i,
+// with ctl[0] advanced once per replay (k_advance).  Wavefront = 64 everywhere.
 #include <cstdlib>
 #include <string>
 
 #include "kernels.h"
 
-#ifndef XDTTS_NT_MASK
-#define XDTTS_NT_MASK 3  // bit KIND set: that LSTM streams its weights with non-temporal loads
-#endif
-
 namespace xdtts {
 
 namespace {
 
+// Wave-wide reductions on the DPP data path (VALU cross-lane moves, a few cycles each) instead of
+// __shfl_xor, which lowers to ds_bpermute: six dependent LDS-crossbar round trips (~100 cycles
+// each) per reduction were a visible part of every latency-bound kernel here.  Sequence (rocPRIM's
+// wave64 pattern for gfx9): quad_perm swaps, row_ror:4, row_ror:8 leave each 16-lane row's total
+// in all its lanes; row_bcast:15 adds row 0 into row 1 and row 2 into row 3; row_bcast:31 adds
+// rows 0+1 into rows 2,3; lane 63 then holds the total and is broadcast with readlane.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move(float old, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_move<0xB1, 0xf>(0.f, v);   // quad_perm:[1,0,3,2]
+  v += dpp_move<0x4E, 0xf>(0.f, v);   // quad_perm:[2,3,0,1]
+  v += dpp_move<0x124, 0xf>(0.f, v);  // row_ror:4
+  v += dpp_move<0x128, 0xf>(0.f, v);  // row_ror:8
+  v += dpp_move<0x142, 0xa>(0.f, v);  // row_bcast:15 -> rows 1, 3
+  v += dpp_move<0x143, 0xc>(0.f, v);  // row_bcast:31 -> rows 2, 3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dpp_move<0xB1, 0xf>(v, v));
+  v = fmaxf(v, dpp_move<0x4E, 0xf>(v, v));
+  v = fmaxf(v, dpp_move<0x124, 0xf>(v, v));
+  v = fmaxf(v, dpp_move<0x128, 0xf>(v, v));
+  v = fmaxf(v, dpp_move<0x142, 0xa>(v, v));
+  v = fmaxf(v, dpp_move<0x143, 0xc>(v, v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float dot4(float4 a, float4 b, float acc) {
   acc = fmaf(a.x, b.x, acc);
@@ -53,6 +78,13 @@ __device__ __forceinline__ float dot4(float4 a, float4 b, float acc) {
   acc = fmaf(a.w, b.w, acc);
   return acc;
 }
+// streamed-once weights: non-temporal so the two GEMV streams do not evict the ~2 MB of
+// small-kernel weights and partial buffers from the 4 MB-per-XCD L2
+__device__ __forceinline__ float4 ld_stream(const float4 *p) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 // src/tacotron2/mod.rs:126-133: the two-branch sigmoid applied to the gate logit on the host
 __device__ __forceinline__ float gate_sigmoid(float x) {
@@ -60,6 +92,12 @@ __device__ __forceinline__ float gate_sigmoid(float x) {
   const float e = expf(x);
   return e / (1.0f + e);
 }
+
+constexpr int NBLK = ATT_RNN / 4;   // 256 LSTM blocks, 4 hidden units each (both LSTMs)
+constexpr int MEL_LD = 84;          // 80 mel + gate, padded to a float4 multiple
+constexpr int CTX_BLOCKS = 8, CTX_COLS = EMB / CTX_BLOCKS;
+constexpr int PM_ROWS = CTX_BLOCKS + NBLK;  // partial-mel rows per chunk: 8 ctx blocks, then 256 h blocks
+static_assert(ATT_RNN == DEC_RNN, "both LSTMs use 256 blocks of 4 units");
 
 // DecoderState::new (mod.rs:202-233): all recurrent state zero.
 __global__ void k_decoder_init(DecoderBufs d, const int *limits) {
@@ -77,22 +115,20 @@ __global__ void k_decoder_init(DecoderBufs d, const int *limits) {
     d.awc[b * d.T + i] = 0.f;
   }
   for (int i = threadIdx.x; i < EMB; i += blockDim.x) d.ctx[b * EMB + i] = 0.f;
-  for (int i = threadIdx.x; i < N_MEL; i += blockDim.x) d.dec_in[b * N_MEL + i] = 0.f;
-  // location features of step 0: conv/dense of all-zero attention weights
+  // step 0: location features of all-zero attention weights
   for (int i = threadIdx.x; i < d.T * ATT_DIM; i += blockDim.x) d.loc[(size_t)b * d.T * ATT_DIM + i] = 0.f;
   if (threadIdx.x == 0) {
     d.nframes[b] = limits[b];
-    if (b == 0) {
-      d.ctl[0] = 0;
-      d.ctl[1] = 0;
-    }
+    if (b == 0) d.ctl[0] = 0;
   }
 }
+
+__global__ void k_advance(DecoderBufs d, int n) { d.ctl[0] += n; }
 
 // Location features of D3 for one (chunk, LOC_TT-step tile):
 //   loc[t][a] = Dense32->128(Conv1d(2->32, k=31, pad=15)([w_prev ; w_cum]))[t][a]
 // They depend only on the previous step's attention weights, so these blocks ride along in the
-// previous step's k_lstm<DEC> launch instead of sitting on the attention critical path.
+// previous step's k_dec_lstm launch instead of sitting on the attention critical path.
 // loc_convT is the conv weight re-laid as [c][k][f] (filter index contiguous) so each thread pulls
 // its 62 taps with lane-consecutive loads and keeps them in registers; the zero-padded weight
 // windows are the only LDS operands of the conv.
@@ -138,34 +174,84 @@ __device__ __forceinline__ void location_role(const DecoderBufs &d, int b, int t
   }
 }
 
-// D1 prenet: x = relu(W1 relu(W0 mel_prev) * m0 * 2) * m1 * 2, no bias, Bernoulli(0.5) masks from
-// the counter RNG (the exported graph keeps this dropout on at inference).  First kernel of a
-// step, spread over PRENET_BLOCKS blocks per chunk so no CU carries the 336 KB of weights alone:
-// every block recomputes layer 1 (80 KB, L2-resident) and owns 256/PRENET_BLOCKS output columns
-// of layer 2.
+// D5 + D6 + D1.  First launch of step s.
+//  * projection of the PREVIOUS step, finished here: mel(s-1)[m] = b_p[m] + sum of the 8 context
+//    partials (k_attention) and the 256 hidden-state partials (k_dec_lstm), m = 80 is the gate
+//    logit.  Block 0 of the chunk stores frames[s-1] / gates[s-1] and applies the stop rule of
+//    mod.rs:319-324 (sigmoid(gate) > threshold; the tripping frame is kept): nframes[b] = s.
+//    Every block takes the same decision from the same sums.
+//  * prenet: x = relu(W1 relu(W0 mel) * m0 * 2) * m1 * 2, no bias, Bernoulli(0.5) masks from the
+//    counter RNG (the exported graph keeps this dropout on at inference).  Spread over
+//    PRENET_BLOCKS blocks per chunk: every block recomputes layer 1 (80 KB, L2-resident) and owns
+//    256/PRENET_BLOCKS output columns of layer 2.
+// `flush` (after the last step of a sequence): only the projection part runs.
 constexpr int PRENET_BLOCKS = 16, PRENET_COLS = PRENET / PRENET_BLOCKS;
 
-__global__ __launch_bounds__(256) void k_prenet(DecoderBufs d, const float *__restrict__ W0T,
-                                                const float *__restrict__ W1T) {
-  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  __shared__ __attribute__((aligned(16))) float s_mel[N_MEL], s_x1[PRENET], s_part[4][PRENET], s_out[4][PRENET_COLS];
-  // all weight loads first, 16 B per lane.  Layer 1: wave w covers inputs [20w, 20w+20) for the
-  // four output columns 4*lane..4*lane+3.  Layer-2 slice (PRENET_COLS = 16 columns of this block):
+__global__ __launch_bounds__(256) void k_prenet(DecoderBufs d, int i, int flush, const float *__restrict__ W0T,
+                                                const float *__restrict__ W1T,
+                                                const float *__restrict__ proj_b) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / PRENET_BLOCKS, jblk = blockIdx.x % PRENET_BLOCKS;
+  __shared__ __attribute__((aligned(16))) float s_mel[MEL_LD], s_x1[PRENET], s_part[4][PRENET], s_out[4][PRENET_COLS];
+  __shared__ __attribute__((aligned(16))) float s_red[8][MEL_LD];
+  // partial-mel rows: thread (m4, part) sums rows part, part+8, ... of the chunk's 264 rows for
+  // the four mel bins 4*m4..4*m4+3 -- 33 independent 16-byte loads
+  const int m4 = tid & 31, part = tid >> 5;
+  const float4 *pm = reinterpret_cast<const float4 *>(d.pmel + (size_t)b * PM_ROWS * MEL_LD);
+  float4 racc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (m4 < MEL_LD / 4) {
+    float4 rv[PM_ROWS / 8];
+#pragma unroll
+    for (int k = 0; k < PM_ROWS / 8; ++k) rv[k] = pm[(size_t)(part + 8 * k) * (MEL_LD / 4) + m4];
+#pragma unroll
+    for (int k = 0; k < PM_ROWS / 8; ++k) {
+      racc.x += rv[k].x;
+      racc.y += rv[k].y;
+      racc.z += rv[k].z;
+      racc.w += rv[k].w;
+    }
+  }
+  // prenet weights, 16 B per lane.  Layer 1: wave w covers inputs [20w, 20w+20) for the four
+  // output columns 4*lane..4*lane+3.  Layer-2 slice (PRENET_COLS = 16 columns of this block):
   // thread (c4, ig) covers inputs ig, ig+64, ig+128, ig+192 for columns col0 + 4*c4 .. +3.
   const float4 *W0 = reinterpret_cast<const float4 *>(W0T), *W1 = reinterpret_cast<const float4 *>(W1T);
   constexpr int L1_PER_WAVE = N_MEL / 4;
   float4 w0[L1_PER_WAVE];
-#pragma unroll
-  for (int k = 0; k < L1_PER_WAVE; ++k) w0[k] = W0[(wave * L1_PER_WAVE + k) * (PRENET / 4) + lane];
-  const int c4 = tid & 3, ig = tid >> 2, col0 = blockIdx.x * PRENET_COLS;
   float4 w1[4];
+  const int c4 = tid & 3, ig = tid >> 2, col0 = jblk * PRENET_COLS;
+  if (!flush) {
 #pragma unroll
-  for (int k = 0; k < 4; ++k) w1[k] = W1[((size_t)(ig + 64 * k) * PRENET + col0) / 4 + c4];
-  if (tid < N_MEL) s_mel[tid] = d.dec_in[b * N_MEL + tid];
-  const int step = d.ctl[0];
+    for (int k = 0; k < L1_PER_WAVE; ++k) w0[k] = W0[(wave * L1_PER_WAVE + k) * (PRENET / 4) + lane];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w1[k] = W1[((size_t)(ig + 64 * k) * PRENET + col0) / 4 + c4];
+  }
+  const float bias = tid < N_MEL + 1 ? proj_b[tid] : 0.f;
+  const int step = d.ctl[0] + i;
   const int nf = d.nframes[b];
   const uint32_t item = d.item_base + (uint32_t)b;
+  if (m4 < MEL_LD / 4) *reinterpret_cast<float4 *>(&s_red[part][4 * m4]) = racc;
   __syncthreads();
+  const bool have_prev = step >= 1 && step - 1 < nf;  // the chunk was active at the previous step
+  if (tid < MEL_LD) {
+    float v = 0.f;
+    if (have_prev && tid < N_MEL + 1) {
+      v = bias;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v += s_red[k][tid];
+    }
+    s_mel[tid] = v;  // step 0: decoder_input = 0 (mod.rs:208)
+  }
+  __syncthreads();
+  const float gate = s_mel[N_MEL];
+  const bool fired = have_prev && d.use_gate && gate_sigmoid(gate) > d.gate_threshold;
+  if (jblk == 0 && have_prev) {
+    if (tid < N_MEL) d.frames[((size_t)b * d.max_steps + (step - 1)) * N_MEL + tid] = s_mel[tid];
+    if (tid == 0) {
+      d.gates[(size_t)b * d.max_steps + (step - 1)] = gate;
+      if (fired) d.nframes[b] = step;  // frame step-1 is the last one
+    }
+  }
+  if (flush || fired || step >= nf) return;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int k = 0; k < L1_PER_WAVE; ++k) {
@@ -203,7 +289,7 @@ __global__ __launch_bounds__(256) void k_prenet(DecoderBufs d, const float *__re
   }
   if (lane < 4) *reinterpret_cast<float4 *>(&s_out[wave][4 * lane]) = acc;
   __syncthreads();
-  if (tid < PRENET_COLS && step < nf) {
+  if (tid < PRENET_COLS) {
     float o = fmaxf((s_out[0][tid] + s_out[1][tid]) + (s_out[2][tid] + s_out[3][tid]), 0.f);
     const int j = col0 + tid;
     if (d.dropout_mode)
@@ -218,47 +304,38 @@ __global__ __launch_bounds__(256) void k_prenet(DecoderBufs d, const float *__re
 // the batch, so HBM sees each weight once per step regardless of B.
 //   KIND 0: attention_rnn, input [prenet x (256) ; ctx_prev (512)] , hidden att_h   -> 1792 cols
 //   KIND 1: decoder_rnn,   input [att_h_new (1024) ; ctx (512)]    , hidden dec_h   -> 2560 cols
-// KIND 1 launches carry extra leading blocks in the location-feature role: they
-// compute the NEXT step's location features from the attention weights this step just produced,
-// hidden under the 42 MB weight stream instead of sitting on the next step's critical path.
+//           epilogue: partial mel    pmel[8+blk][m] = sum_{u in block} W_p[m][u] h_dec[u]
+//           leading blocks: location-feature role for the NEXT step
 template <int NCOLS, int KIND>
-__global__ __launch_bounds__(256) void k_lstm(DecoderBufs d, int cur, const float4 *__restrict__ Wp,
+__global__ __launch_bounds__(256) void k_lstm(DecoderBufs d, int i, int cur, const float4 *__restrict__ Wp,
                                               const float *__restrict__ bias,
-                                              const float *__restrict__ loc_conv,
+                                              const float4 *__restrict__ Wepi,  // q_w4 / proj_wh4
+                                              const float *__restrict__ loc_convT,
                                               const float *__restrict__ loc_denseT) {
   constexpr int NCH = NCOLS / 256;
   constexpr int N0 = KIND == 0 ? PRENET : ATT_RNN;  // first segment length
   constexpr int N1 = EMB;
-  constexpr int HID = KIND == 0 ? ATT_RNN : DEC_RNN;
-  constexpr bool NT_WEIGHTS = XDTTS_NT_MASK & (1 << KIND);
-  int gemv_block = blockIdx.x;
+  constexpr int EPI = KIND == 0 ? 0 : MEL_LD;  // epilogue outputs per block (decoder LSTM: partial mel)
+  int blk = blockIdx.x;
   if (KIND == 1) {  // the first tiles*B blocks take the location role (short; dispatched first)
     const int tiles = (d.T + LOC_TT - 1) / LOC_TT, nloc = tiles * d.B;
     if ((int)blockIdx.x < nloc) {
-      location_role(d, blockIdx.x / tiles, blockIdx.x % tiles, loc_conv, loc_denseT);
+      location_role(d, blockIdx.x / tiles, blockIdx.x % tiles, loc_convT, loc_denseT);
       return;
     }
-    gemv_block -= nloc;
+    blk -= nloc;
   }
-  (void)HID;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int unit = gemv_block * 4 + wave;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int unit = blk * 4 + wave;
   float4 w[4][NCH];
 #pragma unroll
   for (int g = 0; g < 4; ++g)
 #pragma unroll
-    for (int k = 0; k < NCH; ++k) {
-      const float4 *src = Wp + ((size_t)(unit * 4 + g) * NCOLS) / 4 + lane + 64 * k;
-      if (NT_WEIGHTS) {
-        typedef float f4 __attribute__((ext_vector_type(4)));
-        const f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(src));
-        w[g][k] = make_float4(v.x, v.y, v.z, v.w);
-      } else {
-        w[g][k] = *src;
-      }
-    }
+    for (int k = 0; k < NCH; ++k) w[g][k] = ld_stream(Wp + ((size_t)(unit * 4 + g) * NCOLS) / 4 + lane + 64 * k);
   const float4 bz = *reinterpret_cast<const float4 *>(bias + unit * 4);
-  const int step = d.ctl[0];
+  const float4 we = (KIND == 1 && tid < EPI) ? Wepi[(size_t)blk * EPI + tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+  const int step = d.ctl[0] + i;
+  __shared__ __attribute__((aligned(16))) float s_h[4];
   for (int b = 0; b < d.B; ++b) {
     const float *seg0, *seg1, *seg2;
     float *h_out, *c;
@@ -296,12 +373,26 @@ __global__ __launch_bounds__(256) void k_lstm(DecoderBufs d, int cur, const floa
     a1 = wave_sum(a1);
     a2 = wave_sum(a2);
     a3 = wave_sum(a3);
-    if (lane == 0 && step < d.nframes[b]) {
+    const bool act = step < d.nframes[b];
+    if (lane == 0) {
       const float ig = sigmoidf_(a0 + bz.x), fg = sigmoidf_(a1 + bz.y);
       const float gg = tanhf(a2 + bz.z), og = sigmoidf_(a3 + bz.w);
       const float cn = fmaf(fg, c_old, ig * gg);
-      c[unit] = cn;
-      h_out[unit] = og * tanhf(cn);
+      const float hn = og * tanhf(cn);
+      s_h[wave] = hn;
+      if (act) {
+        c[unit] = cn;
+        h_out[unit] = hn;
+      }
+    }
+    if (KIND == 1) {
+      __syncthreads();
+      if (act && tid < EPI) {
+        const float4 h4 = *reinterpret_cast<const float4 *>(s_h);
+        const float pv = fmaf(we.w, h4.w, fmaf(we.z, h4.z, fmaf(we.y, h4.y, we.x * h4.x)));
+        d.pmel[((size_t)b * PM_ROWS + CTX_BLOCKS + blk) * MEL_LD + tid] = pv;
+      }
+      __syncthreads();
     }
   }
 }
@@ -311,7 +402,7 @@ __global__ __launch_bounds__(256) void k_lstm(DecoderBufs d, int cur, const floa
 // then the 256 threads each take a time step and emit
 //   e_part[blk][t] = sum_{a in block} v_a tanh(q_a + loc[t][a] + processed_memory[t][a]).
 // This spreads the 12.8k tanh of a step over 32 CUs instead of one.
-__global__ __launch_bounds__(256) void k_qenergy(DecoderBufs d, int cur, const float4 *__restrict__ Wq,
+__global__ __launch_bounds__(256) void k_qenergy(DecoderBufs d, int i, int cur, const float4 *__restrict__ Wq,
                                                  const float *__restrict__ v_w) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, blk = blockIdx.x;
   const int row = blk * 4 + wave;
@@ -319,7 +410,7 @@ __global__ __launch_bounds__(256) void k_qenergy(DecoderBufs d, int cur, const f
 #pragma unroll
   for (int k = 0; k < 4; ++k) w[k] = Wq[(size_t)row * (ATT_RNN / 4) + lane + 64 * k];
   const float4 v4 = *reinterpret_cast<const float4 *>(v_w + blk * 4);
-  const int step = d.ctl[0];
+  const int step = d.ctl[0] + i;
   __shared__ __attribute__((aligned(16))) float s_q[4];
   for (int b = 0; b < d.B; ++b) {
     if (b > 0 && step >= d.nframes[b]) continue;
@@ -361,16 +452,22 @@ __global__ __launch_bounds__(256) void k_qenergy(DecoderBufs d, int cur, const f
 // the encoder memory is spread over several CUs; it is issued as 16-byte lane-consecutive loads,
 // prefetched at kernel entry (addresses do not depend on the softmax).  Block 0 also stores the
 // new attention weights.
-constexpr int CTX_BLOCKS = 8, CTX_COLS = EMB / CTX_BLOCKS;
-
-__global__ __launch_bounds__(256) void k_softmax_ctx(DecoderBufs d) {
-  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__global__ __launch_bounds__(256) void k_softmax_ctx(DecoderBufs d, int i, const float *__restrict__ proj_wc) {
+  const int b = blockIdx.x / CTX_BLOCKS, cblk = blockIdx.x % CTX_BLOCKS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int T = d.T;
   constexpr int C4 = CTX_COLS / 4, TG = 256 / C4;  // 16 float4 columns x 16 time groups
   constexpr int CTX_PF = 7;
-  __shared__ __attribute__((aligned(16))) float s_e[T_MAX], s_part[TG][CTX_COLS];
+  __shared__ __attribute__((aligned(16))) float s_e[T_MAX], s_part[TG][CTX_COLS], s_ctx[CTX_COLS];
   const int c4 = tid % C4, tg = tid / C4;
-  const float4 *mem = reinterpret_cast<const float4 *>(d.memory + (size_t)b * T * EMB) + blockIdx.x * C4;
+  const float4 *mem = reinterpret_cast<const float4 *>(d.memory + (size_t)b * T * EMB) + cblk * C4;
+  // projection weights of this block's 64 context columns: thread (m, half) holds 32 of row m
+  const int pm_m = tid >> 1, pm_half = tid & 1;
+  float4 wc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    wc[k] = pm_m <= N_MEL ? reinterpret_cast<const float4 *>(proj_wc + ((size_t)cblk * (N_MEL + 1) + pm_m) * CTX_COLS + 32 * pm_half)[k]
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
   float4 pf[CTX_PF];
 #pragma unroll
   for (int u = 0; u < CTX_PF; ++u) {
@@ -388,7 +485,7 @@ __global__ __launch_bounds__(256) void k_softmax_ctx(DecoderBufs d) {
     for (int k = 0; k < ATT_DIM / 4; ++k) e += ev[k];
     s_e[t] = t >= nv ? -INFINITY : e;
   }
-  const int step = d.ctl[0];
+  const int step = d.ctl[0] + i;
   const bool act = step < d.nframes[b];
   __syncthreads();
   if (wave == 0) {
@@ -405,7 +502,7 @@ __global__ __launch_bounds__(256) void k_softmax_ctx(DecoderBufs d) {
     for (int t = lane; t < T; t += 64) s_e[t] = s_e[t] / sum;
   }
   __syncthreads();
-  if (act && blockIdx.x == 0)
+  if (act && cblk == 0)
     for (int t = tid; t < T; t += 256) {
       const float wv = s_e[t];
       d.aw[b * T + t] = wv;
@@ -428,111 +525,84 @@ __global__ __launch_bounds__(256) void k_softmax_ctx(DecoderBufs d) {
   }
   *reinterpret_cast<float4 *>(&s_part[tg][4 * c4]) = acc;
   __syncthreads();
-  if (tid < CTX_COLS && act) {
+  if (tid < CTX_COLS) {
     float v = 0.f;
 #pragma unroll
     for (int g = 0; g < TG; ++g) v += s_part[g][tid];
-    d.ctx[b * EMB + blockIdx.x * CTX_COLS + tid] = v;
-  }
-}
-
-// D5 + D6: mel = W_p [dec_h ; ctx] + b_p (80 rows), gate = W_g [dec_h ; ctx] + b_g (row 80), and
-// the stop rule of mod.rs:319-324 (sigmoid(gate) > threshold, the tripping frame is kept) applied
-// on the device: the gate wave lowers nframes[b] to step+1.  The frame is written both to the
-// output (frames[step]) and to the fixed-address decoder_input state.  The last block to finish
-// advances the step counter (all blocks have read it by then).
-__global__ __launch_bounds__(256) void k_project(DecoderBufs d, int cur, const float4 *__restrict__ Wp,
-                                                 const float *__restrict__ bias) {
-  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const bool valid = row <= N_MEL;
-  const int r = valid ? row : N_MEL;
-  float4 w[6];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) w[k] = Wp[(size_t)r * (PROJ_IN / 4) + lane + 64 * k];
-  const float bz = bias[r];
-  const int step = d.ctl[0];
-  for (int b = 0; b < d.B; ++b) {
-    if (b > 0 && step >= d.nframes[b]) continue;
-    const float *h = d.dec_h[cur ^ 1] + b * DEC_RNN, *cx = d.ctx + b * EMB;
-    float4 xv[6];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) xv[k] = *reinterpret_cast<const float4 *>(h + 256 * k + 4 * lane);
-#pragma unroll
-    for (int k = 0; k < 2; ++k) xv[4 + k] = *reinterpret_cast<const float4 *>(cx + 256 * k + 4 * lane);
-    float a = 0.f;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) a = dot4(w[k], xv[k], a);
-    a = wave_sum(a) + bz;
-    if (lane == 0 && valid && step < d.nframes[b]) {
-      if (row < N_MEL) {
-        d.frames[((size_t)b * d.max_steps + step) * N_MEL + row] = a;
-        d.dec_in[b * N_MEL + row] = a;
-      } else {
-        d.gates[(size_t)b * d.max_steps + step] = a;
-        if (d.use_gate && gate_sigmoid(a) > d.gate_threshold) d.nframes[b] = step + 1;
-      }
-    }
+    s_ctx[tid] = v;
+    if (act) d.ctx[b * EMB + cblk * CTX_COLS + tid] = v;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    const int t = atomicAdd(&d.ctl[1], 1);
-    if (t == (int)gridDim.x - 1) {
-      d.ctl[1] = 0;
-      d.ctl[0] = step + 1;
-    }
+  // partial mel of these context columns: pmel[cblk][m] = W_p[m][1024 + cols] . ctx[cols]
+  {
+    float pv = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) pv = dot4(wc[k], *reinterpret_cast<const float4 *>(&s_ctx[32 * pm_half + 4 * k]), pv);
+    pv += dpp_move<0xB1, 0xf>(0.f, pv);  // lanes 2j, 2j+1 hold the two halves of row m
+    if (act && pm_half == 0 && pm_m <= N_MEL) d.pmel[((size_t)b * PM_ROWS + cblk) * MEL_LD + pm_m] = pv;
   }
 }
 
 }  // namespace
 
+size_t decoder_pmel_floats(int B) { return (size_t)B * PM_ROWS * MEL_LD; }
+
 void launch_decoder_init(const DecoderBufs &d, const int *limits_dev, hipStream_t s) {
+  // partial-mel rows are summed unconditionally; padding columns 81..83 and a first step's rows
+  // must read as zero
+  HIP_CHECK(hipMemsetAsync(d.pmel, 0, decoder_pmel_floats(d.B) * sizeof(float), s));
   hipLaunchKernelGGL(k_decoder_init, dim3(d.B), dim3(256), 0, s, d, limits_dev);
   HIP_CHECK(hipGetLastError());
 }
 
 // Steps are enqueued in (even, odd) pairs: node i uses ping-pong parity i & 1, so a sequence must
-// start on an even step and nsteps must be even.
+// start on an even step and nsteps must be even.  The absolute step of node i is ctl[0] + i;
+// k_advance moves ctl[0] on by nsteps at the end, so the same captured graph replays anywhere.
 void launch_decoder_steps(const DecoderBufs &d, const DeviceWeights &w, int nsteps, hipStream_t s) {
   if (nsteps % 2 != 0) fail(XDTTS_ERR_BAD_ARG, "decoder steps are enqueued in even/odd pairs");
   const int loc_tiles = (d.T + LOC_TT - 1) / LOC_TT;
   const float4 *att_w = reinterpret_cast<const float4 *>(w.att_w.p);
   const float4 *dec_w = reinterpret_cast<const float4 *>(w.dec_w.p);
-  // XDTTS_DEBUG_MIX (developer timing aid only; results are garbage when set): string over
-  // letters p,a,q,s,d,j selecting which kernels a step launches, e.g. "jjjjjj".
+  const float4 *q4 = reinterpret_cast<const float4 *>(w.q_w4.p), *wh4 = reinterpret_cast<const float4 *>(w.proj_wh4.p);
+  // XDTTS_DEBUG_MIX (developer timing aid only; results are garbage when set): string over the
+  // letters p,a,q,s,d selecting which kernels a step launches, e.g. "ppppp".
   const char *mix = getenv("XDTTS_DEBUG_MIX");
-  const std::string order = mix ? mix : "paqsdj";
+  const std::string order = mix ? mix : "paqsd";
   for (int i = 0; i < nsteps; ++i) {
     const int cur = i & 1;
     for (char k : order) {
       switch (k) {
         case 'p':
-          hipLaunchKernelGGL(k_prenet, dim3(PRENET_BLOCKS, d.B), dim3(256), 0, s, d, w.pre0T.p, w.pre1T.p);
+          hipLaunchKernelGGL(k_prenet, dim3(PRENET_BLOCKS * d.B), dim3(256), 0, s, d, i, 0, w.pre0T.p, w.pre1T.p,
+                             w.proj_b.p);
           break;
         case 'a':
-          hipLaunchKernelGGL((k_lstm<ATT_COLS, 0>), dim3(ATT_RNN / 4), dim3(256), 0, s, d, cur, att_w, w.att_b.p,
+          hipLaunchKernelGGL((k_lstm<ATT_COLS, 0>), dim3(NBLK), dim3(256), 0, s, d, i, cur, att_w, w.att_b.p, q4,
                              w.loc_conv.p, w.loc_denseT.p);
           break;
         case 'q':
-          hipLaunchKernelGGL(k_qenergy, dim3(ATT_DIM / 4), dim3(256), 0, s, d, cur,
+          hipLaunchKernelGGL(k_qenergy, dim3(ATT_DIM / 4), dim3(256), 0, s, d, i, cur,
                              reinterpret_cast<const float4 *>(w.q_w.p), w.v_w.p);
           break;
         case 's':
-          hipLaunchKernelGGL(k_softmax_ctx, dim3(CTX_BLOCKS, d.B), dim3(256), 0, s, d);
+          hipLaunchKernelGGL(k_softmax_ctx, dim3(CTX_BLOCKS * d.B), dim3(256), 0, s, d, i, w.proj_wc.p);
           break;
         case 'd':
-          hipLaunchKernelGGL((k_lstm<DEC_COLS, 1>), dim3(DEC_RNN / 4 + loc_tiles * d.B), dim3(256), 0, s, d, cur,
-                             dec_w, w.dec_b.p, w.loc_conv.p, w.loc_denseT.p);
-          break;
-        case 'j':
-          hipLaunchKernelGGL(k_project, dim3((N_MEL + 1 + 3) / 4), dim3(256), 0, s, d, cur,
-                             reinterpret_cast<const float4 *>(w.proj_w.p), w.proj_b.p);
+          hipLaunchKernelGGL((k_lstm<DEC_COLS, 1>), dim3(loc_tiles * d.B + NBLK), dim3(256), 0, s, d, i, cur, dec_w,
+                             w.dec_b.p, wh4, w.loc_conv.p, w.loc_denseT.p);
           break;
         default:
           break;
       }
     }
   }
+  hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, s, d, nsteps);
+  HIP_CHECK(hipGetLastError());
+}
+
+// After the last step of a sequence: finishes the projection of the final step (frames, gate).
+void launch_decoder_flush(const DecoderBufs &d, const DeviceWeights &w, hipStream_t s) {
+  hipLaunchKernelGGL(k_prenet, dim3(PRENET_BLOCKS * d.B), dim3(256), 0, s, d, 0, 1, w.pre0T.p, w.pre1T.p, w.proj_b.p);
   HIP_CHECK(hipGetLastError());
 }
 

@@ -20,13 +20,13 @@ struct DecoderBufs {
   float *aw, *awc;      // [B][T]        attention_weights, attention_weights_cum
   float *ctx;           // [B][512]      attention_context
   float *x;             // [B][256]      prenet output
-  float *dec_in;        // [B][80]       previous mel frame ("decoder_input", mod.rs:285,332)
   float *loc;           // [B][T][128]   location features of the current step
   float *e_part;        // [B][32][T]    per-block partial energies
+  float *pmel;          // [B][264][84]  partial mel/gate sums: 8 context blocks, 256 decoder-LSTM blocks
   float *frames;        // [B][max_steps][80]  decoder_output per step (time-major)
   float *gates;         // [B][max_steps]      gate_prediction logits
   int *nframes;         // [B] in: step limit; out: frames emitted (gate may lower it)
-  int *ctl;             // [0] step counter, [1] ticket
+  int *ctl;             // [0] absolute step of the first node of the graph being replayed
   int max_steps;
   int use_gate;
   float gate_threshold;
@@ -34,8 +34,11 @@ struct DecoderBufs {
   uint32_t dropout_seed, item_base;
 };
 
-// Enqueues `nsteps` decoder steps on `s` (6 kernels each).
+// Enqueues `nsteps` decoder steps on `s` (5 kernels each) and advances the device step base.
 void launch_decoder_steps(const DecoderBufs &d, const DeviceWeights &w, int nsteps, hipStream_t s);
+// After the last step of a sequence: completes the final frame's projection (frames, gate).
+void launch_decoder_flush(const DecoderBufs &d, const DeviceWeights &w, hipStream_t s);
+size_t decoder_pmel_floats(int B);
 // Zeroes the recurrent state (DecoderState::new, mod.rs:202-233) and sets the step limits.
 void launch_decoder_init(const DecoderBufs &d, const int *limits_dev, hipStream_t s);
 

@@ -256,6 +256,15 @@ void DeviceWeights::upload(const std::vector<float> &blob, hipStream_t s) {
   upload_transposed(T(blob, "prenet.1.weight"), PRENET, PRENET, pre1T, s);
   pack_lstm(blob, "attention_rnn", ATT_RNN, ATT_IN, att_w, att_b, s);
   q_w.upload(T(blob, "attention.query_layer.weight"), (size_t)ATT_DIM * ATT_RNN, s);
+  {
+    const float *wq = T(blob, "attention.query_layer.weight");
+    std::vector<float> q4((size_t)256 * ATT_DIM * 4);
+    for (int blk = 0; blk < 256; ++blk)
+      for (int a = 0; a < ATT_DIM; ++a)
+        for (int i = 0; i < 4; ++i) q4[((size_t)blk * ATT_DIM + a) * 4 + i] = wq[(size_t)a * ATT_RNN + 4 * blk + i];
+    q_w4.upload(q4.data(), q4.size(), s);
+    HIP_CHECK(hipStreamSynchronize(s));
+  }
   v_w.upload(T(blob, "attention.v.weight"), ATT_DIM, s);
   upload_transposed(T(blob, "attention.location_conv.weight"), LOC_F, 2 * LOC_K, loc_conv, s);  // -> [c][k][f]
   upload_transposed(T(blob, "attention.location_dense.weight"), ATT_DIM, LOC_F, loc_denseT, s);
@@ -267,6 +276,15 @@ void DeviceWeights::upload(const std::vector<float> &blob, hipStream_t s) {
     std::memcpy(pb.data(), T(blob, "linear_projection.bias"), sizeof(float) * N_MEL);
     pb[N_MEL] = T(blob, "gate_layer.bias")[0];
     proj_w.upload(pw.data(), pw.size(), s);
+    std::vector<float> wh4((size_t)256 * 84 * 4, 0.f), wc((size_t)8 * (N_MEL + 1) * 64);
+    for (int blk = 0; blk < 256; ++blk)
+      for (int m = 0; m <= N_MEL; ++m)
+        for (int i = 0; i < 4; ++i) wh4[((size_t)blk * 84 + m) * 4 + i] = pw[(size_t)m * PROJ_IN + 4 * blk + i];
+    for (int cb = 0; cb < 8; ++cb)
+      for (int m = 0; m <= N_MEL; ++m)
+        for (int c = 0; c < 64; ++c) wc[((size_t)cb * (N_MEL + 1) + m) * 64 + c] = pw[(size_t)m * PROJ_IN + DEC_RNN + 64 * cb + c];
+    proj_wh4.upload(wh4.data(), wh4.size(), s);
+    proj_wc.upload(wc.data(), wc.size(), s);
     proj_b.upload(pb.data(), pb.size(), s);
     HIP_CHECK(hipStreamSynchronize(s));
   }

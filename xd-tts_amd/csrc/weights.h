@@ -42,6 +42,10 @@ struct DeviceWeights {
   DevBuf<float> q_w, v_w, loc_conv, loc_denseT;  // [128][1024], [128], [2][31][32] (transposed), [32][128]
   DevBuf<float> dec_w, dec_b;                // [1024][4][2560], [1024][4]
   DevBuf<float> proj_w, proj_b;              // [81][1536] (row 80 = gate), [81]
+  // layouts for the partial-product epilogues of the LSTM kernels (decoder.hip):
+  DevBuf<float> q_w4;                        // [256 blk][128 a][4]   = W_q[a][4 blk + i]
+  DevBuf<float> proj_wh4;                    // [256 blk][84 m][4]    = W_p[m][4 blk + i]   (m < 81, padded to 84)
+  DevBuf<float> proj_wc;                     // [8 cblk][81 m][64]    = W_p[m][1024 + 64 cblk + c]
   ConvGemm post_conv[POST_CONVS];
   void upload(const std::vector<float> &blob, hipStream_t s);
 };
