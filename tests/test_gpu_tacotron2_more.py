@@ -172,3 +172,38 @@ def test_full_size_config2_mel_parity(pkg, model, orc, blob):
     assert err <= 1e-3 * float(np.sqrt(np.mean(ref.astype(np.float64) ** 2)))  # and relative to the signal
     t = model.last_timings()
     assert t["steps"] == 633  # lock-step: max(633, 167) iterations for 800 frames
+
+
+def test_large_batch_runs_lstms_on_mfma(pkg, model, orc, blob):
+    """B >= 8 chunks in lock-step switches the two LSTM kernels to the f32-MFMA GEMM form
+    (k_lstm_mfma); 19 chunks also exercises a partial second 16-chunk tile.  Each chunk must still
+    equal the oracle run on its own, including chunks that finish early."""
+    rng = np.random.Generator(np.random.PCG64(9))
+    lens = [int(x) for x in rng.integers(5, 101, size=19)]
+    ids_list = [synth_ids(n, seed=50 + i) for i, n in enumerate(lens)]
+    steps = [int(x) for x in rng.integers(3, 25, size=19)]
+    mels = model.infer_batch(ids_list, opts=pkg.default_opts(dropout_seed=17, item_base=7), fixed_steps=steps)
+    worst = 0.0
+    for b, (ids, st) in enumerate(zip(ids_list, steps)):
+        ref = orc.infer_chunk(blob, ids, orc.default_opts(fixed_steps=st, dropout_seed=17, item=7 + b))
+        assert mels[b].shape == (80, st)
+        worst = max(worst, rms(mels[b], ref))
+    assert worst <= 1e-5, worst
+
+
+def test_large_batch_with_gate(pkg, orc, blob):
+    ids_list = [synth_ids(20 + 3 * i, seed=70 + i) for i in range(9)]
+    padded = np.zeros(100, dtype=np.int64)
+    padded[: len(ids_list[0])] = ids_list[0]
+    mem, pm = orc.encoder(blob, padded)
+    rig = rigged_gate_blob(orc, blob, mem, pm, len(ids_list[0]), 4, 40)
+    m = pkg.Tacotron2.from_blob(rig)
+    mels = m.infer_batch(ids_list, opts=pkg.default_opts(dropout_seed=4, max_steps=70))
+    counts = set()
+    for b, ids in enumerate(ids_list):
+        ref = orc.infer_chunk(rig, ids, orc.default_opts(dropout_seed=4, max_steps=70, item=b))
+        assert mels[b].shape == ref.shape, (b, mels[b].shape, ref.shape)
+        assert rms(mels[b], ref) <= 1e-5
+        counts.add(ref.shape[1])
+    assert len(counts) > 1
+    m.close()

@@ -426,6 +426,7 @@ struct xdtts_tacotron2 {
       else if (o.fixed_frames_per_id > 0.f) l = (int)std::lround((double)o.fixed_frames_per_id * lens[b]);
       lim[b] = std::min(std::max(l, 1), o.max_steps);
     }
+    if (B >= BATCH_MFMA_MIN) w.ensure_batched_layout(blob, stream);
     DecoderBufs d = decoder_bufs(B, T, memory.p, pmem.p, o);
     if (fixed_per_item || o.fixed_frames_per_id > 0.f) d.use_gate = 0;
     last_steps = run_decoder(d, lim);

@@ -34,6 +34,7 @@
 // are issued at kernel entry.  The ping-pong parity of the recurrent state and the position `i`
 // of the step inside the replayed graph are kernel arguments; the absolute step is ctl[0] + i,
 // with ctl[0] advanced once per replay (k_advance).  Wavefront = 64 everywhere.
+#include <algorithm>
 #include <cstdlib>
 #include <string>
 
@@ -397,6 +398,126 @@ __global__ __launch_bounds__(256) void k_lstm(DecoderBufs d, int i, int cur, con
   }
 }
 
+// Batched mode: the location features of all chunks as their own launch (hundreds of small blocks;
+// as leading blocks of the 1024-thread GEMM launch they would delay it).
+__global__ __launch_bounds__(256) void k_location(DecoderBufs d, const float *__restrict__ loc_convT,
+                                                  const float *__restrict__ loc_denseT) {
+  const int tiles = (d.T + LOC_TT - 1) / LOC_TT;
+  location_role(d, blockIdx.x / tiles, blockIdx.x % tiles, loc_convT, loc_denseT);
+}
+
+// D2 / D4 for batches (B >= BATCH_MFMA_MIN chunks in lock-step): the LSTM pre-activations become
+// a GEMM  G[16 rows of a block][B chunks] = W[16 x K] . X^T[K x B]  on the exact-fp32 matrix
+// cores (v_mfma_f32_16x16x4_f32).  Still weight-streaming: a block owns the same 4 hidden units
+// (16 gate rows), its sixteen waves split K, every weight is read from HBM once per step and feeds
+// 4 MFMAs per 16-chunk tile straight from the load (the weights are pre-laid in fragment order,
+// weights.h); the activations come from L2 with 64-byte segments per chunk (four waves per SIMD
+// hide that latency).  Accumulators of the sixteen K-slices meet in LDS; wave t then holds, per lane, the four gates of (chunk 16t + lane%16,
+// unit lane/16) -- exactly the MFMA D layout -- and does the cell update in place.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int NCOLS, int KIND, int NT>  // NT = 16-chunk tiles per pass (compile-time: no branches around the MFMAs)
+__global__ __launch_bounds__(64 * MFMA_WAVES) void k_lstm_mfma(DecoderBufs d, int i, int cur, const float4 *__restrict__ Wm,
+                                                   const float *__restrict__ bias,
+                                                   const float4 *__restrict__ Wepi,
+                                                   const float *__restrict__ loc_convT,
+                                                   const float *__restrict__ loc_denseT) {
+  constexpr int NW = MFMA_WAVES, KW = NCOLS / NW, JJ = KW / 16;
+  constexpr int N0 = KIND == 0 ? PRENET : ATT_RNN, N1 = EMB;
+  const int blk = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fi = lane & 15, fg = lane >> 4;
+  const float4 *wsrc = Wm + ((size_t)(blk * NW + wave) * JJ) * 64 + lane;
+  const float4 bz = *reinterpret_cast<const float4 *>(bias + (blk * 4 + fg) * 4);  // unit fg's i,f,g,o biases
+  const int step = d.ctl[0] + i;
+  // the whole weight slab of this wave (16 rows x KW columns = 28..40 KB) goes in flight at once,
+  // like the GEMV kernels: HBM latency needs tens of KB in flight per CU to stream at full rate
+  float4 wreg[JJ];
+#pragma unroll
+  for (int jj = 0; jj < JJ; ++jj) wreg[jj] = ld_stream(wsrc + (size_t)jj * 64);
+  __shared__ __attribute__((aligned(16))) float s_acc[NW][NT][64][4];  // [K-slice][tile][lane][gate]
+  __shared__ __attribute__((aligned(16))) float s_h[64][4];           // [chunk in super-tile][unit]
+  const float *seg0 = KIND == 0 ? d.x : d.att_h[cur ^ 1];
+  const float *seg1 = d.ctx;
+  const float *seg2 = KIND == 0 ? d.att_h[cur] : d.dec_h[cur];
+  float *h_out = KIND == 0 ? d.att_h[cur ^ 1] : d.dec_h[cur ^ 1];
+  float *cst = KIND == 0 ? d.att_c : d.dec_c;
+  for (int n0 = 0; n0 < d.B; n0 += 16 * NT) {
+    int nt[NT];  // chunk of this lane per tile (clamped: tiles past B recompute the last chunk, unused)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) nt[t] = min(n0 + 16 * t + fi, d.B - 1);
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jj = 0; jj < JJ; ++jj) {
+      const int col = wave * KW + 16 * jj;  // wave-uniform; segment boundaries are multiples of 16
+      const float4 wv = wreg[jj];
+      const float *sb;
+      int stride, off;
+      if (col < N0) {
+        sb = seg0;
+        stride = N0;
+        off = col;
+      } else if (col < N0 + N1) {
+        sb = seg1;
+        stride = N1;
+        off = col - N0;
+      } else {
+        sb = seg2;
+        stride = ATT_RNN;
+        off = col - N0 - N1;
+      }
+      float4 xv[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) xv[t] = *reinterpret_cast<const float4 *>(sb + (size_t)nt[t] * stride + off + 4 * fg);
+      // interleave the tiles so consecutive MFMAs hit different accumulators (40-cycle dependent latency)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, xv[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, xv[t].y, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.z, xv[t].z, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, xv[t].w, acc[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4 *>(s_acc[wave][t][lane]) = acc[t];
+    __syncthreads();
+    if (wave < NT) {  // wave t finalises chunk tile t: lane = (chunk fi, unit fg), regs = gates i,f,g,o
+      f32x4 g = *reinterpret_cast<const f32x4 *>(s_acc[0][wave][lane]);
+#pragma unroll
+      for (int q = 1; q < NW; ++q) g += *reinterpret_cast<const f32x4 *>(s_acc[q][wave][lane]);
+      const int n = n0 + 16 * wave + fi, unit = blk * 4 + fg;
+      float hn = 0.f;
+      if (n < d.B) {
+        const float c_old = cst[(size_t)n * ATT_RNN + unit];
+        const float ig = sigmoidf_(g[0] + bz.x), fgt = sigmoidf_(g[1] + bz.y);
+        const float gg = tanhf(g[2] + bz.z), og = sigmoidf_(g[3] + bz.w);
+        const float cn = fmaf(fgt, c_old, ig * gg);
+        hn = og * tanhf(cn);
+        if (step < d.nframes[n]) {
+          cst[(size_t)n * ATT_RNN + unit] = cn;
+          h_out[(size_t)n * ATT_RNN + unit] = hn;
+        }
+      }
+      s_h[16 * wave + fi][fg] = hn;
+    }
+    if (KIND == 1) {  // partial mel of this block's four hidden units, for every chunk of the super-tile
+      __syncthreads();
+      const int nb = min(16 * NT, d.B - n0);
+      for (int idx = tid; idx < nb * MEL_LD; idx += 64 * NW) {
+        const int bl = idx / MEL_LD, m = idx % MEL_LD;
+        const float4 we = Wepi[(size_t)blk * MEL_LD + m];
+        const float4 h4 = *reinterpret_cast<const float4 *>(s_h[bl]);
+        if (step < d.nframes[n0 + bl])
+          d.pmel[((size_t)(n0 + bl) * PM_ROWS + CTX_BLOCKS + blk) * MEL_LD + m] =
+              fmaf(we.w, h4.w, fmaf(we.z, h4.z, fmaf(we.y, h4.y, we.x * h4.x)));
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // D3a: processed query q = W_q att_h_new (128 x 1024, no bias) and, fused, this block's share of
 // the energies.  Block `blk` owns attention dims a in [4 blk, 4 blk + 4): one wave per query row,
 // then the 256 threads each take a time step and emit
@@ -412,8 +533,10 @@ __global__ __launch_bounds__(256) void k_qenergy(DecoderBufs d, int i, int cur, 
   const float4 v4 = *reinterpret_cast<const float4 *>(v_w + blk * 4);
   const int step = d.ctl[0] + i;
   __shared__ __attribute__((aligned(16))) float s_q[4];
-  for (int b = 0; b < d.B; ++b) {
-    if (b > 0 && step >= d.nframes[b]) continue;
+  // small batches: one launch row loops over the chunks; large batches: gridDim.y = B
+  const int b_lo = gridDim.y > 1 ? blockIdx.y : 0, b_hi = gridDim.y > 1 ? b_lo + 1 : d.B;
+  for (int b = b_lo; b < b_hi; ++b) {
+    if (b > b_lo && step >= d.nframes[b]) continue;
     const float *h = d.att_h[cur ^ 1] + b * ATT_RNN;
     float4 hv[4];
 #pragma unroll
@@ -568,6 +691,9 @@ void launch_decoder_steps(const DecoderBufs &d, const DeviceWeights &w, int nste
   // letters p,a,q,s,d selecting which kernels a step launches, e.g. "ppppp".
   const char *mix = getenv("XDTTS_DEBUG_MIX");
   const std::string order = mix ? mix : "paqsd";
+  const bool batched = d.B >= BATCH_MFMA_MIN && w.att_wm.p && w.dec_wm.p;  // LSTMs as MFMA GEMMs
+  const float4 *att_wm = reinterpret_cast<const float4 *>(w.att_wm.p), *dec_wm = reinterpret_cast<const float4 *>(w.dec_wm.p);
+  const int nt_tiles = std::min(4, (d.B + 15) / 16);  // 16-chunk tiles per pass over the weights
   for (int i = 0; i < nsteps; ++i) {
     const int cur = i & 1;
     for (char k : order) {
@@ -577,19 +703,40 @@ void launch_decoder_steps(const DecoderBufs &d, const DeviceWeights &w, int nste
                              w.proj_b.p);
           break;
         case 'a':
-          hipLaunchKernelGGL((k_lstm<ATT_COLS, 0>), dim3(NBLK), dim3(256), 0, s, d, i, cur, att_w, w.att_b.p, q4,
-                             w.loc_conv.p, w.loc_denseT.p);
+          if (batched) {
+            auto launch = [&](auto kern) {
+              hipLaunchKernelGGL(kern, dim3(NBLK), dim3(64 * MFMA_WAVES), 0, s, d, i, cur, att_wm, w.att_b.p, q4, w.loc_conv.p,
+                                 w.loc_denseT.p);
+            };
+            if (nt_tiles == 1) launch(k_lstm_mfma<ATT_COLS, 0, 1>);
+            else if (nt_tiles == 2) launch(k_lstm_mfma<ATT_COLS, 0, 2>);
+            else if (nt_tiles == 3) launch(k_lstm_mfma<ATT_COLS, 0, 3>);
+            else launch(k_lstm_mfma<ATT_COLS, 0, 4>);
+          } else
+            hipLaunchKernelGGL((k_lstm<ATT_COLS, 0>), dim3(NBLK), dim3(256), 0, s, d, i, cur, att_w, w.att_b.p, q4,
+                               w.loc_conv.p, w.loc_denseT.p);
           break;
         case 'q':
-          hipLaunchKernelGGL(k_qenergy, dim3(ATT_DIM / 4), dim3(256), 0, s, d, i, cur,
+          hipLaunchKernelGGL(k_qenergy, dim3(ATT_DIM / 4, batched ? d.B : 1), dim3(256), 0, s, d, i, cur,
                              reinterpret_cast<const float4 *>(w.q_w.p), w.v_w.p);
           break;
         case 's':
           hipLaunchKernelGGL(k_softmax_ctx, dim3(CTX_BLOCKS * d.B), dim3(256), 0, s, d, i, w.proj_wc.p);
           break;
         case 'd':
-          hipLaunchKernelGGL((k_lstm<DEC_COLS, 1>), dim3(loc_tiles * d.B + NBLK), dim3(256), 0, s, d, i, cur, dec_w,
-                             w.dec_b.p, wh4, w.loc_conv.p, w.loc_denseT.p);
+          if (batched) {
+            auto launch = [&](auto kern) {
+              hipLaunchKernelGGL(kern, dim3(NBLK), dim3(64 * MFMA_WAVES), 0, s, d, i, cur, dec_wm, w.dec_b.p, wh4,
+                                 w.loc_conv.p, w.loc_denseT.p);
+            };
+            hipLaunchKernelGGL(k_location, dim3(loc_tiles * d.B), dim3(256), 0, s, d, w.loc_conv.p, w.loc_denseT.p);
+            if (nt_tiles == 1) launch(k_lstm_mfma<DEC_COLS, 1, 1>);
+            else if (nt_tiles == 2) launch(k_lstm_mfma<DEC_COLS, 1, 2>);
+            else if (nt_tiles == 3) launch(k_lstm_mfma<DEC_COLS, 1, 3>);
+            else launch(k_lstm_mfma<DEC_COLS, 1, 4>);
+          } else
+            hipLaunchKernelGGL((k_lstm<DEC_COLS, 1>), dim3(loc_tiles * d.B + NBLK), dim3(256), 0, s, d, i, cur, dec_w,
+                               w.dec_b.p, wh4, w.loc_conv.p, w.loc_denseT.p);
           break;
         default:
           break;

@@ -235,6 +235,35 @@ void load_container(const std::string &dir, std::vector<float> &blob) {
     if (!seen[i]) fail(XDTTS_ERR_IO, "loading tacotron2 weights: tensor %s is missing", tab[i].name);
 }
 
+namespace {
+void pack_lstm_mfma(const std::vector<float> &blob, const std::string &p, int hidden, int nin, DevBuf<float> &out,
+                    hipStream_t s) {
+  const float *wih = T(blob, p + ".weight_ih"), *whh = T(blob, p + ".weight_hh");
+  const int cols = nin + hidden, KW = cols / MFMA_WAVES, JJ = KW / 16;
+  std::vector<float> m((size_t)hidden * 4 * cols);
+  auto W = [&](int unit, int gate, int c) {
+    const int r = gate * hidden + unit;  // PyTorch gate order i,f,g,o
+    return c < nin ? wih[(size_t)r * nin + c] : whh[(size_t)r * hidden + (c - nin)];
+  };
+  for (int blk = 0; blk < hidden / 4; ++blk)
+    for (int wv = 0; wv < MFMA_WAVES; ++wv)
+      for (int jj = 0; jj < JJ; ++jj)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int i = lane & 15, g4 = lane >> 4;
+          float *dst = m.data() + ((((size_t)blk * MFMA_WAVES + wv) * JJ + jj) * 64 + lane) * 4;
+          for (int c = 0; c < 4; ++c) dst[c] = W(blk * 4 + (i >> 2), i & 3, wv * KW + 16 * jj + 4 * g4 + c);
+        }
+  out.upload(m.data(), m.size(), s);
+  HIP_CHECK(hipStreamSynchronize(s));
+}
+}  // namespace
+
+void DeviceWeights::ensure_batched_layout(const std::vector<float> &blob, hipStream_t s) {
+  if (att_wm.p && dec_wm.p) return;
+  pack_lstm_mfma(blob, "attention_rnn", ATT_RNN, ATT_IN, att_wm, s);
+  pack_lstm_mfma(blob, "decoder_rnn", DEC_RNN, DEC_IN, dec_wm, s);
+}
+
 void DeviceWeights::upload(const std::vector<float> &blob, hipStream_t s) {
   if (blob.size() != tensor_total())
     fail(XDTTS_ERR_BAD_ARG, "weight blob has %zu floats, expected %zu", blob.size(), tensor_total());

@@ -31,6 +31,9 @@ struct ConvGemm {
 };
 
 // Device-resident, kernel-ready weights.  Everything stays fp32 (parity bar 1e-4 RMS).
+constexpr int MFMA_WAVES = 16;     // waves per block of the batched LSTM kernel: each takes 1/16 of K
+constexpr int BATCH_MFMA_MIN = 8;  // chunks in lock-step from which the LSTMs run as MFMA GEMMs
+
 struct DeviceWeights {
   DevBuf<float> emb;                         // [148][512]
   ConvGemm enc_conv[ENC_CONVS];              // [512][5*512]
@@ -47,7 +50,14 @@ struct DeviceWeights {
   DevBuf<float> proj_wh4;                    // [256 blk][84 m][4]    = W_p[m][4 blk + i]   (m < 81, padded to 84)
   DevBuf<float> proj_wc;                     // [8 cblk][81 m][64]    = W_p[m][1024 + 64 cblk + c]
   ConvGemm post_conv[POST_CONVS];
+  // MFMA-fragment layout of the two LSTM weight matrices for the batched decoder path
+  // (decoder.hip: k_lstm_mfma): [256 blk][16 waves][KW/16][64 lanes][4] with
+  //   value = W[row 16 blk + (lane & 15)][wave KW + 16 jj + 4 (lane >> 4) + c],  KW = cols / 16,
+  // so one wave-level 16-byte load is the A operand of four v_mfma_f32_16x16x4_f32.  Built lazily
+  // (first batch of >= BATCH_MFMA_MIN chunks): a second 71 MB copy that B = 1 users never pay for.
+  DevBuf<float> att_wm, dec_wm;
   void upload(const std::vector<float> &blob, hipStream_t s);
+  void ensure_batched_layout(const std::vector<float> &blob, hipStream_t s);
 };
 
 }  // namespace xdtts
