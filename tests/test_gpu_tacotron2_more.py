@@ -207,3 +207,17 @@ def test_large_batch_with_gate(pkg, orc, blob):
         counts.add(ref.shape[1])
     assert len(counts) > 1
     m.close()
+
+
+def test_batch_beyond_one_mfma_pass(pkg, model, orc, blob):
+    """70 chunks: more than the 64 chunks one pass of k_lstm_mfma covers, so the kernels loop over two
+    chunk super-tiles with the weights held in registers; spot-check a handful against the oracle."""
+    rng = np.random.Generator(np.random.PCG64(11))
+    lens = [int(x) for x in rng.integers(4, 60, size=70)]
+    ids_list = [synth_ids(n, seed=200 + i) for i, n in enumerate(lens)]
+    steps = [int(x) for x in rng.integers(2, 9, size=70)]
+    mels = model.infer_batch(ids_list, opts=pkg.default_opts(dropout_seed=23), fixed_steps=steps)
+    assert [m.shape for m in mels] == [(80, s) for s in steps]
+    for b in (0, 15, 16, 47, 63, 64, 69):
+        ref = orc.infer_chunk(blob, ids_list[b], orc.default_opts(fixed_steps=steps[b], dropout_seed=23, item=b))
+        assert rms(mels[b], ref) <= 1e-5, b
