@@ -505,7 +505,7 @@ struct xdtts_griffinlim {
   int graph_iters = -1;
   float graph_alpha = 0.f;
   const float *graph_audio = nullptr;
-  DevBuf<float2> tw, ang, tprev;
+  DevBuf<float2> tw, ang, ang2, tprev;
 
   ~xdtts_griffinlim() {
     if (graph) (void)hipGraphExecDestroy(graph);
@@ -515,6 +515,7 @@ struct xdtts_griffinlim {
   GlBufs bufs(int F) {
     S.alloc((size_t)F * nb);
     ang.alloc((size_t)F * nb);
+    ang2.alloc((size_t)F * nb);
     tprev.alloc((size_t)F * nb);
     frames.alloc((size_t)F * n_fft);
     wss_inv.alloc((size_t)std::max(1, hop * (F - 1)));
@@ -526,6 +527,7 @@ struct xdtts_griffinlim {
     g.nb = nb;
     g.S = S.p;
     g.ang = ang.p;
+    g.ang2 = ang2.p;
     g.tprev = tprev.p;
     g.frames = frames.p;
     g.wss_inv = wss_inv.p;
@@ -568,8 +570,7 @@ struct xdtts_griffinlim {
       hipGraph_t gr = nullptr;
       HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
       try {
-        for (int i = 0; i < n_iter; ++i) launch_gl_iteration(g, alpha, stream);
-        launch_gl_final(g, audio.p, stream);
+        launch_gl_iterations(g, n_iter, alpha, audio.p, stream);
       } catch (...) {
         (void)hipStreamEndCapture(stream, &gr);
         if (gr) (void)hipGraphDestroy(gr);

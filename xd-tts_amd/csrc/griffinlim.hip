@@ -10,9 +10,11 @@
 // LDS used only for the two inter-pass exchanges (conflict-free: lanes touch consecutive float2).
 // The real<->complex split/merge twiddle step is fused into the first/last pass, the synthesis
 // and analysis windows and the magnitude projection are fused into the loads/stores, so one
-// iteration touches S, angles and the previous rebuilt spectrum exactly once each; the overlap-add
-// is folded into the STFT's gather (four L2-resident frame reads per sample), so an iteration is
-// two kernels: k_istft_frames -> k_stft_update.
+// iteration touches S, angles and the previous rebuilt spectrum exactly once each.  An iteration is
+// ONE launch (k_gl_fused): the windowed ISTFT frames of a tile (+ halo) live in LDS and the
+// overlap-add is folded into the STFT's gather.
+#include <utility>
+
 #include "kernels.h"
 
 namespace xdtts {
@@ -72,13 +74,21 @@ __device__ __forceinline__ Twiddles load_twiddles(const float2 *__restrict__ tw,
 // 512-point forward complex FFT of one wave.  In: v[r] = x[lane + 64 r].  Runs Stockham passes
 // Ns = 1 and 8 through `buf` (512 float2 of LDS owned by this wave) and the twiddle + butterfly
 // of pass Ns = 64; on return v[r] = X[lane + 64 r] (natural order), nothing left in LDS.
-// Must be called by all waves of the block (contains __syncthreads()).
+// buf is private to the calling wave, so the exchanges only need wave-level ordering.
+// Orders a wave's LDS stores before its later LDS loads of other lanes' addresses.  DS operations
+// of one wave execute in order, so only the compiler has to be held back; waves stay decoupled.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ void fft512(float2 (&v)[8], float2 *buf, const Twiddles &t, int lane) {
   // pass Ns = 1: no twiddles; out[8 j + r]
   fft8(v);
 #pragma unroll
   for (int r = 0; r < 8; ++r) buf[8 * lane + r] = v[r];
-  __syncthreads();
+  wave_lds_sync();
   // pass Ns = 8
   {
     const int k = lane & 7;
@@ -87,12 +97,12 @@ __device__ __forceinline__ void fft512(float2 (&v)[8], float2 *buf, const Twiddl
 #pragma unroll
     for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], t.p8[r - 1]);
     fft8(v);
-    __syncthreads();
+    wave_lds_sync();
     const int j0 = (lane >> 3) * 64 + k;
 #pragma unroll
     for (int r = 0; r < 8; ++r) buf[j0 + 8 * r] = v[r];
   }
-  __syncthreads();
+  wave_lds_sync();
   // pass Ns = 64; out[j + 64 r]
 #pragma unroll
   for (int r = 0; r < 8; ++r) v[r] = buf[lane + 64 * r];
@@ -103,18 +113,13 @@ __device__ __forceinline__ void fft512(float2 (&v)[8], float2 *buf, const Twiddl
 
 constexpr int FRAMES_PER_BLOCK = 4;  // one wave per frame
 
-// ISTFT, per-frame half: X = S * angles (513 bins) -> irfft(1024) -> synthesis window ->
-// frames[f][1024].  The Hermitian merge (X -> packed 512-point spectrum) is fused into the loads.
-__global__ __launch_bounds__(256) void k_istft_frames(GlBufs g) {
-  __shared__ float2 lds[FRAMES_PER_BLOCK][512];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int fr = blockIdx.x * FRAMES_PER_BLOCK + wave;
-  const bool ok = fr < g.F;
-  const int f = ok ? fr : g.F - 1;
+// Spectrum of frame f -> the packed 512-point input of the inverse transform, in registers:
+// X = S * angles (513 bins); Hermitian merge E/O; Z = E + i O; returns conj(Z)[lane + 64 r]
+// (inverse FFT = conj(FFT(conj Z)) / 512).
+__device__ __forceinline__ void istft_load(const GlBufs &g, const float2 *__restrict__ ang, int f, int lane,
+                                           float2 (&v)[8]) {
   const float *S = g.S + (size_t)f * g.nb;
-  const float2 *A = g.ang + (size_t)f * g.nb;
-  const Twiddles tws = load_twiddles(g.tw, lane);
-  float2 v[8];
+  const float2 *A = ang + (size_t)f * g.nb;
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
     const int k = lane + 64 * r, kc = 512 - k;
@@ -129,9 +134,20 @@ __global__ __launch_bounds__(256) void k_istft_frames(GlBufs g) {
     const float2 e = make_float2(0.5f * (xk.x + xc.x), 0.5f * (xk.y - xc.y));   // (X[k] + conj X[512-k]) / 2
     const float2 d = make_float2(0.5f * (xk.x - xc.x), 0.5f * (xk.y + xc.y));   // (X[k] - conj X[512-k]) / 2
     const float2 o = cmul(d, cconj(g.tw[k]));                                   // * e^{+2 pi i k / 1024}
-    // Z = E + i O ; feed conj(Z) to the forward FFT (inverse = conj(FFT(conj Z)) / 512)
     v[r] = make_float2(e.x - o.y, -(e.y + o.x));
   }
+}
+
+// ISTFT, per-frame half: irfft(1024) of S * angles -> synthesis window -> frames[f][1024].
+__global__ __launch_bounds__(256) void k_istft_frames(GlBufs g, const float2 *__restrict__ ang) {
+  __shared__ float2 lds[FRAMES_PER_BLOCK][512];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = blockIdx.x * FRAMES_PER_BLOCK + wave;
+  const bool ok = fr < g.F;
+  const int f = ok ? fr : g.F - 1;
+  const Twiddles tws = load_twiddles(g.tw, lane);
+  float2 v[8];
+  istft_load(g, ang, f, lane, v);
   fft512(v, lds[wave], tws, lane);
   if (!ok) return;
   float2 *out = reinterpret_cast<float2 *>(g.frames + (size_t)f * g.n_fft);
@@ -191,6 +207,37 @@ __global__ void k_wss_inv(GlBufs g) {
   g.wss_inv[n] = wss > 1.17549435e-38f ? wss : 1.0f;  // the divisor (1 where the sum is below tiny)
 }
 
+// Packed 512-point spectrum Z (in LDS) of a real 1024-sample frame -> its 513 bins X, then the
+// Griffin-Lim phase update:  a = X - alpha * tprev;  tprev = X;  angles = a / (|a| + 1e-16).
+// The caller fetches tprev early (tprev_load) so its latency hides behind the transforms.
+__device__ __forceinline__ void tprev_load(const GlBufs &g, int f, int lane, float2 (&pv)[9]) {
+  const float2 *tp = g.tprev + (size_t)f * g.nb;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) pv[r] = tp[lane + 64 * r];
+  pv[8] = tp[512];
+}
+
+__device__ __forceinline__ void stft_update_store(const GlBufs &g, float2 *__restrict__ ang_out, int f, int lane,
+                                                  const float2 *buf, float alpha, const float2 (&pvs)[9]) {
+  float2 *ang = ang_out + (size_t)f * g.nb;
+  float2 *tp = g.tprev + (size_t)f * g.nb;
+#pragma unroll
+  for (int r = 0; r <= 8; ++r) {
+    const int k = lane + 64 * r;
+    if (r == 8 && lane != 0) break;
+    const float2 zk = buf[k & 511], zc = buf[(512 - k) & 511];
+    const float2 e = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));  // (Z[k] + conj Z[512-k]) / 2
+    const float2 o = make_float2(0.5f * (zk.y + zc.y), 0.5f * (zc.x - zk.x));  // (Z[k] - conj Z[512-k]) / (2i)
+    const float2 twk = k == 512 ? make_float2(-1.f, 0.f) : g.tw[k];
+    const float2 x = cadd(e, cmul(twk, o));
+    const float2 pv = pvs[r];
+    tp[k] = x;
+    const float2 a = make_float2(fmaf(-alpha, pv.x, x.x), fmaf(-alpha, pv.y, x.y));
+    const float mag = sqrtf(fmaf(a.x, a.x, a.y * a.y)) + 1e-16f;
+    ang[k] = make_float2(a.x / mag, a.y / mag);
+  }
+}
+
 // STFT + phase update, one wave per frame: the frame's 1024 samples are gathered from the
 // overlap-added ISTFT frames (reflect padding at the ends), analysis window, rfft(1024), then
 //   a = rebuilt - alpha * tprev;  tprev = rebuilt;  angles = a / (|a| + 1e-16).
@@ -219,23 +266,111 @@ __global__ __launch_bounds__(256) void k_stft_update(GlBufs g, float alpha) {
   for (int r = 0; r < 8; ++r) buf[lane + 64 * r] = v[r];
   __syncthreads();
   if (!ok) return;
-  float2 *ang = g.ang + (size_t)f * g.nb;
-  float2 *tp = g.tprev + (size_t)f * g.nb;
+  float2 pv[9];
+  tprev_load(g, f, lane, pv);
+  stft_update_store(g, g.ang, f, lane, buf, alpha, pv);
+}
+
+// One whole Griffin-Lim iteration in ONE launch.  A block owns TF consecutive frames; it inverse-
+// transforms those plus a halo of three frames either side (the frames whose windows overlap its
+// samples at hop = n_fft/4) into LDS, overlap-adds them there, and forward-transforms its own TF
+// frames from LDS -- the ISTFT frame buffer never leaves the CU and an iteration costs one launch
+// boundary instead of two.  The halo is recomputed by the neighbouring block too ((TF+6)/TF more
+// inverse FFTs), and because neighbours read this block's angles while it writes new ones the
+// angles ping-pong between two buffers.  Rounding is identical to the two-kernel path (same FFT,
+// ascending-frame sums, true division by the window sum-square).
+template <int TF>
+__global__ __launch_bounds__(64 * (TF + 6)) void k_gl_fused(GlBufs g, const float2 *__restrict__ ang_in,
+                                                            float2 *__restrict__ ang_out, float alpha) {
+  constexpr int NSLOT = TF + 6;  // = waves per block: one inverse transform each
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *fb = smem;                                                   // [NSLOT][1024] windowed frames
+  float2 *scratch = reinterpret_cast<float2 *>(fb + NSLOT * NFFT);    // [NSLOT waves][512] FFT exchange
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int f0 = blockIdx.x * TF, N = HOP * (g.F - 1);
+  const Twiddles tws = load_twiddles(g.tw, lane);
+  const float2 *win = reinterpret_cast<const float2 *>(g.win);
+  float2 *buf = scratch + wave * 512;
+  // waves 0..TF-1 also own frame f0+wave in phase 2: fetch what that needs from HBM now
+  const int f2 = f0 + wave;
+  const bool own = wave < TF && f2 < g.F;
+  float2 pv[9];
+  float wss[16];
+  if (own) {
+    tprev_load(g, f2, lane, pv);
 #pragma unroll
-  for (int r = 0; r <= 8; ++r) {
-    const int k = lane + 64 * r;
-    if (r == 8 && lane != 0) break;
-    const float2 zk = buf[k & 511], zc = buf[(512 - k) & 511];
-    const float2 e = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));  // (Z[k] + conj Z[512-k]) / 2
-    const float2 o = make_float2(0.5f * (zk.y + zc.y), 0.5f * (zc.x - zk.x));  // (Z[k] - conj Z[512-k]) / (2i)
-    const float2 twk = k == 512 ? make_float2(-1.f, 0.f) : g.tw[k];
-    const float2 x = cadd(e, cmul(twk, o));
-    const float2 pv = tp[k];
-    tp[k] = x;
-    const float2 a = make_float2(fmaf(-alpha, pv.x, x.x), fmaf(-alpha, pv.y, x.y));
-    const float mag = sqrtf(fmaf(a.x, a.x, a.y * a.y)) + 1e-16f;
-    ang[k] = make_float2(a.x / mag, a.y / mag);
+    for (int i = 0; i < 16; ++i)
+      wss[i] = g.wss_inv[reflect_index(f2 * HOP + 2 * (lane + 64 * (i >> 1)) + (i & 1) - NFFT / 2, N)];
   }
+  // phase 1: wave w inverse-transforms frame f0-3+w (zeros outside [0, F))
+  {
+    const int f = f0 - 3 + wave;
+    const bool ok = f >= 0 && f < g.F;
+    float2 *out = reinterpret_cast<float2 *>(fb + wave * NFFT);
+    if (ok) {
+      float2 v[8];
+      istft_load(g, ang_in, f, lane, v);
+      fft512(v, buf, tws, lane);
+      const float sc = 1.0f / 512.0f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int m = lane + 64 * r;
+        const float2 w = win[m];
+        out[m] = make_float2(v[r].x * sc * w.x, -v[r].y * sc * w.y);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) out[lane + 64 * r] = make_float2(0.f, 0.f);
+    }
+  }
+  __syncthreads();
+  // phase 2: waves 0..TF-1 forward-transform the block's own frames, samples gathered from LDS
+  if (!own) return;
+  const int f = f2;
+  float2 v[8];
+  if (f >= 2 && f <= g.F - 3) {
+    // no reflection: sample pair (2m, 2m+1), m = lane + 64 r, sits in frames f+(r>>1)-k, k = 0..3,
+    // at float2 offset lane + 64 (r&1) + 128 k -- all compile-time offsets from one base
+    const float2 *fb2 = reinterpret_cast<const float2 *>(fb) + (wave + 3) * (NFFT / 2) + lane;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      float2 t[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) t[k] = fb2[((r >> 1) - k) * (NFFT / 2) + 64 * (r & 1) + 128 * k];
+      const float y0 = (((t[3].x + t[2].x) + t[1].x) + t[0].x) / wss[2 * r];
+      const float y1 = (((t[3].y + t[2].y) + t[1].y) + t[0].y) / wss[2 * r + 1];
+      const float2 w = win[lane + 64 * r];
+      v[r] = make_float2(y0 * w.x, y1 * w.y);
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int m = lane + 64 * r;
+      const int base = f * HOP + 2 * m - NFFT / 2;
+      float y[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int p = reflect_index(base + h, N);
+        const int q = p + NFFT / 2, jb = q >> 8, rr = q & (HOP - 1);
+        float t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          int slot = jb - k - (f0 - 3);
+          slot = slot < 0 ? 0 : (slot > NSLOT - 1 ? NSLOT - 1 : slot);  // in range by construction
+          t[k] = fb[slot * NFFT + rr + k * HOP];
+        }
+        y[h] = (((t[3] + t[2]) + t[1]) + t[0]) / wss[2 * r + h];
+      }
+      const float2 w = win[m];
+      v[r] = make_float2(y[0] * w.x, y[1] * w.y);
+    }
+  }
+  fft512(v, buf, tws, lane);
+  wave_lds_sync();
+#pragma unroll
+  for (int r = 0; r < 8; ++r) buf[lane + 64 * r] = v[r];
+  wave_lds_sync();
+  stft_update_store(g, ang_out, f, lane, buf, alpha, pv);
 }
 
 // Final ISTFT output: overlap-add + normalisation + centre trim for every sample.
@@ -292,17 +427,33 @@ void launch_gl_prepare(const GlBufs &g, hipStream_t s) {
   HIP_CHECK(hipGetLastError());
 }
 
-void launch_gl_iteration(const GlBufs &g, float alpha, hipStream_t s) {
-  const int nblk = (g.F + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK;
-  hipLaunchKernelGGL(k_istft_frames, dim3(nblk), dim3(256), 0, s, g);
-  hipLaunchKernelGGL(k_stft_update, dim3(nblk), dim3(256), 0, s, g, alpha);
-  HIP_CHECK(hipGetLastError());
-}
-
-void launch_gl_final(const GlBufs &g, float *audio, hipStream_t s) {
+// Enqueues n_iter iterations + the final ISTFT into `audio`.  Frame counts of 16 and more run the
+// fused one-launch iteration with the angles ping-ponging between g.ang and g.ang2; tiny inputs
+// (whose reflect padding folds more than once) use the two-kernel iteration in place.
+void launch_gl_iterations(const GlBufs &g, int n_iter, float alpha, float *audio, hipStream_t s) {
   const int nblk = (g.F + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK;
   const int N = g.hop * (g.F - 1);
-  hipLaunchKernelGGL(k_istft_frames, dim3(nblk), dim3(256), 0, s, g);
+  const float2 *final_ang = g.ang;
+  if (g.F >= 16) {
+    constexpr int TF = 4;
+    const size_t lds = sizeof(float) * (TF + 6) * (NFFT + 1024);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(k_gl_fused<TF>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    HIP_CHECK(attr);
+    const int grid = (g.F + TF - 1) / TF;
+    float2 *a = g.ang, *b = g.ang2;
+    for (int i = 0; i < n_iter; ++i) {
+      hipLaunchKernelGGL(k_gl_fused<TF>, dim3(grid), dim3(64 * (TF + 6)), lds, s, g, a, b, alpha);
+      std::swap(a, b);
+    }
+    final_ang = a;
+  } else {
+    for (int i = 0; i < n_iter; ++i) {
+      hipLaunchKernelGGL(k_istft_frames, dim3(nblk), dim3(256), 0, s, g, g.ang);
+      hipLaunchKernelGGL(k_stft_update, dim3(nblk), dim3(256), 0, s, g, alpha);
+    }
+  }
+  hipLaunchKernelGGL(k_istft_frames, dim3(nblk), dim3(256), 0, s, g, final_ang);
   hipLaunchKernelGGL(k_overlap_add, dim3((N + 255) / 256), dim3(256), 0, s, g, audio);
   HIP_CHECK(hipGetLastError());
 }

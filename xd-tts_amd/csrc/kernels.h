@@ -76,7 +76,7 @@ void launch_bilstm_coop(const float *xproj, const float *whhT_fwd, const float *
 struct GlBufs {
   int F, n_fft, hop, nb;   // frames, 1024, 256, 513
   float *S;                // [F][nb]        linear magnitude
-  float2 *ang;             // [F][nb]        unit-modulus phase estimate
+  float2 *ang, *ang2;      // [F][nb]        unit-modulus phase estimate (ping-pong for the fused iteration)
   float2 *tprev;           // [F][nb]        previous rebuilt spectrum
   float *frames;           // [F][n_fft]     windowed time frames
   float *wss_inv;          // [hop*(F-1)]    window sum-of-squares divisor per output sample
@@ -86,8 +86,7 @@ struct GlBufs {
 void launch_gl_exp_transpose(const float *mel_80xF, float *out_Fx80, int n_mels, int F, hipStream_t s);
 void launch_gl_phase_init(const GlBufs &g, uint32_t seed, const float *phase0_dev, hipStream_t s);
 void launch_gl_prepare(const GlBufs &g, hipStream_t s);                  // wss_inv for this F
-void launch_gl_iteration(const GlBufs &g, float alpha, hipStream_t s);   // istft -> stft (+OLA gather) + update
-void launch_gl_final(const GlBufs &g, float *audio, hipStream_t s);      // istft of S*ang
+void launch_gl_iterations(const GlBufs &g, int n_iter, float alpha, float *audio, hipStream_t s);  // + final ISTFT
 void launch_transpose(const float *in, float *out, int rows, int cols, hipStream_t s);
 
 }  // namespace xdtts
