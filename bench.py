@@ -209,7 +209,7 @@ def main():
             "griffinlim_iterations": gl_ms / K,
         },
         "roofline": {
-            "kernel": "decoder step (k_prenet, k_lstm<ATT>, k_qenergy, k_softmax_ctx, k_lstm<DEC>, k_project)",
+            "kernel": "decoder step (k_prenet, k_lstm<ATT>, k_qenergy, k_softmax_ctx, k_lstm<DEC>: 5 dependent launches)",
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
