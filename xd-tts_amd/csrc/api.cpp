@@ -142,6 +142,9 @@ struct xdtts_tacotron2 {
   DevBuf<float> xpadA, xpadB, xproj, memory, pmem;
   DevBuf<unsigned long long> enc_exchange;
   DevBuf<int> enc_err;
+  DevBuf<unsigned long long> dec_exchange;  // granule buffers of the persistent decoder
+  DevBuf<int> dec_err;
+  int persist_state = -1;                   // -1 unknown, 0 unavailable on this device, 1 usable
   static constexpr int COOP_MAX_B = 16;  // 8*B blocks of 1024 threads must be co-resident
   DevBuf<float> att_h, att_c, dec_h, dec_c, aw, awc, ctx, x, loc, e_part, pmel, frames, gates;
   DevBuf<float> ppA, ppB, mel_dev;
@@ -166,6 +169,8 @@ struct xdtts_tacotron2 {
     HIP_CHECK(hipHostMalloc((void **)&host_ctl, sizeof(int) * (2 + 4096), hipHostMallocDefault));
     enc_err.alloc(1);
     HIP_CHECK(hipMemsetAsync(enc_err.p, 0, sizeof(int), stream));
+    dec_err.alloc(1);
+    HIP_CHECK(hipMemsetAsync(dec_err.p, 0, sizeof(int), stream));
     w.upload(blob, stream);
   }
 
@@ -314,6 +319,17 @@ struct xdtts_tacotron2 {
 
   // run_decoder frame loop (mod.rs:302-342) for B chunks; limits = per-chunk step caps (host).
   // Returns the number of lock-step iterations executed; host_ctl[2+b] = frames of chunk b.
+  // Small lock-step batches run the persistent weight-stationary kernel (decoder_persistent.hip)
+  // when its 256-workgroup grid can be co-resident; XDTTS_DECODER=launch forces the
+  // launch-per-stage path (developer comparison aid).
+  bool use_persistent(const DecoderBufs &d) {
+    if (d.B > PERSIST_B_MAX || d.T > PERSIST_T_MAX) return false;
+    const char *e = getenv("XDTTS_DECODER");
+    if (e && std::string(e) == "launch") return false;
+    if (persist_state < 0) persist_state = decoder_persistent_supported(device, PERSIST_B_MAX, PERSIST_T_MAX) ? 1 : 0;
+    return persist_state == 1;
+  }
+
   int run_decoder(const DecoderBufs &d, const std::vector<int> &lim) {
     limits.upload(lim.data(), lim.size(), stream);
     launch_decoder_init(d, limits.p, stream);
@@ -324,6 +340,26 @@ struct xdtts_tacotron2 {
       HIP_CHECK(hipMemcpyAsync(host_ctl + 2, d.nframes, sizeof(int) * d.B, hipMemcpyDeviceToHost, stream));
       HIP_CHECK(hipStreamSynchronize(stream));
     };
+    if (use_persistent(d)) {
+      // one launch for the whole loop: the stop rule runs on the device and the kernel ends by itself.
+      // Its grid must own the chip, so persistent launches of different handles never overlap.
+      static std::mutex chip;
+      std::lock_guard<std::mutex> lk(chip);
+      dec_exchange.alloc(persist_granule_words(d.B));
+      const PersistBufs g = persist_bufs(dec_exchange.p, dec_err.p, d.B);
+      launch_persist_seed(d, g, limits.p, stream);
+      launch_decoder_persistent(d, w, g, max_lim, stream);
+      int e = 0;
+      HIP_CHECK(hipMemcpyAsync(&e, dec_err.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+      fetch();
+      if (e) {
+        HIP_CHECK(hipMemsetAsync(dec_err.p, 0, sizeof(int), stream));
+        fail(XDTTS_ERR_HIP, "persistent decoder: state exchange timed out (grid not co-resident?)");
+      }
+      int steps = 0;
+      for (int b = 0; b < d.B; ++b) steps = std::max(steps, host_ctl[2 + b]);
+      return steps;
+    }
     if (!d.use_gate) {  // deterministic work: every chunk runs to its cap
       while (launched < max_lim) {
         replay_steps(d);

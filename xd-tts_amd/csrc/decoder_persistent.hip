@@ -1,0 +1,695 @@
+// decoder_persistent.hip -- the Tacotron2 decoder loop (src/tacotron2/mod.rs:302-342) as ONE
+// persistent, weight-stationary launch for small lock-step batches (B <= 4 chunks).
+//
+// The launch-per-stage path (decoder.hip) streams the 71.3 MB of LSTM weights from HBM every step
+// (~11.5 us at the achievable bandwidth) and pays five grid boundaries (~8 us).  Here the weights
+// never move: 256 workgroups, one per CU, 512 threads each; workgroup c keeps the 16 gate rows of
+// attention-LSTM units 4c..4c+3 and of decoder-LSTM units 4c..4c+3 in its register file for the
+// whole utterance (8 waves x 64 lanes x 136 VGPRs = 272 KB per CU), wave w owning gate rows w and
+// w + 8 of each (16 waves x 68 VGPRs leaves too few working registers under the 128-VGPR cap).  What crosses CUs per step is only the state: six all-gather edges
+//     x (256 values) -> all      h_att (1024) -> all      partial energies (8 x T) -> 8
+//     context (512) -> all       h_dec (1024) -> all      mel + gate (81) -> 16
+// carried by data-tagged 8-byte granules {tag = step + 1, value} (one relaxed agent-scope store per
+// value; readers re-read until the tag matches -- MI355X_MICROARCH.md hand-off recipe R2, the
+// scheme the encoder BiLSTM already uses): no flags, no fences, placement-independent.  Two slots
+// per value by step parity; a slot is rewritten two steps later, after every reader has passed an
+// all-to-all dependency on its producer.  tools/ubench_edges.hip measures the skeleton (edges
+// only): 10.8 us per step = 1.8 us per edge.
+//
+// Roles on top of the LSTM slices (disjoint workgroups, per chunk b):
+//   attention, 8 per chunk: 16 of the 128 attention dims each -- query rows in registers, its
+//     [T][64] slice of the encoder memory and [T][16] of processed_memory in LDS; partial
+//     energies -> (edge) -> masked softmax (every one of the 8 recomputes it) -> 64 context
+//     columns; afterwards, off the critical path, the NEXT step's location features for its dims
+//     with the conv(2->32,k31) and dense(32->128) folded into one 62-tap filter per dim;
+//   projection + prenet, 16 per chunk: 5-6 rows of [W_p ; w_gate] in registers -> mel -> (edge)
+//     -> frame store, gate, stop rule (mod.rs:319-324), prenet layer 1 (recomputed by all 16, W0 in
+//     LDS), 16 layer-2 columns -> x(s+1).  The x granules carry the chunk's "still active" bit, so
+//     every workgroup learns of a stop with the data it waits for anyway, and the launch ends by
+//     itself when no chunk is active.
+// Only the column blocks that depend on the newest vector sit on the critical path (x for the
+// attention LSTM, ctx for the decoder LSTM); the other column blocks are accumulated per lane
+// while the producers of the next vector are busy, and one DPP wave reduction closes each row.
+//
+// Every spin is bounded and watches a global error word: a lost workgroup (grid not co-resident)
+// drains the whole launch in microseconds and surfaces as XDTTS_ERR_HIP on the host.
+#include "device_utils.h"
+#include "kernels.h"
+
+namespace xdtts {
+
+namespace {
+
+typedef unsigned long long u64;
+
+constexpr int PT = 512;                  // threads per workgroup (8 waves, 256 VGPRs each)
+constexpr int NW = PT / 64;
+constexpr int P_NCU = ATT_RNN / 4;       // 256 workgroups = LSTM slices
+constexpr int TP = PERSIST_T_MAX;        // encoder-step capacity of the attention role
+constexpr int ATTN_CU = 8, PRE_CU = 16;  // role workgroups per chunk
+constexpr int EP_LD = TP, MEL_GL = 96;
+constexpr unsigned P_SPIN_LIMIT = 1u << 21;
+constexpr unsigned ACT_BIT = 0x80000000u;
+constexpr int WPAD = TP + 32;            // zero-padded attention-weight window, index t + 15
+static_assert(ATT_RNN == DEC_RNN && P_NCU == 256, "one workgroup per 4 + 4 hidden units");
+
+__device__ __forceinline__ void publish(u64 *slot, unsigned tag, float v) {
+  __hip_atomic_store(slot, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 peek(const u64 *slot) {
+  return __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool give_up(unsigned &spins, int *err) {
+  if (++spins > P_SPIN_LIMIT || ((spins & 127u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+    atomicExch(err, 1);
+    return true;
+  }
+  __builtin_amdgcn_s_sleep(1);
+  return false;
+}
+// N granules at base[idx + i * stride], all loads in flight together; `base` is uniform and the
+// offsets are 32-bit so the loads use the SGPR-base addressing form (no 64-bit VGPR addresses kept
+// live across the step loop).  A timed-out slot reads as {tag 0, 0.0f}.
+template <int N>
+__device__ __forceinline__ void gather(const u64 *base, unsigned idx, unsigned stride, unsigned want,
+                                       const bool (&need)[N], float (&out)[N], unsigned (&tag)[N], int *err) {
+  bool done[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    done[i] = !need[i];
+    out[i] = 0.f;
+    tag[i] = 0u;
+  }
+  unsigned spins = 0;
+  for (;;) {
+    u64 v[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      if (!done[i]) v[i] = peek(base + (idx + (unsigned)i * stride));
+    bool all = true;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      if (!done[i]) {
+        const unsigned t = (unsigned)(v[i] >> 32);
+        if ((t & ~ACT_BIT) == want) {
+          out[i] = __uint_as_float((unsigned)v[i]);
+          tag[i] = t;
+          done[i] = true;
+        } else {
+          all = false;
+        }
+      }
+    if (all || give_up(spins, err)) return;
+  }
+}
+
+__device__ __forceinline__ float4 lds4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+// Hides a thread-index expression's known bits from the optimiser.  Without this `idx + CONST`
+// is canonicalised to `idx | CONST` wherever the bits are disjoint, the constant no longer folds
+// into the ds instruction's offset field, and every unrolled access gets its own address register,
+// hoisted out of the step loop and spilled (measured: ~100 scratch reloads per step).
+__device__ __forceinline__ unsigned opaque(unsigned v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
+constexpr int persist_lds_floats(int pb) {
+  const int common = pb * (PRENET + EMB + ATT_RNN + DEC_RNN + 16) + 4;
+  const int attn = TP * 64 + 2 * TP * 16 + 2 * TP + 16 + NW * 64 + 2 * WPAD + 62 * 16 + 64;
+  const int pre = N_MEL * PRENET + MEL_GL + 2 * PRENET + PRENET;
+  return common + (attn > pre ? attn : pre);
+}
+
+struct PersistWeights {
+  const float4 *att_w, *dec_w, *q_w, *proj_w;
+  const float *att_b, *dec_b, *v_w, *loc_fused, *proj_b, *pre0T, *pre1T;
+};
+
+template <int PB>
+__global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, PersistBufs g, PersistWeights w, int nsteps) {
+  // static LDS: with compile-time addresses the per-access offsets fold into the ds instructions
+  // (a dynamic base made the compiler keep ~100 hoisted addresses live across the step loop)
+  __shared__ __attribute__((aligned(16))) float smem[persist_lds_floats(PB)];
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int T = d.T;
+  const unsigned L4 = opaque(4u * (unsigned)lane), TID = opaque((unsigned)tid), TG = opaque((unsigned)wave);
+  // ---- LDS: state vectors of all chunks, then the role's working set -------------------------
+  float *s_x = smem;                     // [PB][256]
+  float *s_ctx = s_x + PB * PRENET;      // [PB][512]
+  float *s_hatt = s_ctx + PB * EMB;      // [PB][1024]
+  float *s_hdec = s_hatt + PB * ATT_RNN; // [PB][1024]
+  float *s_g = s_hdec + PB * DEC_RNN;    // [PB][16] gate pre-activations of this workgroup's rows
+  int *s_act = reinterpret_cast<int *>(s_g + PB * 16);  // [4]
+  float *role = s_g + PB * 16 + 4;
+  // attention role
+  float *s_mem = role;                   // [TP][64]  this workgroup's columns of the encoder memory
+  float *s_pm = s_mem + TP * 64;         // [TP][16]  processed_memory, own dims
+  float *s_loc = s_pm + TP * 16;         // [TP][16]  location features, own dims
+  float *s_aw = s_loc + TP * 16;         // [TP]
+  float *s_awc = s_aw + TP;              // [TP]
+  float *s_q = s_awc + TP;               // [16]
+  float *s_part = s_q + 16;              // [NW][64]
+  float *s_wpad = s_part + NW * 64;      // [2][WPAD]
+  float *s_G = s_wpad + 2 * WPAD;        // [62][16]  fused location filter, own dims
+  float *s_cown = s_G + 62 * 16;         // [64]      own context columns
+  // projection + prenet role
+  float *s_W0 = role;                    // [80][256]
+  float *s_mel = s_W0 + N_MEL * PRENET;  // [96]
+  float *s_l1 = s_mel + MEL_GL;          // [2][256]
+  float *s_p1 = s_l1 + 2 * PRENET;       // [256]
+
+  // ---- resident weights ----------------------------------------------------------------------
+  // packed [unit][gate] order: row 16c + r is unit 4c + r/4, gate r%4; wave w owns r = w and w + 8
+  float4 wa[2][ATT_COLS / 256], wd[2][DEC_COLS / 256];
+  float bias_a[2], bias_d[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int row = 16 * c + wave + NW * r;
+#pragma unroll
+    for (int k = 0; k < ATT_COLS / 256; ++k) wa[r][k] = ld_stream(w.att_w + (size_t)row * (ATT_COLS / 4) + lane + 64 * k);
+#pragma unroll
+    for (int k = 0; k < DEC_COLS / 256; ++k) wd[r][k] = ld_stream(w.dec_w + (size_t)row * (DEC_COLS / 4) + lane + 64 * k);
+    bias_a[r] = w.att_b[row];
+    bias_d[r] = w.dec_b[row];
+  }
+  const bool attn = c < ATTN_CU * PB, pre = !attn && c < (ATTN_CU + PRE_CU) * PB;
+  const int rb = attn ? c / ATTN_CU : (pre ? (c - ATTN_CU * PB) / PRE_CU : 0);  // the role's chunk
+  const int rk = attn ? c % ATTN_CU : (c - ATTN_CU * PB) % PRE_CU;              // slice within the role
+  // The roles' own weights (query rows, projection rows, prenet layer-2 columns) are NOT kept in
+  // registers: they are re-read from L2 every step, issued before the gather they follow, so the
+  // 136 LSTM registers are the only long-lived ones.
+  const int prow = rk + 16 * wave;
+  const bool prow_ok = pre && wave < 6 && prow <= N_MEL;
+
+  // ---- state of the sequence so far (zeros at step 0; a previous launch's write-back otherwise) ----
+  const int step0 = d.ctl[0];
+#pragma unroll
+  for (int b = 0; b < PB; ++b) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      s_hatt[b * ATT_RNN + tid + PT * h] = d.att_h[0][b * ATT_RNN + tid + PT * h];
+      s_hdec[b * DEC_RNN + tid + PT * h] = d.dec_h[0][b * DEC_RNN + tid + PT * h];
+    }
+    s_ctx[b * EMB + tid] = d.ctx[b * EMB + tid];
+  }
+  const int cb = tid >> 2, cu = tid & 3;  // cell-update threads: tid < 4 PB -> (chunk, unit)
+  const bool cell = tid < 4 * PB;
+  float att_c = 0.f, dec_c = 0.f, ha_last = 0.f, hd_last = 0.f;
+  if (cell) {
+    att_c = d.att_c[cb * ATT_RNN + 4 * c + cu];
+    dec_c = d.dec_c[cb * DEC_RNN + 4 * c + cu];
+    ha_last = d.att_h[0][cb * ATT_RNN + 4 * c + cu];
+    hd_last = d.dec_h[0][cb * DEC_RNN + 4 * c + cu];
+  }
+  int nvalid = 0, nf_r = 0;
+  if (attn) {
+    for (int i = tid; i < TP * 64; i += PT) {
+      const int t = i >> 6, cc = i & 63;
+      s_mem[i] = t < T ? d.memory[((size_t)rb * T + t) * EMB + 64 * rk + cc] : 0.f;
+    }
+    for (int i = tid; i < TP * 16; i += PT) {
+      const int t = i >> 4, dd = i & 15;
+      s_pm[i] = t < T ? d.pmem[((size_t)rb * T + t) * ATT_DIM + 16 * rk + dd] : 0.f;
+    }
+    if (tid < TP) {
+      s_aw[tid] = tid < T ? d.aw[rb * T + tid] : 0.f;
+      s_awc[tid] = tid < T ? d.awc[rb * T + tid] : 0.f;
+    }
+    for (int i = tid; i < 62 * 16; i += PT) s_G[i] = w.loc_fused[(size_t)(i >> 4) * ATT_DIM + 16 * rk + (i & 15)];
+    if (tid < 64) s_cown[tid] = d.ctx[rb * EMB + 64 * rk + tid];
+    nvalid = d.n_valid[rb];
+  }
+  if (pre) {
+    for (int i = tid; i < N_MEL * PRENET; i += PT) s_W0[i] = w.pre0T[i];
+    nf_r = d.nframes[rb];
+  }
+  const uint32_t item = d.item_base + (uint32_t)rb;
+  __syncthreads();
+
+  // ---- deferred pieces: everything that does not depend on the newest vector -----------------
+  float aacc[PB][2], dacc[PB][2];
+  auto att_bulk = [&](unsigned L4) {  // attention LSTM, columns [ctx(s-1) ; h_att(s-1)]
+#pragma unroll
+    for (int b = 0; b < PB; ++b) {
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int k = 1; k < 7; ++k) {
+        const float4 v = k < 3 ? lds4(s_ctx + b * EMB + 256 * (k - 1) + L4) : lds4(s_hatt + b * ATT_RNN + 256 * (k - 3) + L4);
+        a0 = dot4(wa[0][k], v, a0);
+        a1 = dot4(wa[1][k], v, a1);
+      }
+      aacc[b][0] = a0;
+      aacc[b][1] = a1;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto dec_bulk_h = [&](unsigned L4) {  // decoder LSTM, columns h_dec(s-1)
+#pragma unroll
+    for (int b = 0; b < PB; ++b) {
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int k = 6; k < 10; ++k) {
+        const float4 v = lds4(s_hdec + b * DEC_RNN + 256 * (k - 6) + L4);
+        a0 = dot4(wd[0][k], v, a0);
+        a1 = dot4(wd[1][k], v, a1);
+      }
+      dacc[b][0] = a0;
+      dacc[b][1] = a1;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // location features of the NEXT step for this workgroup's 16 dims, from s_aw / s_awc:
+  //   loc[t][a] = sum_{c,k} G[a][c][k] pad_c[t + k],  G = dense . conv folded on the host.
+  // 256 threads: (dim pair, 4 consecutive time steps), sliding window in registers.
+  auto location = [&](int tid) {
+    for (int i = tid; i < 2 * WPAD; i += PT) {
+      const int ch = i / WPAD, t = i % WPAD - (LOC_K - 1) / 2;
+      s_wpad[i] = (t >= 0 && t < T) ? (ch ? s_awc[t] : s_aw[t]) : 0.f;
+    }
+    __syncthreads();
+    if (tid < 256) {
+      const int tq = tid >> 3;  // dims 2dp, 2dp+1; steps 4tq .. 4tq+3
+      const unsigned DP2 = 2u * (tid & 7), Q4 = 4u * (unsigned)tq;
+      float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch) {
+        const float *wp = s_wpad + ch * WPAD + Q4;
+        float w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3];
+#pragma unroll 4
+        for (int k = 0; k < LOC_K; ++k) {
+          const float2 gv = *reinterpret_cast<const float2 *>(s_G + (ch * LOC_K + k) * 16 + DP2);
+          a0[0] = fmaf(gv.x, w0, a0[0]);
+          a1[0] = fmaf(gv.y, w0, a1[0]);
+          a0[1] = fmaf(gv.x, w1, a0[1]);
+          a1[1] = fmaf(gv.y, w1, a1[1]);
+          a0[2] = fmaf(gv.x, w2, a0[2]);
+          a1[2] = fmaf(gv.y, w2, a1[2]);
+          a0[3] = fmaf(gv.x, w3, a0[3]);
+          a1[3] = fmaf(gv.y, w3, a1[3]);
+          w0 = w1;
+          w1 = w2;
+          w2 = w3;
+          w3 = wp[k + 4];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<float2 *>(s_loc + 16 * Q4 + DP2 + 16 * i) = make_float2(a0[i], a1[i]);
+    }
+    __syncthreads();
+  };
+  att_bulk(L4);
+  dec_bulk_h(L4);
+  if (attn) location(tid);
+
+  int s = step0;
+  const int s_stop = step0 + nsteps;
+  for (; s < s_stop; ++s) {
+    // Per-iteration opaque copies of the thread indices: nothing derived from them can be hoisted
+    // out of the step loop, so addresses are recomputed next to their use (one VALU op each)
+    // instead of living in ~100 registers (and their spill slots) across the whole iteration.
+    const int tid_it = tid + (int)opaque(0u);
+    {
+    const int tid = tid_it, lane = tid & 63, wave = tid >> 6;
+    const unsigned L4 = 4u * (unsigned)lane, TID = (unsigned)tid, TG = (unsigned)wave;
+    const int cb = tid >> 2, cu = tid & 3;
+    const bool cell = tid < 4 * PB;
+    const int prow = rk + 16 * wave;
+    const bool prow_ok = pre && wave < 6 && prow <= N_MEL;
+    const int p = s & 1;
+    const unsigned want = (unsigned)(s + 1);
+    // ---- P1: x(s) and the chunks' active bits ------------------------------------------------
+    {
+      const int b0 = tid >> 8, i = tid & 255;  // chunks b0 and b0 + 2
+      const bool need[2] = {b0 < PB, b0 + 2 < PB};
+      float v[2];
+      unsigned tg[2];
+      gather<2>(g.x, (unsigned)((p * PB + b0) * PRENET + i), 2u * PRENET, want, need, v, tg, g.err);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        if (need[j]) {
+          s_x[(b0 + 2 * j) * PRENET + i] = v[j];
+          if (i == 0) s_act[b0 + 2 * j] = (tg[j] & ACT_BIT) ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    bool act[PB], any = false;
+#pragma unroll
+    for (int b = 0; b < PB; ++b) {
+      act[b] = s_act[b] != 0;
+      any = any || act[b];
+    }
+    if (!any) break;  // every chunk has stopped (or the exchange failed): the launch ends by itself
+    const bool act_r = s_act[rb] != 0;
+    // attention LSTM: close the rows with the x columns
+#pragma unroll
+    for (int b = 0; b < PB; ++b)
+      if (act[b]) {
+        const float4 v = lds4(s_x + b * PRENET + L4);
+        const float a0 = wave_sum(dot4(wa[0][0], v, aacc[b][0]));
+        const float a1 = wave_sum(dot4(wa[1][0], v, aacc[b][1]));
+        if (lane == 0) {
+          s_g[b * 16 + wave] = a0 + bias_a[0];
+          s_g[b * 16 + wave + NW] = a1 + bias_a[1];
+        }
+      }
+    __syncthreads();
+    if (cell && s_act[cb]) {
+      const float *gp = s_g + cb * 16 + 4 * cu;
+      const float ig = sigmoidf_(gp[0]), fg = sigmoidf_(gp[1]), gg = tanhf(gp[2]), og = sigmoidf_(gp[3]);
+      att_c = fmaf(fg, att_c, ig * gg);
+      ha_last = og * tanhf(att_c);
+      publish(g.hatt + (unsigned)((p * PB + cb) * ATT_RNN + 4 * c + cu), want, ha_last);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- P2: h_att(s) ----------------------------------------------------------------------------
+    float4 sp[8];  // attention: query rows 16 rk + wave (+8); projection: row rk + 16 wave of [W_p ; w_gate]
+    float vv[4];
+    if (attn && act_r) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sp[4 * r + j] = w.q_w[(unsigned)((16 * rk + wave + NW * r) * (ATT_RNN / 4) + lane + 64 * j)];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) vv[i] = w.v_w[16 * rk + 4 * (tid & 3) + i];
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float v[PB];
+      unsigned tg[PB];
+      gather<PB>(g.hatt, (unsigned)(p * PB * ATT_RNN + tid + PT * h), ATT_RNN, want, act, v, tg, g.err);
+#pragma unroll
+      for (int b = 0; b < PB; ++b)
+        if (act[b]) s_hatt[b * ATT_RNN + tid + PT * h] = v[b];
+    }
+    __syncthreads();
+    if (attn && act_r) {
+      // query rows 16 rk + wave (+8), then this workgroup's share of the energies (mod.rs:304, D3)
+      float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 v = lds4(s_hatt + rb * ATT_RNN + 256 * j + L4);
+        q0 = dot4(sp[j], v, q0);
+        q1 = dot4(sp[4 + j], v, q1);
+      }
+      q0 = wave_sum(q0);
+      q1 = wave_sum(q1);
+      if (lane == 0) {
+        s_q[wave] = q0;
+        s_q[wave + NW] = q1;
+      }
+      __syncthreads();
+      const int t = tid >> 2, dq = 4 * (tid & 3);
+      const float4 q4 = lds4(s_q + dq), l4 = lds4(s_loc + 4 * TID), p4 = lds4(s_pm + 4 * TID);
+      float e = vv[0] * tanhf(q4.x + l4.x + p4.x);
+      e = fmaf(vv[1], tanhf(q4.y + l4.y + p4.y), e);
+      e = fmaf(vv[2], tanhf(q4.z + l4.z + p4.z), e);
+      e = fmaf(vv[3], tanhf(q4.w + l4.w + p4.w), e);
+      e += dpp_move<0xB1, 0xf>(0.f, e);  // quad_perm:[1,0,3,2]
+      e += dpp_move<0x4E, 0xf>(0.f, e);  // quad_perm:[2,3,0,1]
+      if ((tid & 3) == 0 && t < T) publish(g.ep + (unsigned)(((p * PB + rb) * ATTN_CU + rk) * EP_LD + t), want, e);
+    }
+    // decoder LSTM: the h_att columns (off the critical path for everyone but the above)
+#pragma unroll
+    for (int b = 0; b < PB; ++b)
+      if (act[b]) {
+        float a0 = dacc[b][0], a1 = dacc[b][1];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float4 v = lds4(s_hatt + b * ATT_RNN + 256 * k + L4);
+          a0 = dot4(wd[0][k], v, a0);
+          a1 = dot4(wd[1][k], v, a1);
+        }
+        dacc[b][0] = a0;
+        dacc[b][1] = a1;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- P3 (attention role): energies of all 8 slices -> softmax -> own context columns ----------
+    if (attn && act_r) {
+      if (wave == 0) {
+        const int t0 = lane, t1 = lane + 64;
+        const unsigned eb = (unsigned)((p * PB + rb) * ATTN_CU * EP_LD);
+        bool n0[ATTN_CU], n1[ATTN_CU];
+#pragma unroll
+        for (int k = 0; k < ATTN_CU; ++k) {
+          n0[k] = t0 < T;
+          n1[k] = t1 < T;
+        }
+        float v0[ATTN_CU], v1[ATTN_CU];
+        unsigned tg[ATTN_CU];
+        gather<ATTN_CU>(g.ep, eb + t0, EP_LD, want, n0, v0, tg, g.err);
+        gather<ATTN_CU>(g.ep, eb + t1, EP_LD, want, n1, v1, tg, g.err);
+        float e0 = 0.f, e1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < ATTN_CU; ++k) {
+          e0 += v0[k];
+          e1 += v1[k];
+        }
+        e0 = t0 < T && t0 < nvalid ? e0 : -INFINITY;  // mask, mod.rs:219-220
+        e1 = t1 < T && t1 < nvalid ? e1 : -INFINITY;
+        const float m = wave_max(fmaxf(e0, e1));
+        const float x0 = expf(e0 - m), x1 = expf(e1 - m);
+        const float sum = wave_sum(x0 + x1);
+        const float a0 = x0 / sum, a1 = x1 / sum;
+        s_aw[t0] = a0;
+        s_awc[t0] += a0;
+        s_aw[t1] = a1;
+        s_awc[t1] += a1;
+      }
+      __syncthreads();
+      {
+        float acc = 0.f;  // column tid & 63, time steps wave + 8 u
+#pragma unroll
+        for (int u = 0; u < TP / NW; ++u) acc = fmaf(s_aw[TG + NW * u], s_mem[TID + NW * 64 * u], acc);  // rows t >= T are zero
+        s_part[TID] = acc;
+      }
+      __syncthreads();
+      if (tid < 64) {
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) v += s_part[q * 64 + TID];
+        s_cown[tid] = v;
+        publish(g.ctx + (unsigned)((p * PB + rb) * EMB + 64 * rk + tid), want, v);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- P4: ctx(s) -> decoder LSTM ------------------------------------------------------------
+    {
+      float v[PB];
+      unsigned tg[PB];
+      gather<PB>(g.ctx, (unsigned)(p * PB * EMB + tid), EMB, want, act, v, tg, g.err);
+#pragma unroll
+      for (int b = 0; b < PB; ++b)
+        if (act[b]) s_ctx[b * EMB + tid] = v[b];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < PB; ++b)
+      if (act[b]) {
+        float a0 = dacc[b][0], a1 = dacc[b][1];
+#pragma unroll
+        for (int k = 4; k < 6; ++k) {
+          const float4 v = lds4(s_ctx + b * EMB + 256 * (k - 4) + L4);
+          a0 = dot4(wd[0][k], v, a0);
+          a1 = dot4(wd[1][k], v, a1);
+        }
+        a0 = wave_sum(a0);
+        a1 = wave_sum(a1);
+        if (lane == 0) {
+          s_g[b * 16 + wave] = a0 + bias_d[0];
+          s_g[b * 16 + wave + NW] = a1 + bias_d[1];
+        }
+      }
+    __syncthreads();
+    if (cell && s_act[cb]) {
+      const float *gp = s_g + cb * 16 + 4 * cu;
+      const float ig = sigmoidf_(gp[0]), fg = sigmoidf_(gp[1]), gg = tanhf(gp[2]), og = sigmoidf_(gp[3]);
+      dec_c = fmaf(fg, dec_c, ig * gg);
+      hd_last = og * tanhf(dec_c);
+      publish(g.hdec + (unsigned)((p * PB + cb) * DEC_RNN + 4 * c + cu), want, hd_last);
+    }
+    att_bulk(L4);  // for step s+1: ctx(s), h_att(s)
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- P5: h_dec(s) -> projection rows ---------------------------------------------------------
+    float pbias = 0.f;
+    if (prow_ok && act_r) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) sp[j] = w.proj_w[(unsigned)(prow * (PROJ_IN / 4) + lane + 64 * j)];
+      pbias = w.proj_b[prow];
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float v[PB];
+      unsigned tg[PB];
+      gather<PB>(g.hdec, (unsigned)(p * PB * DEC_RNN + tid + PT * h), DEC_RNN, want, act, v, tg, g.err);
+#pragma unroll
+      for (int b = 0; b < PB; ++b)
+        if (act[b]) s_hdec[b * DEC_RNN + tid + PT * h] = v[b];
+    }
+    __syncthreads();
+    if (prow_ok && act_r) {
+      float a = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a = dot4(sp[j], lds4(s_hdec + rb * DEC_RNN + 256 * j + L4), a);
+#pragma unroll
+      for (int j = 4; j < 6; ++j) a = dot4(sp[j], lds4(s_ctx + rb * EMB + 256 * (j - 4) + L4), a);
+      a = wave_sum(a);
+      if (lane == 0) publish(g.mel + (unsigned)((p * PB + rb) * MEL_GL + prow), want, a + pbias);
+    }
+    dec_bulk_h(L4);  // for step s+1
+    if (attn && act_r) location(tid);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- P6 (projection + prenet role): frame s, stop rule, x(s+1) ------------------------------
+    if (pre) {
+      bool nxt = false;
+      float w1r[2][4];  // prenet layer 2: columns 16 rk + wave (+8), inputs lane + 64 k
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w1r[r][k] = w.pre1T[(unsigned)((lane + 64 * k) * PRENET + 16 * rk + wave + NW * r)];
+      if (act_r) {
+        if (tid < N_MEL + 1) {
+          const bool need[1] = {true};
+          float v[1];
+          unsigned tg[1];
+          gather<1>(g.mel, (unsigned)((p * PB + rb) * MEL_GL + tid), 0, want, need, v, tg, g.err);
+          s_mel[tid] = v[0];
+        }
+        __syncthreads();
+        const float gate = s_mel[N_MEL];
+        const bool fired = d.use_gate && gate_sigmoid(gate) > d.gate_threshold;  // mod.rs:319-324
+        if (rk == 0) {
+          if (tid < N_MEL) d.frames[((size_t)rb * d.max_steps + s) * N_MEL + tid] = s_mel[tid];
+          if (tid == 0) {
+            d.gates[(size_t)rb * d.max_steps + s] = gate;
+            if (fired) d.nframes[rb] = s + 1;  // the tripping frame is kept
+          }
+        }
+        if (fired) nf_r = s + 1;
+        nxt = s + 1 < nf_r;
+      }
+      float xo[2] = {0.f, 0.f};
+      if (nxt) {
+        // layer 1: output tid & 255, inputs [40 hf, 40 hf + 40), hf = tid >> 8
+        const unsigned HW = (unsigned)((tid >> 8) * (N_MEL / 2) * PRENET + (tid & 255)), HM = (unsigned)((tid >> 8) * (N_MEL / 2));
+        float acc = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < N_MEL / 2; ++k) acc = fmaf(s_W0[HW + PRENET * k], s_mel[HM + k], acc);
+        s_l1[TID] = acc;
+        __syncthreads();
+        if (tid < PRENET) {
+          float v = fmaxf(s_l1[TID] + s_l1[PRENET + TID], 0.f);
+          if (d.dropout_mode)
+            v = (rng_u32(d.dropout_seed, 0x1000u + 2u * item, (uint32_t)(s + 1) * 256u + (uint32_t)tid) >> 31) ? 0.f : 2.f * v;
+          s_p1[tid] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          float a = 0.f;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) a = fmaf(w1r[r][k], s_p1[(L4 >> 2) + 64 * k], a);
+          a = fmaxf(wave_sum(a), 0.f);
+          const int j = 16 * rk + wave + NW * r;
+          if (d.dropout_mode)
+            a = (rng_u32(d.dropout_seed, 0x1001u + 2u * item, (uint32_t)(s + 1) * 256u + (uint32_t)j) >> 31) ? 0.f : 2.f * a;
+          xo[r] = a;
+        }
+      }
+      if (lane < 2)
+        publish(g.x + (unsigned)(((p ^ 1) * PB + rb) * PRENET + 16 * rk + wave + NW * lane), (want + 1u) | (nxt ? ACT_BIT : 0u),
+                lane ? xo[1] : xo[0]);
+    }
+    }
+  }
+
+  // ---- write the state back (a later launch may continue the sequence) -----------------------
+  if (cell) {
+    d.att_c[cb * ATT_RNN + 4 * c + cu] = att_c;
+    d.dec_c[cb * DEC_RNN + 4 * c + cu] = dec_c;
+    d.att_h[0][cb * ATT_RNN + 4 * c + cu] = ha_last;
+    d.dec_h[0][cb * DEC_RNN + 4 * c + cu] = hd_last;
+  }
+  if (attn) {
+    if (tid < 64) d.ctx[rb * EMB + 64 * rk + tid] = s_cown[tid];
+    if (rk == 0 && tid < T) {
+      d.aw[rb * T + tid] = s_aw[tid];
+      d.awc[rb * T + tid] = s_awc[tid];
+    }
+  }
+  if (c == 0 && tid == 0) d.ctl[0] = s;
+}
+
+// x(0) = prenet(0) = 0 (the prenet has no bias, mod.rs:208) with the chunks' initial active bits
+__global__ void k_persist_seed(PersistBufs g, const int *limits, int B) {
+  const int b = blockIdx.x, i = threadIdx.x;
+  publish(g.x + (size_t)b * PRENET + i, 1u | (limits[b] > 0 ? ACT_BIT : 0u), 0.f);
+}
+
+template <int PB>
+void launch_pb(const DecoderBufs &d, const PersistBufs &g, const PersistWeights &pw, int nsteps, hipStream_t s) {
+  hipLaunchKernelGGL(k_decoder_persistent<PB>, dim3(P_NCU), dim3(PT), 0, s, d, g, pw, nsteps);
+  HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace
+
+size_t persist_granule_words(int B) {
+  return (size_t)2 * B * (PRENET + ATT_RNN + ATTN_CU * EP_LD + EMB + DEC_RNN + MEL_GL);
+}
+
+PersistBufs persist_bufs(unsigned long long *base, int *err, int B) {
+  PersistBufs g{};
+  g.x = base;
+  g.hatt = g.x + (size_t)2 * B * PRENET;
+  g.ep = g.hatt + (size_t)2 * B * ATT_RNN;
+  g.ctx = g.ep + (size_t)2 * B * ATTN_CU * EP_LD;
+  g.hdec = g.ctx + (size_t)2 * B * EMB;
+  g.mel = g.hdec + (size_t)2 * B * DEC_RNN;
+  g.err = err;
+  return g;
+}
+
+// The grid must be co-resident: one workgroup per CU on a 256-CU part, nothing else of ours running.
+bool decoder_persistent_supported(int device, int B, int T) {
+  if (B < 1 || B > PERSIST_B_MAX || T > PERSIST_T_MAX) return false;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return false;
+  if (prop.multiProcessorCount < P_NCU) return false;
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_decoder_persistent<PERSIST_B_MAX>, PT, 0) != hipSuccess)
+    return false;
+  return per_cu >= 1;
+}
+
+void launch_persist_seed(const DecoderBufs &d, const PersistBufs &g, const int *limits_dev, hipStream_t s) {
+  HIP_CHECK(hipMemsetAsync(g.x, 0, persist_granule_words(d.B) * sizeof(unsigned long long), s));
+  hipLaunchKernelGGL(k_persist_seed, dim3(d.B), dim3(PRENET), 0, s, g, limits_dev, d.B);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_decoder_persistent(const DecoderBufs &d, const DeviceWeights &w, const PersistBufs &g, int nsteps,
+                               hipStream_t s) {
+  PersistWeights pw{};
+  pw.att_w = reinterpret_cast<const float4 *>(w.att_w.p);
+  pw.dec_w = reinterpret_cast<const float4 *>(w.dec_w.p);
+  pw.q_w = reinterpret_cast<const float4 *>(w.q_w.p);
+  pw.proj_w = reinterpret_cast<const float4 *>(w.proj_w.p);
+  pw.att_b = w.att_b.p;
+  pw.dec_b = w.dec_b.p;
+  pw.v_w = w.v_w.p;
+  pw.loc_fused = w.loc_fused.p;
+  pw.proj_b = w.proj_b.p;
+  pw.pre0T = w.pre0T.p;
+  pw.pre1T = w.pre1T.p;
+  switch (d.B) {
+    case 1: launch_pb<1>(d, g, pw, nsteps, s); break;
+    case 2: launch_pb<2>(d, g, pw, nsteps, s); break;
+    case 3: launch_pb<3>(d, g, pw, nsteps, s); break;
+    case 4: launch_pb<4>(d, g, pw, nsteps, s); break;
+    default: fail(XDTTS_ERR_BAD_ARG, "persistent decoder: %d chunks (max %d)", d.B, PERSIST_B_MAX);
+  }
+}
+
+}  // namespace xdtts

@@ -42,6 +42,24 @@ size_t decoder_pmel_floats(int B);
 // Zeroes the recurrent state (DecoderState::new, mod.rs:202-233) and sets the step limits.
 void launch_decoder_init(const DecoderBufs &d, const int *limits_dev, hipStream_t s);
 
+// ---- persistent weight-stationary decoder (decoder_persistent.hip), small lock-step batches ------
+constexpr int PERSIST_B_MAX = 4;    // chunks in lock-step
+constexpr int PERSIST_T_MAX = 128;  // encoder steps (the reference's window is 100, mod.rs:363)
+// Granule exchange buffers: 8-byte {tag, value} records, [2 step parities][B][n] each.
+struct PersistBufs {
+  unsigned long long *x, *hatt, *ep, *ctx, *hdec, *mel;
+  int *err;  // set by a workgroup whose bounded spin ran out
+};
+size_t persist_granule_words(int B);
+PersistBufs persist_bufs(unsigned long long *base, int *err, int B);
+bool decoder_persistent_supported(int device, int B, int T);
+// After launch_decoder_init: clears the exchange and publishes x(0) with the chunks' active bits.
+void launch_persist_seed(const DecoderBufs &d, const PersistBufs &g, const int *limits_dev, hipStream_t s);
+// Runs up to `nsteps` decoder steps in one launch (ends early when every chunk has stopped);
+// frames/gates/nframes are complete on return, ctl[0] = steps executed.  No flush needed.
+void launch_decoder_persistent(const DecoderBufs &d, const DeviceWeights &w, const PersistBufs &g, int nsteps,
+                               hipStream_t s);
+
 // ---- NT GEMM on the f32 MFMA: C = act(A W^T + bias) (+R) ---------------------------------------
 struct GemmArgs {
   const float *A;

@@ -297,6 +297,19 @@ void DeviceWeights::upload(const std::vector<float> &blob, hipStream_t s) {
   v_w.upload(T(blob, "attention.v.weight"), ATT_DIM, s);
   upload_transposed(T(blob, "attention.location_conv.weight"), LOC_F, 2 * LOC_K, loc_conv, s);  // -> [c][k][f]
   upload_transposed(T(blob, "attention.location_dense.weight"), ATT_DIM, LOC_F, loc_denseT, s);
+  {
+    // loc[t][a] = sum_f dense[a][f] sum_{c,k} conv[f][c][k] w_c[t+k-15]: one 62-tap filter per attention dim
+    const float *cv = T(blob, "attention.location_conv.weight"), *dn = T(blob, "attention.location_dense.weight");
+    std::vector<float> gf((size_t)2 * LOC_K * ATT_DIM);
+    for (int ck = 0; ck < 2 * LOC_K; ++ck)
+      for (int a = 0; a < ATT_DIM; ++a) {
+        double acc = 0.0;
+        for (int f = 0; f < LOC_F; ++f) acc += (double)dn[(size_t)a * LOC_F + f] * (double)cv[(size_t)f * 2 * LOC_K + ck];
+        gf[(size_t)ck * ATT_DIM + a] = (float)acc;
+      }
+    loc_fused.upload(gf.data(), gf.size(), s);
+    HIP_CHECK(hipStreamSynchronize(s));
+  }
   pack_lstm(blob, "decoder_rnn", DEC_RNN, DEC_IN, dec_w, dec_b, s);
   {
     std::vector<float> pw((size_t)(N_MEL + 1) * PROJ_IN), pb(N_MEL + 1);

@@ -43,6 +43,7 @@ struct DeviceWeights {
   DevBuf<float> pre0T, pre1T;                // [80][256], [256][256] (transposed)
   DevBuf<float> att_w, att_b;                // [1024 units][4 gates][1792], [1024][4]
   DevBuf<float> q_w, v_w, loc_conv, loc_denseT;  // [128][1024], [128], [2][31][32] (transposed), [32][128]
+  DevBuf<float> loc_fused;                   // [2*31 taps][128]  location dense . conv folded (persistent decoder)
   DevBuf<float> dec_w, dec_b;                // [1024][4][2560], [1024][4]
   DevBuf<float> proj_w, proj_b;              // [81][1536] (row 80 = gate), [81]
   // layouts for the partial-product epilogues of the LSTM kernels (decoder.hip):
