@@ -16,6 +16,8 @@ cases = [("B=1 fixed 60", [synth_ids(95)], dict(fixed_steps=60)),
          ("B=2 fixed/id", [synth_ids(95), synth_ids(25, seed=3)], dict(fixed_frames_per_id=6.667)),
          ("B=3 fixed 100", [synth_ids(40), synth_ids(77), synth_ids(100)], dict(fixed_steps=100)),
          ("B=1 gate", [synth_ids(30)], dict(max_steps=300)),
+         ("B=2 both 200", [synth_ids(95), synth_ids(60, seed=3)], dict(fixed_steps=200)),
+         ("B=4 all 100", [synth_ids(95), synth_ids(60, seed=3), synth_ids(33, seed=4), synth_ids(100, seed=5)], dict(fixed_steps=100)),
          ]
 for name, ids_list, kw in cases:
     o = pkg.default_opts(**kw)

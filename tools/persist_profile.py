@@ -1,0 +1,26 @@
+"""Developer aid (profile build only: make CXXFLAGS='-O3 -std=c++17 -fPIC -DXDTTS_PERSIST_PROFILE'):
+per-phase wall-clock of the persistent decoder, averaged per step, by workgroup role."""
+import importlib, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+pkg = importlib.import_module("xd-tts_amd")
+from conftest import synth_ids
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+steps = 400
+path = "/tmp/persist_prof.txt"
+os.environ["XDTTS_PERSIST_PROFILE"] = path
+m = pkg.Tacotron2.synthetic()
+ids = [synth_ids(95, seed=1 + b) for b in range(B)]
+o = pkg.default_opts(fixed_steps=steps)
+for _ in range(2):
+    m.infer_batch(ids, opts=o)
+t = m.last_timings()
+print("B=%d: %.2f us/step" % (B, t["decoder_ms"] * 1e3 / steps))
+a = np.loadtxt(path)[:, :11] / 100.0 / steps  # 100 MHz clock -> us per step
+names = ["loop", "wait x", "att tail", "wait h_att", "q+energies/bulk", "softmax+ctx", "wait ctx", "dec tail+bulk", "wait h_dec", "proj/bulk/loc", "prenet"]
+roles = {"attention": slice(0, 8 * B), "proj+prenet": slice(8 * B, 24 * B), "plain": slice(24 * B, 256)}
+print("%-18s" % "phase" + "".join("%14s" % r for r in roles))
+for i, n in enumerate(names):
+    print("%-18s" % n + "".join("%14.2f" % a[sl, i].mean() for sl in roles.values()))
+print("%-18s" % "sum" + "".join("%14.2f" % a[sl].sum(axis=1).mean() for sl in roles.values()))

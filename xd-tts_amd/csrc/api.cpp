@@ -346,9 +346,28 @@ struct xdtts_tacotron2 {
       static std::mutex chip;
       std::lock_guard<std::mutex> lk(chip);
       dec_exchange.alloc(persist_granule_words(d.B));
-      const PersistBufs g = persist_bufs(dec_exchange.p, dec_err.p, d.B);
+      PersistBufs g = persist_bufs(dec_exchange.p, dec_err.p, d.B);
+#ifdef XDTTS_PERSIST_PROFILE
+      static DevBuf<unsigned long long> prof;
+      prof.alloc(256 * 16);
+      g.prof = prof.p;
+#endif
       launch_persist_seed(d, g, limits.p, stream);
       launch_decoder_persistent(d, w, g, max_lim, stream);
+#ifdef XDTTS_PERSIST_PROFILE
+      if (const char *path = getenv("XDTTS_PERSIST_PROFILE")) {
+        std::vector<unsigned long long> hp(256 * 16);
+        HIP_CHECK(hipMemcpyAsync(hp.data(), prof.p, hp.size() * 8, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        if (FILE *f = fopen(path, "w")) {
+          for (int c = 0; c < 256; ++c) {
+            for (int i = 0; i < 16; ++i) fprintf(f, "%llu ", hp[c * 16 + i]);
+            fprintf(f, "\n");
+          }
+          fclose(f);
+        }
+      }
+#endif
       int e = 0;
       HIP_CHECK(hipMemcpyAsync(&e, dec_err.p, sizeof(int), hipMemcpyDeviceToHost, stream));
       fetch();

@@ -108,17 +108,35 @@ __device__ __forceinline__ float4 lds4(const float *p) { return *reinterpret_cas
 // is canonicalised to `idx | CONST` wherever the bits are disjoint, the constant no longer folds
 // into the ds instruction's offset field, and every unrolled access gets its own address register,
 // hoisted out of the step loop and spilled (measured: ~100 scratch reloads per step).
+// Keeps the per-chunk bodies of an unrolled chunk loop in program order: without it the LDS loads
+// of every chunk are hoisted ahead of the first FMA and the live set grows by ~40 VGPRs per chunk.
+__device__ __forceinline__ void chunk_fence() { asm volatile("" ::: "memory"); }
 __device__ __forceinline__ unsigned opaque(unsigned v) {
   asm volatile("" : "+v"(v));
   return v;
 }
 
 constexpr int persist_lds_floats(int pb) {
-  const int common = pb * (PRENET + EMB + ATT_RNN + DEC_RNN + 16) + 4;
-  const int attn = TP * 64 + 2 * TP * 16 + 2 * TP + 16 + NW * 64 + 2 * WPAD + 62 * 16 + 64;
-  const int pre = N_MEL * PRENET + MEL_GL + 2 * PRENET + PRENET;
+  const int common = pb * (PRENET + EMB + ATT_RNN + DEC_RNN + 16) + 4 + 32 + 16 * pb;
+  const int attn = TP * 64 + 2 * TP * 16 + 2 * TP + 16 + NW * 64 + 2 * WPAD + 62 * 16 + 64 + TP + 16 + 8 * PT * 4;
+  const int pre = N_MEL * PRENET + MEL_GL + 2 * PRENET + PRENET + 6 * PT * 4;
   return common + (attn > pre ? attn : pre);
 }
+
+// Developer build (-DXDTTS_PERSIST_PROFILE): thread 0 of every workgroup accumulates the 100 MHz
+// wall clock between phase markers into g.prof[workgroup][16] (see tools/persist_profile.py).
+#ifdef XDTTS_PERSIST_PROFILE
+#define PROF_MARK(i)                                       \
+  do {                                                     \
+    if (tid == 0) {                                        \
+      const u64 now_ = wall_clock64();                     \
+      s_prof[i] += now_ - prof_last;                       \
+      prof_last = now_;                                    \
+    }                                                      \
+  } while (0)
+#else
+#define PROF_MARK(i) do { } while (0)
+#endif
 
 struct PersistWeights {
   const float4 *att_w, *dec_w, *q_w, *proj_w;
@@ -140,7 +158,9 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
   float *s_hdec = s_hatt + PB * ATT_RNN; // [PB][1024]
   float *s_g = s_hdec + PB * DEC_RNN;    // [PB][16] gate pre-activations of this workgroup's rows
   int *s_act = reinterpret_cast<int *>(s_g + PB * 16);  // [4]
-  float *role = s_g + PB * 16 + 4;
+  float *s_bias = s_g + PB * 16 + 4;    // [2][16] b_ih + b_hh of this workgroup's attention / decoder rows
+  float *s_cell = s_bias + 32;           // [4][4 PB] att_c, dec_c, h_att, h_dec of the (chunk, unit) cell threads
+  float *role = s_cell + 16 * PB;
   // attention role
   float *s_mem = role;                   // [TP][64]  this workgroup's columns of the encoder memory
   float *s_pm = s_mem + TP * 64;         // [TP][16]  processed_memory, own dims
@@ -152,16 +172,19 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
   float *s_wpad = s_part + NW * 64;      // [2][WPAD]
   float *s_G = s_wpad + 2 * WPAD;        // [62][16]  fused location filter, own dims
   float *s_cown = s_G + 62 * 16;         // [64]      own context columns
+  float *s_e = s_cown + 64;              // [TP]      masked energies
+  float *s_vv = s_e + TP;                // [16]      v, own dims
+  float *s_qw = s_vv + 16;               // [8][PT] float4: query rows 16 rk + wave (+8), 4 x 16 B per lane each
   // projection + prenet role
   float *s_W0 = role;                    // [80][256]
   float *s_mel = s_W0 + N_MEL * PRENET;  // [96]
   float *s_l1 = s_mel + MEL_GL;          // [2][256]
   float *s_p1 = s_l1 + 2 * PRENET;       // [256]
+  float *s_pw = s_p1 + PRENET;           // [6][PT] float4: row rk + 16 wave of [W_p ; w_gate] (waves 0..5)
 
   // ---- resident weights ----------------------------------------------------------------------
   // packed [unit][gate] order: row 16c + r is unit 4c + r/4, gate r%4; wave w owns r = w and w + 8
   float4 wa[2][ATT_COLS / 256], wd[2][DEC_COLS / 256];
-  float bias_a[2], bias_d[2];
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
     const int row = 16 * c + wave + NW * r;
@@ -169,8 +192,10 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
     for (int k = 0; k < ATT_COLS / 256; ++k) wa[r][k] = ld_stream(w.att_w + (size_t)row * (ATT_COLS / 4) + lane + 64 * k);
 #pragma unroll
     for (int k = 0; k < DEC_COLS / 256; ++k) wd[r][k] = ld_stream(w.dec_w + (size_t)row * (DEC_COLS / 4) + lane + 64 * k);
-    bias_a[r] = w.att_b[row];
-    bias_d[r] = w.dec_b[row];
+    if (lane == 0) {
+      s_bias[wave + NW * r] = w.att_b[row];
+      s_bias[16 + wave + NW * r] = w.dec_b[row];
+    }
   }
   const bool attn = c < ATTN_CU * PB, pre = !attn && c < (ATTN_CU + PRE_CU) * PB;
   const int rb = attn ? c / ATTN_CU : (pre ? (c - ATTN_CU * PB) / PRE_CU : 0);  // the role's chunk
@@ -194,12 +219,11 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
   }
   const int cb = tid >> 2, cu = tid & 3;  // cell-update threads: tid < 4 PB -> (chunk, unit)
   const bool cell = tid < 4 * PB;
-  float att_c = 0.f, dec_c = 0.f, ha_last = 0.f, hd_last = 0.f;
   if (cell) {
-    att_c = d.att_c[cb * ATT_RNN + 4 * c + cu];
-    dec_c = d.dec_c[cb * DEC_RNN + 4 * c + cu];
-    ha_last = d.att_h[0][cb * ATT_RNN + 4 * c + cu];
-    hd_last = d.dec_h[0][cb * DEC_RNN + 4 * c + cu];
+    s_cell[tid] = d.att_c[cb * ATT_RNN + 4 * c + cu];
+    s_cell[4 * PB + tid] = d.dec_c[cb * DEC_RNN + 4 * c + cu];
+    s_cell[8 * PB + tid] = d.att_h[0][cb * ATT_RNN + 4 * c + cu];
+    s_cell[12 * PB + tid] = d.dec_h[0][cb * DEC_RNN + 4 * c + cu];
   }
   int nvalid = 0, nf_r = 0;
   if (attn) {
@@ -217,10 +241,21 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
     }
     for (int i = tid; i < 62 * 16; i += PT) s_G[i] = w.loc_fused[(size_t)(i >> 4) * ATT_DIM + 16 * rk + (i & 15)];
     if (tid < 64) s_cown[tid] = d.ctx[rb * EMB + 64 * rk + tid];
+    if (tid < 16) s_vv[tid] = w.v_w[16 * rk + tid];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<float4 *>(s_qw + 4 * ((4 * r + j) * PT + tid)) = w.q_w[(unsigned)((16 * rk + wave + NW * r) * (ATT_RNN / 4) + lane + 64 * j)];
     nvalid = d.n_valid[rb];
   }
   if (pre) {
     for (int i = tid; i < N_MEL * PRENET; i += PT) s_W0[i] = w.pre0T[i];
+    if (prow_ok) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+        *reinterpret_cast<float4 *>(s_pw + 4 * (j * PT + tid)) = w.proj_w[(unsigned)(prow * (PROJ_IN / 4) + lane + 64 * j)];
+    }
     nf_r = d.nframes[rb];
   }
   const uint32_t item = d.item_base + (uint32_t)rb;
@@ -240,7 +275,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       }
       aacc[b][0] = a0;
       aacc[b][1] = a1;
-      __builtin_amdgcn_sched_barrier(0);
+      chunk_fence();
     }
   };
   auto dec_bulk_h = [&](unsigned L4) {  // decoder LSTM, columns h_dec(s-1)
@@ -255,7 +290,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       }
       dacc[b][0] = a0;
       dacc[b][1] = a1;
-      __builtin_amdgcn_sched_barrier(0);
+      chunk_fence();
     }
   };
   // location features of the NEXT step for this workgroup's 16 dims, from s_aw / s_awc:
@@ -302,6 +337,12 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
   dec_bulk_h(L4);
   if (attn) location(tid);
 
+#ifdef XDTTS_PERSIST_PROFILE
+  __shared__ u64 s_prof[16];
+  if (tid < 16) s_prof[tid] = 0;
+  u64 prof_last = wall_clock64();
+  __syncthreads();
+#endif
   int s = step0;
   const int s_stop = step0 + nsteps;
   for (; s < s_stop; ++s) {
@@ -318,6 +359,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
     const bool prow_ok = pre && wave < 6 && prow <= N_MEL;
     const int p = s & 1;
     const unsigned want = (unsigned)(s + 1);
+    PROF_MARK(0);  // loop overhead / previous P6 tail
     // ---- P1: x(s) and the chunks' active bits ------------------------------------------------
     {
       const int b0 = tid >> 8, i = tid & 255;  // chunks b0 and b0 + 2
@@ -339,6 +381,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       act[b] = s_act[b] != 0;
       any = any || act[b];
     }
+    PROF_MARK(1);  // wait x
     if (!any) break;  // every chunk has stopped (or the exchange failed): the launch ends by itself
     const bool act_r = s_act[rb] != 0;
     // attention LSTM: close the rows with the x columns
@@ -349,30 +392,23 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
         const float a0 = wave_sum(dot4(wa[0][0], v, aacc[b][0]));
         const float a1 = wave_sum(dot4(wa[1][0], v, aacc[b][1]));
         if (lane == 0) {
-          s_g[b * 16 + wave] = a0 + bias_a[0];
-          s_g[b * 16 + wave + NW] = a1 + bias_a[1];
+          s_g[b * 16 + wave] = a0 + s_bias[wave];
+          s_g[b * 16 + wave + NW] = a1 + s_bias[wave + NW];
         }
+        chunk_fence();
       }
     __syncthreads();
     if (cell && s_act[cb]) {
       const float *gp = s_g + cb * 16 + 4 * cu;
       const float ig = sigmoidf_(gp[0]), fg = sigmoidf_(gp[1]), gg = tanhf(gp[2]), og = sigmoidf_(gp[3]);
-      att_c = fmaf(fg, att_c, ig * gg);
-      ha_last = og * tanhf(att_c);
-      publish(g.hatt + (unsigned)((p * PB + cb) * ATT_RNN + 4 * c + cu), want, ha_last);
+      const float cn = fmaf(fg, s_cell[tid], ig * gg), hn = og * tanhf(cn);
+      publish(g.hatt + (unsigned)((p * PB + cb) * ATT_RNN + 4 * c + cu), want, hn);
+      s_cell[tid] = cn;
+      s_cell[8 * PB + tid] = hn;
     }
+    PROF_MARK(2);  // att tail + cell + publish
     __builtin_amdgcn_sched_barrier(0);
     // ---- P2: h_att(s) ----------------------------------------------------------------------------
-    float4 sp[8];  // attention: query rows 16 rk + wave (+8); projection: row rk + 16 wave of [W_p ; w_gate]
-    float vv[4];
-    if (attn && act_r) {
-#pragma unroll
-      for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) sp[4 * r + j] = w.q_w[(unsigned)((16 * rk + wave + NW * r) * (ATT_RNN / 4) + lane + 64 * j)];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) vv[i] = w.v_w[16 * rk + 4 * (tid & 3) + i];
-    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       float v[PB];
@@ -383,14 +419,15 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
         if (act[b]) s_hatt[b * ATT_RNN + tid + PT * h] = v[b];
     }
     __syncthreads();
+    PROF_MARK(3);  // wait h_att
     if (attn && act_r) {
       // query rows 16 rk + wave (+8), then this workgroup's share of the energies (mod.rs:304, D3)
       float q0 = 0.f, q1 = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float4 v = lds4(s_hatt + rb * ATT_RNN + 256 * j + L4);
-        q0 = dot4(sp[j], v, q0);
-        q1 = dot4(sp[4 + j], v, q1);
+        q0 = dot4(lds4(s_qw + 4 * (j * PT + TID)), v, q0);
+        q1 = dot4(lds4(s_qw + 4 * ((4 + j) * PT + TID)), v, q1);
       }
       q0 = wave_sum(q0);
       q1 = wave_sum(q1);
@@ -400,11 +437,11 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       }
       __syncthreads();
       const int t = tid >> 2, dq = 4 * (tid & 3);
-      const float4 q4 = lds4(s_q + dq), l4 = lds4(s_loc + 4 * TID), p4 = lds4(s_pm + 4 * TID);
-      float e = vv[0] * tanhf(q4.x + l4.x + p4.x);
-      e = fmaf(vv[1], tanhf(q4.y + l4.y + p4.y), e);
-      e = fmaf(vv[2], tanhf(q4.z + l4.z + p4.z), e);
-      e = fmaf(vv[3], tanhf(q4.w + l4.w + p4.w), e);
+      const float4 q4 = lds4(s_q + dq), l4 = lds4(s_loc + 4 * TID), p4 = lds4(s_pm + 4 * TID), v4 = lds4(s_vv + dq);
+      float e = v4.x * tanhf(q4.x + l4.x + p4.x);
+      e = fmaf(v4.y, tanhf(q4.y + l4.y + p4.y), e);
+      e = fmaf(v4.z, tanhf(q4.z + l4.z + p4.z), e);
+      e = fmaf(v4.w, tanhf(q4.w + l4.w + p4.w), e);
       e += dpp_move<0xB1, 0xf>(0.f, e);  // quad_perm:[1,0,3,2]
       e += dpp_move<0x4E, 0xf>(0.f, e);  // quad_perm:[2,3,0,1]
       if ((tid & 3) == 0 && t < T) publish(g.ep + (unsigned)(((p * PB + rb) * ATTN_CU + rk) * EP_LD + t), want, e);
@@ -422,46 +459,47 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
         }
         dacc[b][0] = a0;
         dacc[b][1] = a1;
-        __builtin_amdgcn_sched_barrier(0);
+        chunk_fence();
       }
+    PROF_MARK(4);  // q + energies (attention) + dec bulk
     __builtin_amdgcn_sched_barrier(0);
     // ---- P3 (attention role): energies of all 8 slices -> softmax -> own context columns ----------
     if (attn && act_r) {
-      if (wave == 0) {
-        const int t0 = lane, t1 = lane + 64;
-        const unsigned eb = (unsigned)((p * PB + rb) * ATTN_CU * EP_LD);
-        bool n0[ATTN_CU], n1[ATTN_CU];
-#pragma unroll
-        for (int k = 0; k < ATTN_CU; ++k) {
-          n0[k] = t0 < T;
-          n1[k] = t1 < T;
-        }
-        float v0[ATTN_CU], v1[ATTN_CU];
-        unsigned tg[ATTN_CU];
-        gather<ATTN_CU>(g.ep, eb + t0, EP_LD, want, n0, v0, tg, g.err);
-        gather<ATTN_CU>(g.ep, eb + t1, EP_LD, want, n1, v1, tg, g.err);
-        float e0 = 0.f, e1 = 0.f;
-#pragma unroll
-        for (int k = 0; k < ATTN_CU; ++k) {
-          e0 += v0[k];
-          e1 += v1[k];
-        }
-        e0 = t0 < T && t0 < nvalid ? e0 : -INFINITY;  // mask, mod.rs:219-220
-        e1 = t1 < T && t1 < nvalid ? e1 : -INFINITY;
+      {
+        // all threads poll: thread -> time step tid/4, slices 2j and 2j+1 (j = tid%4); quad sum
+        const int t = tid >> 2, j = tid & 3;
+        const bool need[2] = {t < T, t < T};
+        float v[2];
+        unsigned tg[2];
+        gather<2>(g.ep, (unsigned)(((p * PB + rb) * ATTN_CU + 2 * j) * EP_LD + t), EP_LD, want, need, v, tg, g.err);
+        float e = v[0] + v[1];
+        e += dpp_move<0xB1, 0xf>(0.f, e);  // quad_perm:[1,0,3,2]
+        e += dpp_move<0x4E, 0xf>(0.f, e);  // quad_perm:[2,3,0,1]
+        if (j == 0) s_e[t] = (t < T && t < nvalid) ? e : -INFINITY;  // mask, mod.rs:219-220
+      }
+      __syncthreads();
+      {
+        // every wave recomputes the softmax in registers (lane <-> steps lane, lane + 64), so the
+        // context partials need no second LDS round trip: weights come by readlane
+        const float e0 = s_e[lane], e1 = s_e[lane + 64];
         const float m = wave_max(fmaxf(e0, e1));
         const float x0 = expf(e0 - m), x1 = expf(e1 - m);
         const float sum = wave_sum(x0 + x1);
         const float a0 = x0 / sum, a1 = x1 / sum;
-        s_aw[t0] = a0;
-        s_awc[t0] += a0;
-        s_aw[t1] = a1;
-        s_awc[t1] += a1;
-      }
-      __syncthreads();
-      {
-        float acc = 0.f;  // column tid & 63, time steps wave + 8 u
+        if (wave == 0) {
+          s_aw[lane] = a0;
+          s_awc[lane] += a0;
+          s_aw[lane + 64] = a1;
+          s_awc[lane + 64] += a1;
+        }
+        const int ws = __builtin_amdgcn_readfirstlane(wave);
+        float acc = 0.f;  // column lane, time steps wave + 8 u (rows t >= T of s_mem are zero)
 #pragma unroll
-        for (int u = 0; u < TP / NW; ++u) acc = fmaf(s_aw[TG + NW * u], s_mem[TID + NW * 64 * u], acc);  // rows t >= T are zero
+        for (int u = 0; u < TP / NW; ++u) {
+          const int src = __float_as_int(u < 8 ? a0 : a1);
+          const float wv = __int_as_float(__builtin_amdgcn_readlane(src, ws + NW * (u & 7)));
+          acc = fmaf(wv, s_mem[TID + NW * 64 * u], acc);
+        }
         s_part[TID] = acc;
       }
       __syncthreads();
@@ -473,6 +511,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
         publish(g.ctx + (unsigned)((p * PB + rb) * EMB + 64 * rk + tid), want, v);
       }
     }
+    PROF_MARK(5);  // attention: wait e_part + softmax + ctx
     __builtin_amdgcn_sched_barrier(0);
     // ---- P4: ctx(s) -> decoder LSTM ------------------------------------------------------------
     {
@@ -484,6 +523,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
         if (act[b]) s_ctx[b * EMB + tid] = v[b];
     }
     __syncthreads();
+    PROF_MARK(6);  // wait ctx
 #pragma unroll
     for (int b = 0; b < PB; ++b)
       if (act[b]) {
@@ -497,27 +537,24 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
         a0 = wave_sum(a0);
         a1 = wave_sum(a1);
         if (lane == 0) {
-          s_g[b * 16 + wave] = a0 + bias_d[0];
-          s_g[b * 16 + wave + NW] = a1 + bias_d[1];
+          s_g[b * 16 + wave] = a0 + s_bias[16 + wave];
+          s_g[b * 16 + wave + NW] = a1 + s_bias[16 + wave + NW];
         }
+        chunk_fence();
       }
     __syncthreads();
     if (cell && s_act[cb]) {
       const float *gp = s_g + cb * 16 + 4 * cu;
       const float ig = sigmoidf_(gp[0]), fg = sigmoidf_(gp[1]), gg = tanhf(gp[2]), og = sigmoidf_(gp[3]);
-      dec_c = fmaf(fg, dec_c, ig * gg);
-      hd_last = og * tanhf(dec_c);
-      publish(g.hdec + (unsigned)((p * PB + cb) * DEC_RNN + 4 * c + cu), want, hd_last);
+      const float cn = fmaf(fg, s_cell[4 * PB + tid], ig * gg), hn = og * tanhf(cn);
+      publish(g.hdec + (unsigned)((p * PB + cb) * DEC_RNN + 4 * c + cu), want, hn);
+      s_cell[4 * PB + tid] = cn;
+      s_cell[12 * PB + tid] = hn;
     }
     att_bulk(L4);  // for step s+1: ctx(s), h_att(s)
+    PROF_MARK(7);  // dec tail + cell + publish + att bulk
     __builtin_amdgcn_sched_barrier(0);
     // ---- P5: h_dec(s) -> projection rows ---------------------------------------------------------
-    float pbias = 0.f;
-    if (prow_ok && act_r) {
-#pragma unroll
-      for (int j = 0; j < 6; ++j) sp[j] = w.proj_w[(unsigned)(prow * (PROJ_IN / 4) + lane + 64 * j)];
-      pbias = w.proj_b[prow];
-    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       float v[PB];
@@ -528,17 +565,19 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
         if (act[b]) s_hdec[b * DEC_RNN + tid + PT * h] = v[b];
     }
     __syncthreads();
+    PROF_MARK(8);  // wait h_dec
     if (prow_ok && act_r) {
       float a = 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) a = dot4(sp[j], lds4(s_hdec + rb * DEC_RNN + 256 * j + L4), a);
+      for (int j = 0; j < 4; ++j) a = dot4(lds4(s_pw + 4 * (j * PT + TID)), lds4(s_hdec + rb * DEC_RNN + 256 * j + L4), a);
 #pragma unroll
-      for (int j = 4; j < 6; ++j) a = dot4(sp[j], lds4(s_ctx + rb * EMB + 256 * (j - 4) + L4), a);
+      for (int j = 4; j < 6; ++j) a = dot4(lds4(s_pw + 4 * (j * PT + TID)), lds4(s_ctx + rb * EMB + 256 * (j - 4) + L4), a);
       a = wave_sum(a);
-      if (lane == 0) publish(g.mel + (unsigned)((p * PB + rb) * MEL_GL + prow), want, a + pbias);
+      if (lane == 0) publish(g.mel + (unsigned)((p * PB + rb) * MEL_GL + prow), want, a + w.proj_b[prow]);
     }
     dec_bulk_h(L4);  // for step s+1
     if (attn && act_r) location(tid);
+    PROF_MARK(9);  // projection rows + dec bulk + location
     __builtin_amdgcn_sched_barrier(0);
     // ---- P6 (projection + prenet role): frame s, stop rule, x(s+1) ------------------------------
     if (pre) {
@@ -601,15 +640,20 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
         publish(g.x + (unsigned)(((p ^ 1) * PB + rb) * PRENET + 16 * rk + wave + NW * lane), (want + 1u) | (nxt ? ACT_BIT : 0u),
                 lane ? xo[1] : xo[0]);
     }
+    PROF_MARK(10);  // prenet role: wait mel + frame store + prenet + publish x
     }
   }
+#ifdef XDTTS_PERSIST_PROFILE
+  __syncthreads();
+  if (g.prof && tid < 16) g.prof[c * 16 + tid] = s_prof[tid];
+#endif
 
   // ---- write the state back (a later launch may continue the sequence) -----------------------
   if (cell) {
-    d.att_c[cb * ATT_RNN + 4 * c + cu] = att_c;
-    d.dec_c[cb * DEC_RNN + 4 * c + cu] = dec_c;
-    d.att_h[0][cb * ATT_RNN + 4 * c + cu] = ha_last;
-    d.dec_h[0][cb * DEC_RNN + 4 * c + cu] = hd_last;
+    d.att_c[cb * ATT_RNN + 4 * c + cu] = s_cell[tid];
+    d.dec_c[cb * DEC_RNN + 4 * c + cu] = s_cell[4 * PB + tid];
+    d.att_h[0][cb * ATT_RNN + 4 * c + cu] = s_cell[8 * PB + tid];
+    d.dec_h[0][cb * DEC_RNN + 4 * c + cu] = s_cell[12 * PB + tid];
   }
   if (attn) {
     if (tid < 64) d.ctx[rb * EMB + 64 * rk + tid] = s_cown[tid];
@@ -686,8 +730,6 @@ void launch_decoder_persistent(const DecoderBufs &d, const DeviceWeights &w, con
   switch (d.B) {
     case 1: launch_pb<1>(d, g, pw, nsteps, s); break;
     case 2: launch_pb<2>(d, g, pw, nsteps, s); break;
-    case 3: launch_pb<3>(d, g, pw, nsteps, s); break;
-    case 4: launch_pb<4>(d, g, pw, nsteps, s); break;
     default: fail(XDTTS_ERR_BAD_ARG, "persistent decoder: %d chunks (max %d)", d.B, PERSIST_B_MAX);
   }
 }

@@ -43,12 +43,13 @@ size_t decoder_pmel_floats(int B);
 void launch_decoder_init(const DecoderBufs &d, const int *limits_dev, hipStream_t s);
 
 // ---- persistent weight-stationary decoder (decoder_persistent.hip), small lock-step batches ------
-constexpr int PERSIST_B_MAX = 4;    // chunks in lock-step
+constexpr int PERSIST_B_MAX = 2;    // chunks in lock-step (register file + LDS of a CU hold the slices and two chunks' state)
 constexpr int PERSIST_T_MAX = 128;  // encoder steps (the reference's window is 100, mod.rs:363)
 // Granule exchange buffers: 8-byte {tag, value} records, [2 step parities][B][n] each.
 struct PersistBufs {
   unsigned long long *x, *hatt, *ep, *ctx, *hdec, *mel;
   int *err;  // set by a workgroup whose bounded spin ran out
+  unsigned long long *prof;  // developer profile build only: [256][16] phase clocks, else null
 };
 size_t persist_granule_words(int B);
 PersistBufs persist_bufs(unsigned long long *base, int *err, int B);
