@@ -1,0 +1,91 @@
+"""GPU parity, decoder loop engines: the persistent weight-stationary kernel (B <= 2, T <= 128;
+csrc/decoder_persistent.hip) and the launch-per-stage path (csrc/decoder.hip) must both reproduce
+the CPU oracle -- same frame counts, frames within 1e-5 RMS -- and agree with each other.
+XDTTS_DECODER=launch is the library's developer switch that forces the second engine."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import rms, synth_ids
+from test_gpu_tacotron2_more import LOGIT_06, rigged_gate_blob
+
+pytestmark = pytest.mark.gpu
+
+
+class engine:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        self.old = os.environ.get("XDTTS_DECODER")
+        os.environ["XDTTS_DECODER"] = self.name
+
+    def __exit__(self, *a):
+        if self.old is None:
+            os.environ.pop("XDTTS_DECODER", None)
+        else:
+            os.environ["XDTTS_DECODER"] = self.old
+
+
+def encode(orc, blob, n, seed=1):
+    ids = np.zeros(100, dtype=np.int64)
+    ids[:n] = synth_ids(n, seed=seed)
+    return orc.encoder(blob, ids)
+
+
+@pytest.mark.parametrize("mode", ["persistent", "launch"])
+def test_both_engines_match_oracle_with_stop_rule(pkg, orc, blob, mode):
+    mem, pm = encode(orc, blob, 33)
+    rig = rigged_gate_blob(orc, blob, mem, pm, 33, 21, 30)
+    rframes, rgates = orc.run_decoder(rig, mem, pm, 33, orc.default_opts(dropout_seed=21))
+    assert 1 <= len(rframes) < 60
+    with engine(mode):
+        m = pkg.Tacotron2.from_blob(rig)
+        for _ in range(2):  # second call: state and exchange buffers are re-initialised
+            frames, gates = m.decoder(mem, pm, 33, pkg.default_opts(dropout_seed=21))
+            assert frames.shape == rframes.shape
+            assert rms(frames, rframes) <= 1e-5 and np.abs(gates - rgates).max() <= 1e-5
+            assert gates[-1] > LOGIT_06 and np.all(gates[:-1] <= LOGIT_06)
+        m.close()
+
+
+def test_engines_agree_on_ragged_pair_with_gate(pkg, orc, blob):
+    """Two chunks in lock-step, each stopped by its own gate at a different step."""
+    lens = [41, 18]
+    mems = [encode(orc, blob, n, seed=5 + i) for i, n in enumerate(lens)]
+    rig = rigged_gate_blob(orc, blob, mems[0][0], mems[0][1], lens[0], 100, 25)
+    ids = [synth_ids(n, seed=5 + i) for i, n in enumerate(lens)]
+    o = pkg.default_opts(dropout_seed=100, max_steps=90)
+    out = {}
+    for mode in ("persistent", "launch"):
+        with engine(mode):
+            m = pkg.Tacotron2.from_blob(rig)
+            out[mode] = m.infer_batch(ids, opts=o)
+            m.close()
+    for a, b in zip(out["persistent"], out["launch"]):
+        assert a.shape == b.shape and rms(a, b) <= 1e-6
+    assert out["persistent"][0].shape[1] != out["persistent"][1].shape[1] or out["persistent"][0].shape[1] < 90
+
+
+@pytest.mark.parametrize("T,n_valid", [(7, 5), (64, 64), (100, 1), (128, 120), (130, 97)])
+def test_encoder_lengths_across_the_engine_boundary(pkg, model, orc, blob, T, n_valid):
+    """T <= 128 runs the persistent kernel, longer memories the launch path; both mask t >= n_valid."""
+    rng = np.random.Generator(np.random.PCG64(T))
+    mem = rng.standard_normal((T, 512)).astype(np.float32) * 0.5
+    pm = rng.standard_normal((T, 128)).astype(np.float32) * 0.5
+    ro = orc.default_opts(fixed_steps=24, dropout_seed=9)
+    rframes, rgates = orc.run_decoder(blob, mem, pm, n_valid, ro)
+    frames, gates = model.decoder(mem, pm, n_valid, pkg.default_opts(fixed_steps=24, dropout_seed=9))
+    assert frames.shape == rframes.shape == (24, 80)
+    assert rms(frames, rframes) <= 1e-5 and np.abs(gates - rgates).max() <= 1e-5
+
+
+def test_persistent_engine_long_sequence_and_dropout_off(pkg, model, orc, blob):
+    mem, pm = encode(orc, blob, 95)
+    for dm in (0, 1):
+        ro = orc.default_opts(fixed_steps=300, dropout_seed=4, dropout_mode=dm)
+        rframes, _ = orc.run_decoder(blob, mem, pm, 95, ro)
+        frames, _ = model.decoder(mem, pm, 95, pkg.default_opts(fixed_steps=300, dropout_seed=4, dropout_mode=dm))
+        assert frames.shape == rframes.shape
+        assert rms(frames, rframes) <= 1e-4  # north_star tolerance at full length

@@ -119,7 +119,7 @@ __device__ __forceinline__ unsigned opaque(unsigned v) {
 constexpr int persist_lds_floats(int pb) {
   const int common = pb * (PRENET + EMB + ATT_RNN + DEC_RNN + 16) + 4 + 32 + 16 * pb;
   const int attn = TP * 64 + 2 * TP * 16 + 2 * TP + 16 + NW * 64 + 2 * WPAD + 62 * 16 + 64 + TP + 16 + 8 * PT * 4;
-  const int pre = N_MEL * PRENET + MEL_GL + 2 * PRENET + PRENET + 6 * PT * 4;
+  const int pre = N_MEL * PRENET + MEL_GL + 2 * PRENET + 8 + 6 * PT * 4;
   return common + (attn > pre ? attn : pre);
 }
 
@@ -179,8 +179,8 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
   float *s_W0 = role;                    // [80][256]
   float *s_mel = s_W0 + N_MEL * PRENET;  // [96]
   float *s_l1 = s_mel + MEL_GL;          // [2][256]
-  float *s_p1 = s_l1 + 2 * PRENET;       // [256]
-  float *s_pw = s_p1 + PRENET;           // [6][PT] float4: row rk + 16 wave of [W_p ; w_gate] (waves 0..5)
+  float *s_pb = s_l1 + 2 * PRENET;           // [8] projection biases of this workgroup's rows (by wave)
+  float *s_pw = s_pb + 8;                // [6][PT] float4: row rk + 16 wave of [W_p ; w_gate] (waves 0..5)
 
   // ---- resident weights ----------------------------------------------------------------------
   // packed [unit][gate] order: row 16c + r is unit 4c + r/4, gate r%4; wave w owns r = w and w + 8
@@ -252,6 +252,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
   if (pre) {
     for (int i = tid; i < N_MEL * PRENET; i += PT) s_W0[i] = w.pre0T[i];
     if (prow_ok) {
+      if (lane == 0) s_pb[wave] = w.proj_b[prow];
 #pragma unroll
       for (int j = 0; j < 6; ++j)
         *reinterpret_cast<float4 *>(s_pw + 4 * (j * PT + tid)) = w.proj_w[(unsigned)(prow * (PROJ_IN / 4) + lane + 64 * j)];
@@ -409,14 +410,17 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
     PROF_MARK(2);  // att tail + cell + publish
     __builtin_amdgcn_sched_barrier(0);
     // ---- P2: h_att(s) ----------------------------------------------------------------------------
+    {
+      // both halves of every active chunk's vector in flight together: granule tid + 512 i, i = 2 b + half
+      bool need[2 * PB];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      float v[PB];
-      unsigned tg[PB];
-      gather<PB>(g.hatt, (unsigned)(p * PB * ATT_RNN + tid + PT * h), ATT_RNN, want, act, v, tg, g.err);
+      for (int i = 0; i < 2 * PB; ++i) need[i] = act[i >> 1];
+      float v[2 * PB];
+      unsigned tg[2 * PB];
+      gather<2 * PB>(g.hatt, (unsigned)(p * PB * ATT_RNN + tid), PT, want, need, v, tg, g.err);
 #pragma unroll
-      for (int b = 0; b < PB; ++b)
-        if (act[b]) s_hatt[b * ATT_RNN + tid + PT * h] = v[b];
+      for (int i = 0; i < 2 * PB; ++i)
+        if (need[i]) s_hatt[TID + PT * i] = v[i];
     }
     __syncthreads();
     PROF_MARK(3);  // wait h_att
@@ -555,14 +559,17 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
     PROF_MARK(7);  // dec tail + cell + publish + att bulk
     __builtin_amdgcn_sched_barrier(0);
     // ---- P5: h_dec(s) -> projection rows ---------------------------------------------------------
+    {
+      // both halves of every active chunk's vector in flight together: granule tid + 512 i, i = 2 b + half
+      bool need[2 * PB];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      float v[PB];
-      unsigned tg[PB];
-      gather<PB>(g.hdec, (unsigned)(p * PB * DEC_RNN + tid + PT * h), DEC_RNN, want, act, v, tg, g.err);
+      for (int i = 0; i < 2 * PB; ++i) need[i] = act[i >> 1];
+      float v[2 * PB];
+      unsigned tg[2 * PB];
+      gather<2 * PB>(g.hdec, (unsigned)(p * PB * DEC_RNN + tid), PT, want, need, v, tg, g.err);
 #pragma unroll
-      for (int b = 0; b < PB; ++b)
-        if (act[b]) s_hdec[b * DEC_RNN + tid + PT * h] = v[b];
+      for (int i = 0; i < 2 * PB; ++i)
+        if (need[i]) s_hdec[TID + PT * i] = v[i];
     }
     __syncthreads();
     PROF_MARK(8);  // wait h_dec
@@ -573,7 +580,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
 #pragma unroll
       for (int j = 4; j < 6; ++j) a = dot4(lds4(s_pw + 4 * (j * PT + TID)), lds4(s_ctx + rb * EMB + 256 * (j - 4) + L4), a);
       a = wave_sum(a);
-      if (lane == 0) publish(g.mel + (unsigned)((p * PB + rb) * MEL_GL + prow), want, a + w.proj_b[prow]);
+      if (lane == 0) publish(g.mel + (unsigned)((p * PB + rb) * MEL_GL + prow), want, a + s_pb[wave]);
     }
     dec_bulk_h(L4);  // for step s+1
     if (attn && act_r) location(tid);
@@ -587,6 +594,16 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       for (int r = 0; r < 2; ++r)
 #pragma unroll
         for (int k = 0; k < 4; ++k) w1r[r][k] = w.pre1T[(unsigned)((lane + 64 * k) * PRENET + 16 * rk + wave + NW * r)];
+      // the Bernoulli(0.5) masks of step s+1 do not depend on the data: hash them while the mel is in flight
+      unsigned drop1 = 0u, drop2 = 0u;
+      if (d.dropout_mode) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          drop1 |= (rng_u32(d.dropout_seed, 0x1000u + 2u * item, (uint32_t)(s + 1) * 256u + (uint32_t)(lane + 64 * k)) >> 31) << k;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+          drop2 |= (rng_u32(d.dropout_seed, 0x1001u + 2u * item, (uint32_t)(s + 1) * 256u + (uint32_t)(16 * rk + wave + NW * r)) >> 31) << r;
+      }
       if (act_r) {
         if (tid < N_MEL + 1) {
           const bool need[1] = {true};
@@ -617,23 +634,21 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
         for (int k = 0; k < N_MEL / 2; ++k) acc = fmaf(s_W0[HW + PRENET * k], s_mel[HM + k], acc);
         s_l1[TID] = acc;
         __syncthreads();
-        if (tid < PRENET) {
-          float v = fmaxf(s_l1[TID] + s_l1[PRENET + TID], 0.f);
-          if (d.dropout_mode)
-            v = (rng_u32(d.dropout_seed, 0x1000u + 2u * item, (uint32_t)(s + 1) * 256u + (uint32_t)tid) >> 31) ? 0.f : 2.f * v;
-          s_p1[tid] = v;
+        // every wave finishes layer 1 for the inputs its lanes consume (ReLU, dropout) -- no second
+        // LDS round trip -- and reduces its two layer-2 columns
+        float pk[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float v = fmaxf(s_l1[(L4 >> 2) + 64 * k] + s_l1[PRENET + (L4 >> 2) + 64 * k], 0.f);
+          pk[k] = (drop1 >> k) & 1u ? 0.f : (d.dropout_mode ? 2.f * v : v);
         }
-        __syncthreads();
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
           float a = 0.f;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) a = fmaf(w1r[r][k], s_p1[(L4 >> 2) + 64 * k], a);
+          for (int k = 0; k < 4; ++k) a = fmaf(w1r[r][k], pk[k], a);
           a = fmaxf(wave_sum(a), 0.f);
-          const int j = 16 * rk + wave + NW * r;
-          if (d.dropout_mode)
-            a = (rng_u32(d.dropout_seed, 0x1001u + 2u * item, (uint32_t)(s + 1) * 256u + (uint32_t)j) >> 31) ? 0.f : 2.f * a;
-          xo[r] = a;
+          xo[r] = (drop2 >> r) & 1u ? 0.f : (d.dropout_mode ? 2.f * a : a);
         }
       }
       if (lane < 2)
