@@ -44,14 +44,15 @@ def per_item_bytes(T):
 
 
 def pmc_traffic():
-    """HBM bytes per decoder step from the committed rocprofv3 PMC passes of this same command
-    (profiles/): counters cannot be read from inside the process, so the figure is the profiled one."""
+    """HBM bytes per decoder launch (= one utterance's whole frame loop) from the committed rocprofv3
+    PMC passes of this same command (profiles/): counters cannot be read from inside the process,
+    so the figure is the profiled one."""
     import glob
 
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
     if not files:
         return None
-    return json.load(open(files[-1])).get("decoder_step_traffic_bytes")
+    return json.load(open(files[-1])).get("decoder_launch_traffic_bytes")
 
 
 def synth_ids(n, seed=1):
@@ -171,9 +172,10 @@ def main():
     total_frames = frames * K * world
     value = total_frames / elapsed
 
-    # roofline of the dominant kernel group: one decoder step (HIP events around the loop on the
-    # library's stream, summed over the timed region).  Lock-step iteration s serves the chunks
-    # still active at s.
+    # roofline of the dominant kernel: the persistent decoder launch (k_decoder_persistent<2>, one per
+    # utterance, HIP events around it on the library's stream, summed over the timed region).  Its
+    # algorithmic bytes are SURVEY 8(d)'s per-step figure x the steps it executes: every decoder
+    # parameter once per step + per-chunk memory/state for the chunks still active at that step.
     steps_per_utt = dec_steps / K
     active = sum(min(s, int(steps_per_utt)) for s in chunk_steps)          # sum over steps of #active chunks
     bytes_per_utt = steps_per_utt * DECODER_PARAM_BYTES + active * per_item_bytes(T_ENC)
@@ -209,16 +211,19 @@ def main():
             "griffinlim_iterations": gl_ms / K,
         },
         "roofline": {
-            "kernel": "decoder step (k_prenet, k_lstm<ATT>, k_qenergy, k_softmax_ctx, k_lstm<DEC>: 5 dependent launches)",
+            "kernel": "k_decoder_persistent<2> (one launch per utterance = %d lock-step decoder steps; weights stay in registers, so HBM traffic is far below the algorithmic bytes and the bound in practice is the 6 state-exchange edges per step, DESIGN.md section 4)" % int(steps_per_utt),
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": pmc_traffic(),
-            "us_per_launch": step_us,
-            "algorithmic_bytes_per_launch": bytes_per_utt / steps_per_utt,
-            "launches_per_utterance": steps_per_utt,
+            "us_per_launch": dec_ms / K * 1e3,
+            "algorithmic_bytes_per_launch": bytes_per_utt,
+            "launches_per_utterance": 1,
+            "steps_per_launch": steps_per_utt,
+            "us_per_step": step_us,
+            "algorithmic_bytes_per_step": bytes_per_utt / steps_per_utt,
         },
     }
     if rank == 0:

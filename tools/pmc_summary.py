@@ -7,15 +7,16 @@ usage: pmc_summary.py FETCH.db WRITE.db OUT_PREFIX ROUND "<command that was prof
 Units and correction (MI355X_MICROARCH.md, HBM section): rocprofv3 reports KB per dispatch;
 on gfx950 FETCH_SIZE tallies the 128-B requests of wide coalesced streaming reads at 64 B, so
 corrected_fetch = 2 x FETCH_SIZE.  WRITE_SIZE is left uncorrected.  bench.py reads
-`decoder_step_traffic_bytes` from the newest JSON for its roofline.traffic field.
+`decoder_launch_traffic_bytes` from the newest JSON for its roofline.traffic field.
 """
 import json
 import re
 import sqlite3
 import sys
 
-STEP_KERNELS = ("k_prenet", "k_lstm<1792, 0>", "k_qenergy", "k_softmax_ctx", "k_lstm<2560, 1>")
-ALGORITHMIC_STEP_BYTES = 73132835.0  # DESIGN.md section 4: weights + per-step state, one chunk of 95 ids
+DECODER_KERNEL = "k_decoder_persistent<2>"   # one launch per utterance on the bench workload
+STEPS_PER_LAUNCH = 633                        # bench: chunks [95, 25] -> 633 lock-step iterations
+ALGORITHMIC_STEP_BYTES = 73132835.0  # DESIGN.md section 4: weights + per-step state, bench average
 
 
 def short(name):
@@ -44,23 +45,24 @@ def main(fdb, wdb, prefix, rnd, cmd):
              "%-64s %6s %14s %18s %14s" % ("kernel", "calls", "FETCH_SIZE_KB", "corrected_fetch_MB", "WRITE_SIZE_KB")]
     for k in sorted(f, key=lambda k: -f[k][0] * f[k][1]):
         lines.append("%-64s %6d %14.1f %18.3f %14.1f" % (k, f[k][0], f[k][1], 2 * f[k][1] * 1024 / 1e6, w.get(k, (0, 0.0))[1]))
-    missing = [k for k in STEP_KERNELS if k not in f]
-    if missing:
-        raise SystemExit("decoder-step kernels missing from the trace: %s" % missing)
-    fetch_kb = sum(f[k][1] for k in STEP_KERNELS)
-    write_kb = sum(w[k][1] for k in STEP_KERNELS)
+    if DECODER_KERNEL not in f:
+        raise SystemExit("%s missing from the trace: %s" % (DECODER_KERNEL, sorted(f)))
+    fetch_kb, write_kb = f[DECODER_KERNEL][1], w[DECODER_KERNEL][1]
     traffic = 2 * fetch_kb * 1024 + write_kb * 1024
-    lines += ["", "decoder step (%d kernels: %s): corrected fetch %.2f MB + write %.2f MB = %.2f MB per step; "
-              "algorithmic bytes per step %.2f MB -> traffic/algorithmic = %.3f" % (
-                  len(STEP_KERNELS), ", ".join(STEP_KERNELS), 2 * fetch_kb * 1024 / 1e6, write_kb * 1024 / 1e6, traffic / 1e6,
-                  ALGORITHMIC_STEP_BYTES / 1e6, traffic / ALGORITHMIC_STEP_BYTES)]
+    alg = ALGORITHMIC_STEP_BYTES * STEPS_PER_LAUNCH
+    lines += ["", "%s: corrected fetch %.2f MB + write %.2f MB = %.2f MB per launch (%d steps) = %.3f MB per step; "
+              "algorithmic bytes %.1f MB per launch (%.2f MB per step) -> traffic/algorithmic = %.4f: the LSTM weights "
+              "are read from HBM once per utterance, not once per step" % (
+                  DECODER_KERNEL, 2 * fetch_kb * 1024 / 1e6, write_kb * 1024 / 1e6, traffic / 1e6, STEPS_PER_LAUNCH,
+                  traffic / STEPS_PER_LAUNCH / 1e6, alg / 1e6, ALGORITHMIC_STEP_BYTES / 1e6, traffic / alg)]
     open(prefix + ".txt", "w").write("\n".join(lines) + "\n")
     json.dump({"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) on `%s`; FETCH_SIZE doubled per "
                          "MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B)" % cmd,
-               "decoder_step_kernels": list(STEP_KERNELS),
-               "decoder_step_traffic_bytes": round(traffic),
-               "decoder_step_fetch_kb_raw": round(fetch_kb, 1),
-               "decoder_step_write_kb_raw": round(write_kb, 1),
+               "decoder_kernel": DECODER_KERNEL,
+               "steps_per_launch": STEPS_PER_LAUNCH,
+               "decoder_launch_traffic_bytes": round(traffic),
+               "decoder_launch_fetch_kb_raw": round(fetch_kb, 1),
+               "decoder_launch_write_kb_raw": round(write_kb, 1),
                "round": int(rnd)}, open(prefix + ".json", "w"), indent=1)
     print("\n".join(lines))
 
