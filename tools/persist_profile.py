@@ -11,8 +11,12 @@ steps = 400
 path = "/tmp/persist_prof.txt"
 os.environ["XDTTS_PERSIST_PROFILE"] = path
 m = pkg.Tacotron2.synthetic()
+ragged = len(sys.argv) > 2 and sys.argv[2] == "ragged"   # second chunk stops after ~13 steps
 ids = [synth_ids(95, seed=1 + b) for b in range(B)]
 o = pkg.default_opts(fixed_steps=steps)
+if ragged:
+    ids = [synth_ids(60), synth_ids(2, seed=2)]
+    o = pkg.default_opts(fixed_frames_per_id=steps / 60.0)
 for _ in range(2):
     m.infer_batch(ids, opts=o)
 t = m.last_timings()

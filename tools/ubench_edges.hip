@@ -14,6 +14,9 @@
 typedef unsigned long long u64;
 constexpr int NCU = 256, NT = 1024;
 constexpr int ATT0 = 0, NATT = 8, PRE0 = 8, NPRE = 16;
+__device__ __forceinline__ void publish_local(u64 *slot, int step, float v) {  // stays in this XCD's L2
+  *reinterpret_cast<volatile u64 *>(slot) = ((u64)(unsigned)(step + 1) << 32) | (u64)__float_as_uint(v);
+}
 constexpr unsigned SPIN_LIMIT = 1u << 20;
 
 struct Gran {
@@ -28,8 +31,40 @@ __device__ __forceinline__ void publish(u64 *slot, int step, float v) {
   __hip_atomic_store(slot, ((u64)(unsigned)(step + 1) << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED,
                      __HIP_MEMORY_SCOPE_AGENT);
 }
+// Pipelined polling: DEPTH loads of the same granule in flight, issued ~STAGGER apart; the oldest is
+// checked while the younger ones are still travelling, so a landed value is seen within one
+// stagger interval instead of one full load round trip.
+template <int DEPTH>
+__device__ __forceinline__ float gather_pipe(const u64 *slot, int step, int *err) {
+  u64 v[DEPTH];
+  unsigned spins = 0;
+#pragma unroll
+  for (int i = 0; i < DEPTH; ++i) {
+    asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(v[i]) : "v"(slot) : "memory");
+    __builtin_amdgcn_s_sleep(2);
+  }
+  for (;;) {
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i) {
+      asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v[i]) : "n"(DEPTH - 1) : "memory");
+      const u64 x = v[i];
+      if ((unsigned)(x >> 32) == (unsigned)(step + 1)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return __uint_as_float((unsigned)x);
+      }
+      asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(v[i]) : "v"(slot) : "memory");
+      if (++spins > SPIN_LIMIT * 4u || ((spins & 1023) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        atomicExch(err, 1);
+        return 0.f;
+      }
+    }
+  }
+}
+
 template <int SLEEP>
 __device__ __forceinline__ float gather_t(const u64 *slot, int step, int *err) {
+  if constexpr (SLEEP >= 100) return gather_pipe<SLEEP - 98>(slot, step, err);
   unsigned spins = 0;
   for (;;) {
     const u64 v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -42,11 +77,37 @@ __device__ __forceinline__ float gather_t(const u64 *slot, int step, int *err) {
   }
 }
 
+struct alignas(16) U2 { u64 a, b; };
+// two adjacent granules with one 16-byte sc1 load; each granule is still checked by its own tag
+__device__ __forceinline__ float2 gather_pair(const u64 *slot, int step, int *err) {
+  unsigned spins = 0;
+  for (;;) {
+    U2 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(slot) : "memory");
+    if ((unsigned)(v.a >> 32) == (unsigned)(step + 1) && (unsigned)(v.b >> 32) == (unsigned)(step + 1))
+      return make_float2(__uint_as_float((unsigned)v.a), __uint_as_float((unsigned)v.b));
+    if (++spins > SPIN_LIMIT || ((spins & 255) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+      atomicExch(err, 1);
+      return make_float2(0.f, 0.f);
+    }
+  }
+}
+
 template <int SLEEP>
 __global__ __launch_bounds__(NT) void k_skeleton(Gran g, int nsteps, int sleep_compute) {
   const int c = blockIdx.x, tid = threadIdx.x;
   __shared__ float s_x[256], s_hatt[1024], s_ctx[512], s_hdec[1024], s_ep[8][128], s_mel[96];
-  const bool attn = c >= ATT0 && c < ATT0 + NATT, pre = c >= PRE0 && c < PRE0 + NPRE;
+  bool attn = c >= ATT0 && c < ATT0 + NATT, pre = c >= PRE0 && c < PRE0 + NPRE;
+  int ak = c - ATT0, pj = c - PRE0;
+  if (SLEEP == 8) {  // same-XCD groups under the observed block -> XCD b % 8 placement
+    attn = (c & 7) == 0 && c < 64;
+    ak = c >> 3;
+    pre = (c & 7) == 1 && c < 128;
+    pj = c >> 3;
+  }
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  if (tid == 0) g.sink[c * NT + 1] = (float)(xcc & 15);
   float bad = 0.f;
   for (int s = 0; s < nsteps; ++s) {
     const int p = s & 1;
@@ -59,15 +120,22 @@ __global__ __launch_bounds__(NT) void k_skeleton(Gran g, int nsteps, int sleep_c
     __syncthreads();
     if (tid < 4) publish(g.hatt + p * 1024 + 4 * c + tid, s, expect(s, 1, 4 * c + tid) + 0.f * s_x[tid]);
     // P2: h_att(s) -> everyone
-    {
+    if (SLEEP == 7) {
+      if (tid < 512) {
+        const float2 v = gather_pair(g.hatt + p * 1024 + 2 * tid, s, g.err);
+        bad += fabsf(v.x - expect(s, 1, 2 * tid)) + fabsf(v.y - expect(s, 1, 2 * tid + 1));
+        s_hatt[2 * tid] = v.x;
+        s_hatt[2 * tid + 1] = v.y;
+      }
+    } else {
       const float v = gather_t<SLEEP>(g.hatt + p * 1024 + tid, s, g.err);
       bad += fabsf(v - expect(s, 1, tid));
       s_hatt[tid] = v;
     }
     __syncthreads();
     if (attn) {
-      const int k = c - ATT0;
-      if (tid < 100) publish(g.ep + (p * 8 + k) * 128 + tid, s, expect(s, 2, k * 128 + tid) + 0.f * s_hatt[tid]);
+      const int k = ak;
+      if (tid < 100) { if (SLEEP == 8) publish_local(g.ep + (p * 8 + k) * 128 + tid, s, expect(s, 2, k * 128 + tid) + 0.f * s_hatt[tid]); else publish(g.ep + (p * 8 + k) * 128 + tid, s, expect(s, 2, k * 128 + tid) + 0.f * s_hatt[tid]); }
       // P3: e_part -> the 8 attention blocks (wave 0 and 1 poll 8 granules per lane)
       if (tid < 100) {
         float e = 0.f;
@@ -82,7 +150,14 @@ __global__ __launch_bounds__(NT) void k_skeleton(Gran g, int nsteps, int sleep_c
       if (tid < 64) publish(g.ctx + p * 512 + 64 * k + tid, s, expect(s, 3, 64 * k + tid) + 0.f * s_ep[0][tid]);
     }
     // P4: ctx(s) -> everyone
-    if (tid < 512) {
+    if (SLEEP == 7) {
+      if (tid < 256) {
+        const float2 v = gather_pair(g.ctx + p * 512 + 2 * tid, s, g.err);
+        bad += fabsf(v.x - expect(s, 3, 2 * tid)) + fabsf(v.y - expect(s, 3, 2 * tid + 1));
+        s_ctx[2 * tid] = v.x;
+        s_ctx[2 * tid + 1] = v.y;
+      }
+    } else if (tid < 512) {
       const float v = gather_t<SLEEP>(g.ctx + p * 512 + tid, s, g.err);
       bad += fabsf(v - expect(s, 3, tid));
       s_ctx[tid] = v;
@@ -90,15 +165,22 @@ __global__ __launch_bounds__(NT) void k_skeleton(Gran g, int nsteps, int sleep_c
     __syncthreads();
     if (tid < 4) publish(g.hdec + p * 1024 + 4 * c + tid, s, expect(s, 4, 4 * c + tid) + 0.f * s_ctx[tid]);
     // P5: h_dec(s) -> everyone
-    {
+    if (SLEEP == 7) {
+      if (tid < 512) {
+        const float2 v = gather_pair(g.hdec + p * 1024 + 2 * tid, s, g.err);
+        bad += fabsf(v.x - expect(s, 4, 2 * tid)) + fabsf(v.y - expect(s, 4, 2 * tid + 1));
+        s_hdec[2 * tid] = v.x;
+        s_hdec[2 * tid + 1] = v.y;
+      }
+    } else {
       const float v = gather_t<SLEEP>(g.hdec + p * 1024 + tid, s, g.err);
       bad += fabsf(v - expect(s, 4, tid));
       s_hdec[tid] = v;
     }
     __syncthreads();
     if (pre) {
-      const int j = c - PRE0;
-      if (tid < 6 && j + 16 * tid < 81) publish(g.mel + p * 96 + j + 16 * tid, s, expect(s, 5, j + 16 * tid) + 0.f * s_hdec[tid]);
+      const int j = pj;
+      if (tid < 6 && j + 16 * tid < 81) { if (SLEEP == 8) publish_local(g.mel + p * 96 + j + 16 * tid, s, expect(s, 5, j + 16 * tid) + 0.f * s_hdec[tid]); else publish(g.mel + p * 96 + j + 16 * tid, s, expect(s, 5, j + 16 * tid) + 0.f * s_hdec[tid]); }
       // P6: mel -> the 16 prenet blocks, which publish x(s+1)
       if (tid < 81) {
         const float v = gather_t<SLEEP>(g.mel + p * 96 + tid, s, g.err);
@@ -111,7 +193,7 @@ __global__ __launch_bounds__(NT) void k_skeleton(Gran g, int nsteps, int sleep_c
     for (int i = 0; i < sleep_compute; ++i) __builtin_amdgcn_s_sleep(8);
   }
   if (bad != 0.f) atomicExch(g.err, 2);
-  g.sink[c * NT + tid] = bad;
+  if (tid != 1) g.sink[c * NT + tid] = bad;
 }
 
 __global__ void k_seed(Gran g) {  // x(0)
@@ -146,15 +228,24 @@ int main(int argc, char **argv) {
     hipEventRecord(a, st);
     if (rep == 0) hipLaunchKernelGGL(k_skeleton<1>, dim3(NCU), dim3(NT), 0, st, g, nsteps, 0);
     if (rep == 1) hipLaunchKernelGGL(k_skeleton<0>, dim3(NCU), dim3(NT), 0, st, g, nsteps, 0);
-    if (rep == 2) hipLaunchKernelGGL(k_skeleton<4>, dim3(NCU), dim3(NT), 0, st, g, nsteps, 0);
-    if (rep == 3) hipLaunchKernelGGL(k_skeleton<1>, dim3(NCU), dim3(NT), 0, st, g, nsteps, 0);
+    if (rep == 2) hipLaunchKernelGGL(k_skeleton<7>, dim3(NCU), dim3(NT), 0, st, g, nsteps, 0);
+    if (rep == 3) hipLaunchKernelGGL(k_skeleton<8>, dim3(NCU), dim3(NT), 0, st, g, nsteps, 0);
     hipEventRecord(b, st);
     CK(hipStreamSynchronize(st));
     float ms;
     hipEventElapsedTime(&ms, a, b);
     int err = 0;
     CK(hipMemcpy(&err, g.err, 4, hipMemcpyDeviceToHost));
-    printf("rep %d (sleep 1,0,4,1): %d steps, %.3f ms, %.2f us per step (6 edges), err=%d\n", rep, nsteps, ms, ms * 1e3f / nsteps, err);
+    if (rep == 3) {
+      static float hs[NCU * NT];
+      CK(hipMemcpy(hs, g.sink, sizeof hs, hipMemcpyDeviceToHost));
+      int ok = 1;
+      for (int c = 0; c < NCU; ++c) ok &= ((int)hs[c * NT + 1] == (c & 7));
+      printf("XCC_ID == block %% 8 for every block: %s (block 0..9 ids:", ok ? "yes" : "NO");
+      for (int c = 0; c < 10; ++c) printf(" %d", (int)hs[c * NT + 1]);
+      printf(")\n");
+    }
+    printf("rep %d (sleep1, sleep0, 16-byte pair loads, same-XCD groups with plain stores): %d steps, %.3f ms, %.2f us per step (6 edges), err=%d\n", rep, nsteps, ms, ms * 1e3f / nsteps, err);
   }
   return 0;
 }

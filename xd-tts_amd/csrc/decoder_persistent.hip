@@ -138,6 +138,14 @@ constexpr int persist_lds_floats(int pb) {
 #define PROF_MARK(i) do { } while (0)
 #endif
 
+// Hardware exp2/rcp forms for the few transcendental chains that sit on the per-step critical path
+// (cell updates, energies, softmax).  v_exp_f32 / v_rcp_f32 are 1-ulp instructions; against libm's
+// expf/tanhf the results move by a few 1e-7 absolute, far inside the 1e-4 parity bar, and each cell
+// update loses ~120 dependent instructions.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + fast_exp(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(fast_exp(2.0f * x) + 1.0f); }
+
 struct PersistWeights {
   const float4 *att_w, *dec_w, *q_w, *proj_w;
   const float *att_b, *dec_b, *v_w, *loc_fused, *proj_b, *pre0T, *pre1T;
@@ -150,7 +158,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
   __shared__ __attribute__((aligned(16))) float smem[persist_lds_floats(PB)];
   const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int T = d.T;
-  const unsigned L4 = opaque(4u * (unsigned)lane), TID = opaque((unsigned)tid), TG = opaque((unsigned)wave);
+  const unsigned L4 = opaque(4u * (unsigned)lane);
   // ---- LDS: state vectors of all chunks, then the role's working set -------------------------
   float *s_x = smem;                     // [PB][256]
   float *s_ctx = s_x + PB * PRENET;      // [PB][512]
@@ -264,9 +272,10 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
 
   // ---- deferred pieces: everything that does not depend on the newest vector -----------------
   float aacc[PB][2], dacc[PB][2];
-  auto att_bulk = [&](unsigned L4) {  // attention LSTM, columns [ctx(s-1) ; h_att(s-1)]
+  auto att_bulk = [&](unsigned L4, bool all) {  // attention LSTM, columns [ctx(s-1) ; h_att(s-1)]
 #pragma unroll
     for (int b = 0; b < PB; ++b) {
+      if (!all && !s_act[b]) continue;  // a stopped chunk's state is frozen
       float a0 = 0.f, a1 = 0.f;
 #pragma unroll
       for (int k = 1; k < 7; ++k) {
@@ -279,9 +288,10 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       chunk_fence();
     }
   };
-  auto dec_bulk_h = [&](unsigned L4) {  // decoder LSTM, columns h_dec(s-1)
+  auto dec_bulk_h = [&](unsigned L4, bool all) {  // decoder LSTM, columns h_dec(s-1)
 #pragma unroll
     for (int b = 0; b < PB; ++b) {
+      if (!all && !s_act[b]) continue;
       float a0 = 0.f, a1 = 0.f;
 #pragma unroll
       for (int k = 6; k < 10; ++k) {
@@ -334,8 +344,8 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
     }
     __syncthreads();
   };
-  att_bulk(L4);
-  dec_bulk_h(L4);
+  att_bulk(L4, true);
+  dec_bulk_h(L4, true);
   if (attn) location(tid);
 
 #ifdef XDTTS_PERSIST_PROFILE
@@ -353,7 +363,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
     const int tid_it = tid + (int)opaque(0u);
     {
     const int tid = tid_it, lane = tid & 63, wave = tid >> 6;
-    const unsigned L4 = 4u * (unsigned)lane, TID = (unsigned)tid, TG = (unsigned)wave;
+    const unsigned L4 = 4u * (unsigned)lane, TID = (unsigned)tid;
     const int cb = tid >> 2, cu = tid & 3;
     const bool cell = tid < 4 * PB;
     const int prow = rk + 16 * wave;
@@ -396,13 +406,12 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
           s_g[b * 16 + wave] = a0 + s_bias[wave];
           s_g[b * 16 + wave + NW] = a1 + s_bias[wave + NW];
         }
-        chunk_fence();
       }
     __syncthreads();
     if (cell && s_act[cb]) {
       const float *gp = s_g + cb * 16 + 4 * cu;
-      const float ig = sigmoidf_(gp[0]), fg = sigmoidf_(gp[1]), gg = tanhf(gp[2]), og = sigmoidf_(gp[3]);
-      const float cn = fmaf(fg, s_cell[tid], ig * gg), hn = og * tanhf(cn);
+      const float ig = fast_sigmoid(gp[0]), fg = fast_sigmoid(gp[1]), gg = fast_tanh(gp[2]), og = fast_sigmoid(gp[3]);
+      const float cn = fmaf(fg, s_cell[tid], ig * gg), hn = og * fast_tanh(cn);
       publish(g.hatt + (unsigned)((p * PB + cb) * ATT_RNN + 4 * c + cu), want, hn);
       s_cell[tid] = cn;
       s_cell[8 * PB + tid] = hn;
@@ -442,10 +451,10 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       __syncthreads();
       const int t = tid >> 2, dq = 4 * (tid & 3);
       const float4 q4 = lds4(s_q + dq), l4 = lds4(s_loc + 4 * TID), p4 = lds4(s_pm + 4 * TID), v4 = lds4(s_vv + dq);
-      float e = v4.x * tanhf(q4.x + l4.x + p4.x);
-      e = fmaf(v4.y, tanhf(q4.y + l4.y + p4.y), e);
-      e = fmaf(v4.z, tanhf(q4.z + l4.z + p4.z), e);
-      e = fmaf(v4.w, tanhf(q4.w + l4.w + p4.w), e);
+      float e = v4.x * fast_tanh(q4.x + l4.x + p4.x);
+      e = fmaf(v4.y, fast_tanh(q4.y + l4.y + p4.y), e);
+      e = fmaf(v4.z, fast_tanh(q4.z + l4.z + p4.z), e);
+      e = fmaf(v4.w, fast_tanh(q4.w + l4.w + p4.w), e);
       e += dpp_move<0xB1, 0xf>(0.f, e);  // quad_perm:[1,0,3,2]
       e += dpp_move<0x4E, 0xf>(0.f, e);  // quad_perm:[2,3,0,1]
       if ((tid & 3) == 0 && t < T) publish(g.ep + (unsigned)(((p * PB + rb) * ATTN_CU + rk) * EP_LD + t), want, e);
@@ -487,9 +496,9 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
         // context partials need no second LDS round trip: weights come by readlane
         const float e0 = s_e[lane], e1 = s_e[lane + 64];
         const float m = wave_max(fmaxf(e0, e1));
-        const float x0 = expf(e0 - m), x1 = expf(e1 - m);
-        const float sum = wave_sum(x0 + x1);
-        const float a0 = x0 / sum, a1 = x1 / sum;
+        const float x0 = fast_exp(e0 - m), x1 = fast_exp(e1 - m);
+        const float rs = __builtin_amdgcn_rcpf(wave_sum(x0 + x1));
+        const float a0 = x0 * rs, a1 = x1 * rs;
         if (wave == 0) {
           s_aw[lane] = a0;
           s_awc[lane] += a0;
@@ -544,18 +553,17 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
           s_g[b * 16 + wave] = a0 + s_bias[16 + wave];
           s_g[b * 16 + wave + NW] = a1 + s_bias[16 + wave + NW];
         }
-        chunk_fence();
       }
     __syncthreads();
     if (cell && s_act[cb]) {
       const float *gp = s_g + cb * 16 + 4 * cu;
-      const float ig = sigmoidf_(gp[0]), fg = sigmoidf_(gp[1]), gg = tanhf(gp[2]), og = sigmoidf_(gp[3]);
-      const float cn = fmaf(fg, s_cell[4 * PB + tid], ig * gg), hn = og * tanhf(cn);
+      const float ig = fast_sigmoid(gp[0]), fg = fast_sigmoid(gp[1]), gg = fast_tanh(gp[2]), og = fast_sigmoid(gp[3]);
+      const float cn = fmaf(fg, s_cell[4 * PB + tid], ig * gg), hn = og * fast_tanh(cn);
       publish(g.hdec + (unsigned)((p * PB + cb) * DEC_RNN + 4 * c + cu), want, hn);
       s_cell[4 * PB + tid] = cn;
       s_cell[12 * PB + tid] = hn;
     }
-    att_bulk(L4);  // for step s+1: ctx(s), h_att(s)
+    att_bulk(L4, false);  // for step s+1: ctx(s), h_att(s)
     PROF_MARK(7);  // dec tail + cell + publish + att bulk
     __builtin_amdgcn_sched_barrier(0);
     // ---- P5: h_dec(s) -> projection rows ---------------------------------------------------------
@@ -582,7 +590,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       a = wave_sum(a);
       if (lane == 0) publish(g.mel + (unsigned)((p * PB + rb) * MEL_GL + prow), want, a + s_pb[wave]);
     }
-    dec_bulk_h(L4);  // for step s+1
+    dec_bulk_h(L4, false);  // for step s+1
     if (attn && act_r) location(tid);
     PROF_MARK(9);  // projection rows + dec bulk + location
     __builtin_amdgcn_sched_barrier(0);
