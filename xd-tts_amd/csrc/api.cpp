@@ -123,6 +123,14 @@ struct Events {
 
 using namespace xdtts;
 
+// The cooperative encoder BiLSTM and the persistent decoder need their whole grid co-resident, so
+// two of them from different handles must never be in flight together (each could hold CUs the
+// other waits for).  Every call that launches one holds this lock from enqueue to completion.
+static std::recursive_mutex &chip_mutex(int device) {
+  static std::recursive_mutex m[64];  // one per GPU of this process
+  return m[(unsigned)device % 64u];
+}
+
 // ================================================================================================
 // Tacotron2 handle
 // ================================================================================================
@@ -343,8 +351,7 @@ struct xdtts_tacotron2 {
     if (use_persistent(d)) {
       // one launch for the whole loop: the stop rule runs on the device and the kernel ends by itself.
       // Its grid must own the chip, so persistent launches of different handles never overlap.
-      static std::mutex chip;
-      std::lock_guard<std::mutex> lk(chip);
+      std::lock_guard<std::recursive_mutex> lk(chip_mutex(device));
       dec_exchange.alloc(persist_granule_words(d.B));
       PersistBufs g = persist_bufs(dec_exchange.p, dec_err.p, d.B);
 #ifdef XDTTS_PERSIST_PROFILE
@@ -471,6 +478,7 @@ struct xdtts_tacotron2 {
     ids.upload(ids_host, (size_t)B * T, stream);
     n_valid.upload(lens, B, stream);
     HIP_CHECK(hipStreamSynchronize(stream));  // ids_host may be a caller temporary
+    std::lock_guard<std::recursive_mutex> chip(chip_mutex(device));  // released after run_decoder's final sync
     run_encoder(B, T);
     HIP_CHECK(hipEventRecord(ev.e[1], stream));
     std::vector<int> lim(B);
@@ -895,6 +903,7 @@ xdtts_status xdtts_tacotron2_encoder(xdtts_tacotron2 *h, const int64_t *ids, int
     std::lock_guard<std::mutex> lk(h->mu);
     HIP_CHECK(hipSetDevice(h->device));
     h->ids.upload(ids, T, h->stream);
+    std::lock_guard<std::recursive_mutex> chip(chip_mutex(h->device));
     h->run_encoder(1, T);
     HIP_CHECK(hipMemcpyAsync(memory, h->memory.p, (size_t)T * EMB * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipMemcpyAsync(processed_memory, h->pmem.p, (size_t)T * ATT_DIM * sizeof(float), hipMemcpyDeviceToHost, h->stream));
