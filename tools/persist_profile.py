@@ -23,7 +23,10 @@ t = m.last_timings()
 print("B=%d: %.2f us/step" % (B, t["decoder_ms"] * 1e3 / steps))
 a = np.loadtxt(path)[:, :11] / 100.0 / steps  # 100 MHz clock -> us per step
 names = ["loop", "wait x", "att tail", "wait h_att", "q+energies/bulk", "softmax+ctx", "wait ctx", "dec tail+bulk", "wait h_dec", "proj/bulk/loc", "prenet"]
-roles = {"attention": slice(0, 8 * B), "proj+prenet": slice(8 * B, 24 * B), "plain": slice(24 * B, 256)}
+roles = {"attn c0": slice(0, 8), "pre c0": slice(8 * B, 8 * B + 16), "plain": slice(24 * B, 256)}
+if B > 1:
+    roles["attn c1"] = slice(8, 16)
+    roles["pre c1"] = slice(8 * B + 16, 8 * B + 32)
 print("%-18s" % "phase" + "".join("%14s" % r for r in roles))
 for i, n in enumerate(names):
     print("%-18s" % n + "".join("%14.2f" % a[sl, i].mean() for sl in roles.values()))

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
   float *s_hatt = s_ctx + PB * EMB;      // [PB][1024]
   float *s_hdec = s_hatt + PB * ATT_RNN; // [PB][1024]
   float *s_g = s_hdec + PB * DEC_RNN;    // [PB][16] gate pre-activations of this workgroup's rows
-  int *s_act = reinterpret_cast<int *>(s_g + PB * 16);  // [4]
+  int *s_act = reinterpret_cast<int *>(s_g + PB * 16);  // [2] active at this step, [2..3] alive: not yet seen inactive
   float *s_bias = s_g + PB * 16 + 4;    // [2][16] b_ih + b_hh of this workgroup's attention / decoder rows
   float *s_cell = s_bias + 32;           // [4][4 PB] att_c, dec_c, h_att, h_dec of the (chunk, unit) cell threads
   float *role = s_cell + 16 * PB;
@@ -216,6 +216,10 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
 
   // ---- state of the sequence so far (zeros at step 0; a previous launch's write-back otherwise) ----
   const int step0 = d.ctl[0];
+  if (tid < PB) {
+    s_act[tid] = 0;
+    s_act[2 + tid] = step0 < d.nframes[tid];  // a stopped chunk is never polled again
+  }
 #pragma unroll
   for (int b = 0; b < PB; ++b) {
 #pragma unroll
@@ -374,7 +378,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
     // ---- P1: x(s) and the chunks' active bits ------------------------------------------------
     {
       const int b0 = tid >> 8, i = tid & 255;  // chunks b0 and b0 + 2
-      const bool need[2] = {b0 < PB, b0 + 2 < PB};
+      const bool need[2] = {b0 < PB && s_act[2 + (b0 < PB ? b0 : 0)] != 0, false};  // (PB <= 2: chunk b0 only)
       float v[2];
       unsigned tg[2];
       gather<2>(g.x, (unsigned)((p * PB + b0) * PRENET + i), 2u * PRENET, want, need, v, tg, g.err);
@@ -392,6 +396,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       act[b] = s_act[b] != 0;
       any = any || act[b];
     }
+    if (tid < PB) s_act[2 + tid] = s_act[tid];  // read again only after the barriers of this step
     PROF_MARK(1);  // wait x
     if (!any) break;  // every chunk has stopped (or the exchange failed): the launch ends by itself
     const bool act_r = s_act[rb] != 0;
@@ -595,7 +600,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
     PROF_MARK(9);  // projection rows + dec bulk + location
     __builtin_amdgcn_sched_barrier(0);
     // ---- P6 (projection + prenet role): frame s, stop rule, x(s+1) ------------------------------
-    if (pre) {
+    if (pre && act_r) {  // a chunk's last x (active bit clear) is published at the step it stops
       bool nxt = false;
       float w1r[2][4];  // prenet layer 2: columns 16 rk + wave (+8), inputs lane + 64 k
 #pragma unroll
