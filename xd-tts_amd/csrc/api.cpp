@@ -354,6 +354,7 @@ struct xdtts_tacotron2 {
       std::lock_guard<std::recursive_mutex> lk(chip_mutex(device));
       dec_exchange.alloc(persist_granule_words(d.B));
       PersistBufs g = persist_bufs(dec_exchange.p, dec_err.p, d.B);
+      if (const char *lz = getenv("XDTTS_LAZY_POLL")) g.lazy = atoi(lz);  // developer tuning knob
 #ifdef XDTTS_PERSIST_PROFILE
       static DevBuf<unsigned long long> prof;
       prof.alloc(256 * 16);
