@@ -354,7 +354,8 @@ struct xdtts_tacotron2 {
       std::lock_guard<std::recursive_mutex> lk(chip_mutex(device));
       dec_exchange.alloc(persist_granule_words(d.B));
       PersistBufs g = persist_bufs(dec_exchange.p, dec_err.p, d.B);
-      if (const char *lz = getenv("XDTTS_LAZY_POLL")) g.lazy = atoi(lz);  // developer tuning knob
+      if (const char *lz = getenv("XDTTS_LAZY_POLL")) g.lazy = atoi(lz);  // developer tuning knobs
+      if (const char *fp = getenv("XDTTS_FIRST_POLL")) g.first = atoi(fp);
 #ifdef XDTTS_PERSIST_PROFILE
       static DevBuf<unsigned long long> prof;
       prof.alloc(256 * 16);

@@ -388,6 +388,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       const bool need[2] = {b0 < PB && s_act[2 + (b0 < PB ? b0 : 0)] != 0, false};  // (PB <= 2: chunk b0 only)
       float v[2];
       unsigned tg[2];
+      lazy_wait(g.first);
       gather<2>(g.x, (unsigned)((p * PB + b0) * PRENET + i), 2u * PRENET, want, need, v, tg, g.err);
 #pragma unroll
       for (int j = 0; j < 2; ++j)
@@ -438,7 +439,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       for (int i = 0; i < 2 * PB; ++i) need[i] = act[i >> 1];
       float v[2 * PB];
       unsigned tg[2 * PB];
-      if (!attn) lazy_wait(g.lazy);  // only the attention role needs h_att at once
+      lazy_wait(attn ? g.first : g.lazy);  // only the attention role needs h_att at once
       gather<2 * PB>(g.hatt, (unsigned)(p * PB * ATT_RNN + tid), PT, want, need, v, tg, g.err);
 #pragma unroll
       for (int i = 0; i < 2 * PB; ++i)
@@ -543,6 +544,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
     {
       float v[PB];
       unsigned tg[PB];
+      lazy_wait(g.first);
       gather<PB>(g.ctx, (unsigned)(p * PB * EMB + tid), EMB, want, act, v, tg, g.err);
 #pragma unroll
       for (int b = 0; b < PB; ++b)
@@ -587,7 +589,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       for (int i = 0; i < 2 * PB; ++i) need[i] = act[i >> 1];
       float v[2 * PB];
       unsigned tg[2 * PB];
-      if (!pre) lazy_wait(g.lazy);  // only the projection role needs h_dec at once
+      lazy_wait(pre ? g.first : g.lazy);  // only the projection role needs h_dec at once
       gather<2 * PB>(g.hdec, (unsigned)(p * PB * DEC_RNN + tid), PT, want, need, v, tg, g.err);
 #pragma unroll
       for (int i = 0; i < 2 * PB; ++i)
@@ -730,6 +732,7 @@ PersistBufs persist_bufs(unsigned long long *base, int *err, int B) {
   g.mel = g.hdec + (size_t)2 * B * DEC_RNN;
   g.err = err;
   g.lazy = PERSIST_LAZY_DEFAULT;
+  g.first = 2;  // ~0.4 us: the first polls of a critical consumer cannot succeed earlier (measured: -0.3 us per step)
   return g;
 }
 

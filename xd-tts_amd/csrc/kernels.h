@@ -49,6 +49,7 @@ constexpr int PERSIST_T_MAX = 128;  // encoder steps (the reference's window is 
 struct PersistBufs {
   unsigned long long *x, *hatt, *ep, *ctx, *hdec, *mel;
   int *err;  // set by a workgroup whose bounded spin ran out
+  int first;  // delay before a critical consumer's first poll, x 512 clocks (developer knob)
   int lazy;  // late-poll delay of the off-critical-path consumers, x 512 clocks
   unsigned long long *prof;  // developer profile build only: [256][16] phase clocks, else null
 };
