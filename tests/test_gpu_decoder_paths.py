@@ -68,6 +68,30 @@ def test_engines_agree_on_ragged_pair_with_gate(pkg, orc, blob):
     assert out["persistent"][0].shape[1] != out["persistent"][1].shape[1] or out["persistent"][0].shape[1] < 90
 
 
+def test_three_and_four_chunks_run_as_two_persistent_launches(pkg, orc, blob):
+    """B = 3..4: the persistent engine takes the chunks two at a time over views of the state arrays;
+    every chunk must still equal its own single-chunk oracle run (item index = dropout stream)."""
+    lens = [37, 12, 58, 23]
+    ids = [synth_ids(n, seed=11 + i) for i, n in enumerate(lens)]
+    for B in (3, 4):
+        o = pkg.default_opts(fixed_steps=40, dropout_seed=77, item_base=5)
+        m = pkg.Tacotron2.from_blob(blob)
+        out = m.infer_batch(ids[:B], opts=o)
+        with engine("launch"):
+            ref = m.infer_batch(ids[:B], opts=o)
+        m.close()
+        for a, b in zip(out, ref):
+            assert a.shape == b.shape == (80, 40) and rms(a, b) <= 1e-6
+        for b in range(B):
+            padded = np.zeros(100, dtype=np.int64)
+            padded[: lens[b]] = ids[b]
+            mem, pm = orc.encoder(blob, padded)
+            ro = orc.default_opts(fixed_steps=40, dropout_seed=77, item=5 + b)
+            rframes, _ = orc.run_decoder(blob, mem, pm, lens[b], ro)
+            post = orc.postnet(blob, rframes)
+            assert rms(out[b], post) <= 1e-5
+
+
 @pytest.mark.parametrize("T,n_valid", [(7, 5), (64, 64), (100, 1), (128, 120), (130, 97)])
 def test_encoder_lengths_across_the_engine_boundary(pkg, model, orc, blob, T, n_valid):
     """T <= 128 runs the persistent kernel, longer memories the launch path; both mask t >= n_valid."""
