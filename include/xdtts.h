@@ -188,6 +188,23 @@ int32_t xdtts_split_score(int64_t id);
 xdtts_status xdtts_find_splits(const int64_t *ids, size_t n, size_t max_size, size_t *out,
                                size_t cap, size_t *n_out);
 
+/* ---- output stage (host) -- src/lib.rs:25-30,125-176 -------------------------------------- */
+#define XDTTS_SAMPLE_RATE 22050 /* WAV_SPEC, src/lib.rs:25-30: mono, 22050 Hz, 16-bit signed PCM */
+/* `(*sample * i16::MAX as f32) as i16` -- src/lib.rs:153-155.  Rust's float -> int `as` truncates
+ * toward zero, saturates at the i16 range and maps NaN to 0. */
+xdtts_status xdtts_audio_to_i16(const float *audio, size_t n, int16_t *pcm);
+/* write_silence -- src/lib.rs:162-176: number of zero samples of an SSML break,
+ * round(sample_rate * seconds). */
+size_t xdtts_silence_samples(double seconds, uint32_t sample_rate);
+/* A complete RIFF/WAVE file with the reference's WAV_SPEC (what hound's WavWriter produces for the
+ * i16 writer of src/lib.rs:152-157): 44-byte PCM header + little-endian samples. */
+xdtts_status xdtts_wav_write(const char *path, const int16_t *pcm, size_t n, uint32_t sample_rate);
+/* ndarray_npy::write_npy(&path, &spectrogram) -- src/lib.rs:128-141: .npy version 1.0, '<f4',
+ * C order, shape (rows, cols). */
+xdtts_status xdtts_npy_write_f32(const char *path, const float *data, size_t rows, size_t cols);
+/* Real time factor as logged at src/lib.rs:145-151: compute seconds / (samples / 22050). */
+double xdtts_real_time_factor(double compute_seconds, size_t n_samples);
+
 /* ---- misc ------------------------------------------------------------------------------- */
 void xdtts_free(void *p);
 const char *xdtts_last_error(void);

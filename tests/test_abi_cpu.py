@@ -189,3 +189,61 @@ def test_cpp_host_mirror_sanity_on_gpu(pkg, tmp_path):
     rows, _x, cols = lines[1].split()[1:]
     assert int(rows) == 80 and int(cols) > 0
     assert int(lines[2].split()[1]) == 256 * (int(cols) - 1)
+
+
+# ---- output stage (src/lib.rs:25-30,125-176): host-side, runs without a GPU ------------------------
+
+def test_audio_to_i16_follows_rust_float_to_int_cast(pkg):
+    """`(sample * i16::MAX as f32) as i16`: truncation toward zero, saturation, NaN -> 0."""
+    x = np.array([0.0, 1.0, -1.0, 0.5, -0.5, 0.999985, 1.5, -1.5, 3.0e-5, -3.0e-5, 6.2e-5, np.nan, np.inf, -np.inf], np.float32)
+    got = pkg.audio_to_i16(x)
+    want = []
+    for v in x:
+        s = np.float32(v) * np.float32(32767.0)
+        if np.isnan(s):
+            want.append(0)
+        else:
+            want.append(int(max(-32768.0, min(32767.0, np.trunc(s)))))
+    assert got.dtype == np.int16 and got.tolist() == want
+    assert got[:5].tolist() == [0, 32767, -32767, 16383, -16383]  # truncation, not rounding
+
+
+def test_silence_length_of_a_break(pkg):
+    assert pkg.silence_samples(0.0) == 0
+    assert pkg.silence_samples(1.0) == 22050
+    assert pkg.silence_samples(0.25) == 5513   # 5512.5 rounds away from zero (f32::round)
+    assert pkg.silence_samples(0.00002) == 0
+    assert pkg.silence_samples(0.5, 16000) == 8000
+
+
+def test_wav_file_has_the_reference_spec(pkg, tmp_path):
+    import wave
+
+    rng = np.random.Generator(np.random.PCG64(5))
+    audio = rng.uniform(-1.2, 1.2, size=4321).astype(np.float32)
+    path = str(tmp_path / "out.wav")
+    pkg.write_wav(path, audio)
+    with wave.open(path, "rb") as w:
+        assert (w.getnchannels(), w.getframerate(), w.getsampwidth(), w.getnframes()) == (1, 22050, 2, 4321)
+        pcm = np.frombuffer(w.readframes(4321), dtype="<i2")
+    assert np.array_equal(pcm, pkg.audio_to_i16(audio))
+    assert os.path.getsize(path) == 44 + 2 * 4321
+    pkg.write_wav(str(tmp_path / "empty.wav"), np.zeros(0, np.float32))
+    assert os.path.getsize(str(tmp_path / "empty.wav")) == 44
+    with pytest.raises(pkg.XdttsError):
+        pkg.write_wav(str(tmp_path / "no_such_dir" / "x.wav"), audio)
+
+
+def test_mel_npy_dump_is_readable_by_numpy(pkg, tmp_path):
+    mel = np.arange(80 * 37, dtype=np.float32).reshape(80, 37) / 7.0
+    path = str(tmp_path / "mel.npy")
+    pkg.write_mel_npy(path, mel)
+    back = np.load(path)
+    assert back.dtype == np.float32 and back.shape == (80, 37) and np.array_equal(back, mel)
+    assert not np.isfortran(back)
+
+
+def test_real_time_factor_formula(pkg):
+    assert pkg.real_time_factor(1.0, 22050) == pytest.approx(1.0)
+    assert pkg.real_time_factor(0.0106, 204544) == pytest.approx(0.0106 / (204544 / 22050.0))
+    assert pkg.real_time_factor(1.0, 0) == 0.0

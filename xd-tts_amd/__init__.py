@@ -89,6 +89,11 @@ SYMBOLS = {
     "xdtts_unit_id": (C.c_int64, [C.c_char_p, _I32]),
     "xdtts_split_score": (_I32, [C.c_int64]),
     "xdtts_find_splits": (_I32, [_VP, _SZ, _SZ, _VP, _SZ, C.POINTER(_SZ)]),
+    "xdtts_audio_to_i16": (_I32, [_VP, _SZ, _VP]),
+    "xdtts_silence_samples": (_SZ, [C.c_double, _U32]),
+    "xdtts_wav_write": (_I32, [C.c_char_p, _VP, _SZ, _U32]),
+    "xdtts_npy_write_f32": (_I32, [C.c_char_p, _VP, _SZ, _SZ]),
+    "xdtts_real_time_factor": (C.c_double, [C.c_double, _SZ]),
     "xdtts_free": (None, [_VP]),
     "xdtts_last_error": (C.c_char_p, []),
     "xdtts_device_count": (_I32, []),
@@ -163,6 +168,38 @@ def units_to_ids(tokens, as_character=False):
     """The filter_map of src/tacotron2/mod.rs:403-406: units without an id are dropped."""
     out = [unit_id(t, as_character) for t in tokens]
     return np.array([i for i in out if i is not None], dtype=np.int64)
+
+
+SAMPLE_RATE = 22050  # WAV_SPEC, src/lib.rs:25-30
+
+
+def audio_to_i16(audio):
+    """`(sample * i16::MAX as f32) as i16` (src/lib.rs:153-155): truncating, saturating, NaN -> 0."""
+    a = np.ascontiguousarray(audio, dtype=np.float32).ravel()
+    out = np.empty(a.size, dtype=np.int16)
+    _check(lib.xdtts_audio_to_i16(_ptr(a), a.size, _ptr(out)))
+    return out
+
+
+def silence_samples(seconds, sample_rate=SAMPLE_RATE):
+    """write_silence (src/lib.rs:162-176)."""
+    return int(lib.xdtts_silence_samples(float(seconds), int(sample_rate)))
+
+
+def write_wav(path, audio, sample_rate=SAMPLE_RATE):
+    """f32 audio (or ready int16 PCM) -> mono 16-bit WAV with the reference's WAV_SPEC."""
+    pcm = np.ascontiguousarray(audio) if np.asarray(audio).dtype == np.int16 else audio_to_i16(audio)
+    _check(lib.xdtts_wav_write(os.fsencode(path), _ptr(pcm), pcm.size, int(sample_rate)))
+
+
+def write_mel_npy(path, mel):
+    """ndarray_npy::write_npy of the (80, F) spectrogram (src/lib.rs:128-141)."""
+    m = np.ascontiguousarray(mel, dtype=np.float32)
+    _check(lib.xdtts_npy_write_f32(os.fsencode(path), _ptr(m), m.shape[0], m.shape[1]))
+
+
+def real_time_factor(compute_seconds, n_samples):
+    return float(lib.xdtts_real_time_factor(float(compute_seconds), int(n_samples)))
 
 
 def find_splits(ids, max_size=100):

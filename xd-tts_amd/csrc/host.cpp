@@ -2,9 +2,12 @@
 // the Unit -> id table (generate_id_list, src/tacotron2/mod.rs:90-122), the id lookup
 // (best_match_for_unit, src/phonemes.rs:627-660) and the chunker (find_splits,
 // src/phonemes.rs:681-753 with split_score :663-671).  Integer/string work, microseconds; kept in
-// C++ because the reference's host language (Rust) has no toolchain in this image.
+// C++ because the reference's host language (Rust) has no toolchain in this image.  Also the
+// output stage of src/lib.rs (f32 -> i16, WAV, .npy dump, SSML-break silence, RTF).
 #include <algorithm>
 #include <cctype>
+#include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -171,6 +174,87 @@ xdtts_status xdtts_find_splits(const int64_t *ids, size_t n, size_t max_size, si
   }
   std::copy(merged.begin(), merged.end(), out);
   return XDTTS_OK;
+}
+
+// ---- output stage: src/lib.rs:25-30 (WAV_SPEC), :128-141 (.npy dump), :145-157 (RTF, i16), :162-176 ----
+
+// `(*sample * i16::MAX as f32) as i16`: Rust's `as` truncates toward zero, saturates, NaN -> 0.
+xdtts_status xdtts_audio_to_i16(const float *audio, size_t n, int16_t *pcm) {
+  if ((!audio || !pcm) && n) {
+    xdtts::set_last_error("audio_to_i16: null argument");
+    return XDTTS_ERR_BAD_ARG;
+  }
+  for (size_t i = 0; i < n; ++i) {
+    const float v = audio[i] * 32767.0f;
+    int16_t q;
+    if (v != v) q = 0;
+    else if (v >= 32767.0f) q = 32767;
+    else if (v <= -32768.0f) q = -32768;
+    else q = (int16_t)v;  // C++ float -> int conversion truncates toward zero, like Rust's in range
+    pcm[i] = q;
+  }
+  return XDTTS_OK;
+}
+
+size_t xdtts_silence_samples(double seconds, uint32_t sample_rate) {
+  // `(sample_rate as f32 * duration.as_secs_f32()).round() as u32`, src/lib.rs:166
+  const float v = std::round((float)sample_rate * (float)seconds);
+  return v > 0.f ? (size_t)v : 0;
+}
+
+static bool put(FILE *f, const void *p, size_t n) { return std::fwrite(p, 1, n, f) == n; }
+
+xdtts_status xdtts_wav_write(const char *path, const int16_t *pcm, size_t n, uint32_t sample_rate) {
+  if (!path || (!pcm && n) || n > 0x7fffffffu / 2) {
+    xdtts::set_last_error("wav_write: bad argument");
+    return XDTTS_ERR_BAD_ARG;
+  }
+  FILE *f = std::fopen(path, "wb");
+  if (!f) {
+    xdtts::set_last_error("wav_write: cannot open output file");
+    return XDTTS_ERR_IO;
+  }
+  const uint32_t data = (uint32_t)(n * 2), riff = 36 + data, fmt_len = 16, byte_rate = sample_rate * 2;
+  const uint16_t pcm_tag = 1, channels = 1, block = 2, bits = 16;
+  bool ok = put(f, "RIFF", 4) && put(f, &riff, 4) && put(f, "WAVEfmt ", 8) && put(f, &fmt_len, 4) && put(f, &pcm_tag, 2) &&
+            put(f, &channels, 2) && put(f, &sample_rate, 4) && put(f, &byte_rate, 4) && put(f, &block, 2) &&
+            put(f, &bits, 2) && put(f, "data", 4) && put(f, &data, 4) && (n == 0 || put(f, pcm, n * 2));
+  ok = (std::fclose(f) == 0) && ok;
+  if (!ok) {
+    xdtts::set_last_error("wav_write: short write");
+    return XDTTS_ERR_IO;
+  }
+  return XDTTS_OK;
+}
+
+xdtts_status xdtts_npy_write_f32(const char *path, const float *data, size_t rows, size_t cols) {
+  if (!path || (!data && rows * cols)) {
+    xdtts::set_last_error("npy_write: null argument");
+    return XDTTS_ERR_BAD_ARG;
+  }
+  char dict[128];
+  int len = std::snprintf(dict, sizeof dict, "{'descr': '<f4', 'fortran_order': False, 'shape': (%zu, %zu), }", rows, cols);
+  std::string hdr(dict, (size_t)len);
+  while ((10 + hdr.size() + 1) % 64 != 0) hdr.push_back(' ');  // magic(6) + version(2) + len(2) + dict + '\n'
+  hdr.push_back('\n');
+  const uint16_t hlen = (uint16_t)hdr.size();
+  FILE *f = std::fopen(path, "wb");
+  if (!f) {
+    xdtts::set_last_error("npy_write: cannot open output file");
+    return XDTTS_ERR_IO;
+  }
+  bool ok = put(f, "\x93NUMPY\x01\x00", 8) && put(f, &hlen, 2) && put(f, hdr.data(), hdr.size()) &&
+            (rows * cols == 0 || put(f, data, rows * cols * sizeof(float)));
+  ok = (std::fclose(f) == 0) && ok;
+  if (!ok) {
+    xdtts::set_last_error("npy_write: short write");
+    return XDTTS_ERR_IO;
+  }
+  return XDTTS_OK;
+}
+
+double xdtts_real_time_factor(double compute_seconds, size_t n_samples) {
+  return n_samples ? compute_seconds / ((double)n_samples / (double)XDTTS_SAMPLE_RATE) : 0.0;
 }
 
 }  // extern "C"
