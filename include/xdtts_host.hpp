@@ -136,4 +136,19 @@ inline GriffinLim create_griffin_lim(int device_id = 0) {
   return GriffinLim(mel_basis, 1024 - 256, 1.7f, 30, 0.99f, device_id);
 }
 
+// XdTts::infer's output stage (src/lib.rs:145-157): RTF, `(sample * i16::MAX as f32) as i16`,
+// mono 22050 Hz 16-bit WAV (WAV_SPEC, src/lib.rs:25-30).
+inline std::vector<int16_t> to_i16(const std::vector<float> &audio) {
+  std::vector<int16_t> pcm(audio.size());
+  check(xdtts_audio_to_i16(audio.data(), audio.size(), pcm.data()));
+  return pcm;
+}
+inline void write_wav(const std::string &path, const std::vector<float> &audio) {
+  const std::vector<int16_t> pcm = to_i16(audio);
+  check(xdtts_wav_write(path.c_str(), pcm.data(), pcm.size(), XDTTS_SAMPLE_RATE));
+}
+inline void write_npy(const std::string &path, const Array2 &mel) {  // src/lib.rs:128-141
+  check(xdtts_npy_write_f32(path.c_str(), mel.data.data(), mel.rows, mel.cols));
+}
+
 }  // namespace xdtts
