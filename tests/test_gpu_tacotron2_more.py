@@ -221,3 +221,25 @@ def test_batch_beyond_one_mfma_pass(pkg, model, orc, blob):
     for b in (0, 15, 16, 47, 63, 64, 69):
         ref = orc.infer_chunk(blob, ids_list[b], orc.default_opts(fixed_steps=steps[b], dropout_seed=23, item=b))
         assert rms(mels[b], ref) <= 1e-5, b
+
+
+def test_onnx_export_converts_and_loads(pkg, model, blob, tmp_path):
+    """ONNX graphs (synthetic, written the way torch.onnx.export names/packs the
+    parameters) -> tools/onnx_to_xdtw.py -> Tacotron2::load(dir) gives the same mel as the blob."""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(G), "..", "tools"))
+    import onnx_to_xdtw as conv
+    import onnx_writer
+
+    T = {name: blob[off : off + int(np.prod(shape))].reshape(shape) for name, shape, off in pkg.tensor_table()}
+    assert [n for n, _ in conv.tensor_table()] == [t[0] for t in pkg.tensor_table()]
+    onnx_writer.write_models(str(tmp_path), T, "named")
+    conv.write_container(str(tmp_path), conv.collect(str(tmp_path)))
+    ids = synth_ids(40)
+    o = pkg.default_opts(fixed_steps=30, dropout_seed=8)
+    want = model.infer(ids, opts=o)
+    m = pkg.Tacotron2.load(str(tmp_path))
+    got = m.infer(ids, opts=o)
+    m.close()
+    assert got.shape == want.shape == (80, 30) and np.array_equal(got, want)
