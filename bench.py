@@ -44,7 +44,7 @@ def per_item_bytes(T):
 
 
 def pmc_traffic():
-    """HBM bytes per decoder launch (= one utterance's whole frame loop) from the committed rocprofv3
+    """HBM bytes of the decoder launches of one utterance (its whole frame loop) from the committed rocprofv3
     PMC passes of this same command (profiles/): counters cannot be read from inside the process,
     so the figure is the profiled one."""
     import glob
@@ -172,10 +172,11 @@ def main():
     total_frames = frames * K * world
     value = total_frames / elapsed
 
-    # roofline of the dominant kernel: the persistent decoder launch (k_decoder_persistent<2>, one per
-    # utterance, HIP events around it on the library's stream, summed over the timed region).  Its
-    # algorithmic bytes are SURVEY 8(d)'s per-step figure x the steps it executes: every decoder
-    # parameter once per step + per-chunk memory/state for the chunks still active at that step.
+    # roofline of the dominant kernel: the persistent decoder (k_decoder_persistent<2> while both chunks
+    # run, continued by k_decoder_persistent<1> for the longer one; HIP events around the pair on the
+    # library's stream, summed over the timed region).  Its algorithmic bytes are SURVEY 8(d)'s
+    # per-step figure x the steps executed: every decoder parameter once per step + per-chunk
+    # memory/state for the chunks still active at that step.
     steps_per_utt = dec_steps / K
     active = sum(min(s, int(steps_per_utt)) for s in chunk_steps)          # sum over steps of #active chunks
     bytes_per_utt = steps_per_utt * DECODER_PARAM_BYTES + active * per_item_bytes(T_ENC)
@@ -211,7 +212,7 @@ def main():
             "griffinlim_iterations": gl_ms / K,
         },
         "roofline": {
-            "kernel": "k_decoder_persistent<2> (one launch per utterance = %d lock-step decoder steps; weights stay in registers, so HBM traffic is far below the algorithmic bytes and the bound in practice is the 6 state-exchange edges per step, DESIGN.md section 4)" % int(steps_per_utt),
+            "kernel": "k_decoder_persistent (<2> for the %d steps both chunks run, then <1>: %d lock-step decoder steps per utterance in two launches; weights stay in registers, so HBM traffic is far below the algorithmic bytes and the bound in practice is the 6 state-exchange edges per step, DESIGN.md section 4)" % (min(chunk_steps), int(steps_per_utt)),
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
@@ -220,7 +221,7 @@ def main():
             "traffic": pmc_traffic(),
             "us_per_launch": dec_ms / K * 1e3,
             "algorithmic_bytes_per_launch": bytes_per_utt,
-            "launches_per_utterance": 1,
+            "launches_per_utterance": 2,
             "steps_per_launch": steps_per_utt,
             "us_per_step": step_us,
             "algorithmic_bytes_per_step": bytes_per_utt / steps_per_utt,

@@ -14,7 +14,7 @@ import re
 import sqlite3
 import sys
 
-DECODER_KERNEL = "k_decoder_persistent<2>"   # one launch per utterance on the bench workload
+DECODER_KERNELS = ("k_decoder_persistent<2>", "k_decoder_persistent<1>")   # per utterance: one launch each on the bench workload
 STEPS_PER_LAUNCH = 633                        # bench: chunks [95, 25] -> 633 lock-step iterations
 ALGORITHMIC_STEP_BYTES = 73132835.0  # weights + per-step state, bench average
 
@@ -45,20 +45,23 @@ def main(fdb, wdb, prefix, rnd, cmd):
              "%-64s %6s %14s %18s %14s" % ("kernel", "calls", "FETCH_SIZE_KB", "corrected_fetch_MB", "WRITE_SIZE_KB")]
     for k in sorted(f, key=lambda k: -f[k][0] * f[k][1]):
         lines.append("%-64s %6d %14.1f %18.3f %14.1f" % (k, f[k][0], f[k][1], 2 * f[k][1] * 1024 / 1e6, w.get(k, (0, 0.0))[1]))
-    if DECODER_KERNEL not in f:
-        raise SystemExit("%s missing from the trace: %s" % (DECODER_KERNEL, sorted(f)))
-    fetch_kb, write_kb = f[DECODER_KERNEL][1], w[DECODER_KERNEL][1]
+    missing = [k for k in DECODER_KERNELS if k not in f]
+    if missing:
+        raise SystemExit("%s missing from the trace: %s" % (missing, sorted(f)))
+    fetch_kb = sum(f[k][1] for k in DECODER_KERNELS)
+    write_kb = sum(w[k][1] for k in DECODER_KERNELS)
+    DECODER_KERNEL = " + ".join(DECODER_KERNELS)
     traffic = 2 * fetch_kb * 1024 + write_kb * 1024
     alg = ALGORITHMIC_STEP_BYTES * STEPS_PER_LAUNCH
-    lines += ["", "%s: corrected fetch %.2f MB + write %.2f MB = %.2f MB per launch (%d steps) = %.3f MB per step; "
-              "algorithmic bytes %.1f MB per launch (%.2f MB per step) -> traffic/algorithmic = %.4f: the LSTM weights "
-              "are read from HBM once per utterance, not once per step" % (
+    lines += ["", "%s: corrected fetch %.2f MB + write %.2f MB = %.2f MB per utterance (%d steps) = %.3f MB per step; "
+              "algorithmic bytes %.1f MB per utterance (%.2f MB per step) -> traffic/algorithmic = %.4f: the LSTM weights "
+              "are read from HBM once per launch (twice per utterance), not once per step" % (
                   DECODER_KERNEL, 2 * fetch_kb * 1024 / 1e6, write_kb * 1024 / 1e6, traffic / 1e6, STEPS_PER_LAUNCH,
                   traffic / STEPS_PER_LAUNCH / 1e6, alg / 1e6, ALGORITHMIC_STEP_BYTES / 1e6, traffic / alg)]
     open(prefix + ".txt", "w").write("\n".join(lines) + "\n")
     json.dump({"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) on `%s`; FETCH_SIZE doubled per "
                          "MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B)" % cmd,
-               "decoder_kernel": DECODER_KERNEL,
+               "decoder_kernels": list(DECODER_KERNELS),
                "steps_per_launch": STEPS_PER_LAUNCH,
                "decoder_launch_traffic_bytes": round(traffic),
                "decoder_launch_fetch_kb_raw": round(fetch_kb, 1),

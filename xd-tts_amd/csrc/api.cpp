@@ -354,8 +354,10 @@ struct xdtts_tacotron2 {
       std::lock_guard<std::recursive_mutex> lk(chip_mutex(device));
       // Chunks are independent, so 3 or 4 of them run as two launches of <= 2 over views of the
       // state arrays (measured: 2 x 15.4 us per step-pair against 37 us per step of the launch path).
-      for (int b0 = 0; b0 < d.B; b0 += PERSIST_B_MAX) {
-        const int n = std::min(PERSIST_B_MAX, d.B - b0);
+      // A 2-chunk launch ends when its first chunk stops and the other is continued by the 1-chunk
+      // kernel (~1 us per step faster): the state crosses through the kernel's write-back, x(s)
+      // stays in the exchange.
+      auto view = [&](int b0, int n) {
         DecoderBufs v = d;
         v.B = n;
         v.memory += (size_t)b0 * d.T * EMB;
@@ -374,12 +376,19 @@ struct xdtts_tacotron2 {
         v.gates += (size_t)b0 * d.max_steps;
         v.nframes += b0;
         v.item_base += (uint32_t)b0;
+        return v;
+      };
+      const char *no_shrink = getenv("XDTTS_NO_SHRINK");  // developer comparison aid
+      for (int b0 = 0; b0 < d.B; b0 += PERSIST_B_MAX) {
+        const int n = std::min(PERSIST_B_MAX, d.B - b0);
+        const DecoderBufs v = view(b0, n);
         int sub_lim = 0;
         for (int b = 0; b < n; ++b) sub_lim = std::max(sub_lim, lim[b0 + b]);
         dec_exchange.alloc(persist_granule_words(n));
         PersistBufs g = persist_bufs(dec_exchange.p, dec_err.p, n);
         if (const char *lz = getenv("XDTTS_LAZY_POLL")) g.lazy = atoi(lz);  // developer tuning knobs
         if (const char *fp = getenv("XDTTS_FIRST_POLL")) g.first = atoi(fp);
+        g.shrink = (n == 2 && !no_shrink) ? 1 : 0;
 #ifdef XDTTS_PERSIST_PROFILE
         static DevBuf<unsigned long long> prof;
         prof.alloc(256 * 16);
@@ -388,6 +397,20 @@ struct xdtts_tacotron2 {
         if (b0 > 0) HIP_CHECK(hipMemsetAsync(d.ctl, 0, sizeof(int), stream));  // step counter of the new launch
         launch_persist_seed(v, g, limits.p + b0, stream);
         launch_decoder_persistent(v, w, g, sub_lim, stream);
+        if (g.shrink) {
+          // which chunk, if any, is still running?  (ctl[0] = steps executed, nframes[b] = its end)
+          HIP_CHECK(hipMemcpyAsync(host_ctl, d.ctl, sizeof(int) * 2, hipMemcpyDeviceToHost, stream));
+          HIP_CHECK(hipMemcpyAsync(host_ctl + 2, v.nframes, sizeof(int) * n, hipMemcpyDeviceToHost, stream));
+          HIP_CHECK(hipStreamSynchronize(stream));
+          const int done = host_ctl[0];
+          for (int r = 0; r < n; ++r)
+            if (host_ctl[2 + r] > done) {
+              PersistBufs g1 = persist_view(g, r);
+              g1.shrink = 0;
+              launch_decoder_persistent(view(b0 + r, 1), w, g1, lim[b0 + r] - done, stream);
+              break;  // at most one chunk of a pair survives the other
+            }
+        }
 #ifdef XDTTS_PERSIST_PROFILE
         if (const char *path = getenv("XDTTS_PERSIST_PROFILE")) {
           std::vector<unsigned long long> hp(256 * 16);

@@ -48,6 +48,8 @@ constexpr int P_NCU = ATT_RNN / 4;       // 256 workgroups = LSTM slices
 constexpr int TP = PERSIST_T_MAX;        // encoder-step capacity of the attention role
 constexpr int ATTN_CU = 8, PRE_CU = 16;  // role workgroups per chunk
 constexpr int EP_LD = TP, MEL_GL = 96;
+constexpr int GS = PERSIST_B_MAX;        // chunk stride of the granule arrays: the same for every launch width, so a
+                                         // 1-chunk launch can continue a sequence that a 2-chunk launch began
 constexpr unsigned P_SPIN_LIMIT = 1u << 21;
 constexpr unsigned ACT_BIT = 0x80000000u;
 constexpr int PERSIST_LAZY_DEFAULT = 4;  // ~0.85 us; measured flat from 2 to 12, 1 us per step better than 0
@@ -389,7 +391,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       float v[2];
       unsigned tg[2];
       lazy_wait(g.first);
-      gather<2>(g.x, (unsigned)((p * PB + b0) * PRENET + i), 2u * PRENET, want, need, v, tg, g.err);
+      gather<2>(g.x, (unsigned)((p * GS + b0) * PRENET + i), 2u * PRENET, want, need, v, tg, g.err);
 #pragma unroll
       for (int j = 0; j < 2; ++j)
         if (need[j]) {
@@ -406,7 +408,10 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
     }
     if (tid < PB) s_act[2 + tid] = s_act[tid];  // read again only after the barriers of this step
     PROF_MARK(1);  // wait x
-    if (!any) break;  // every chunk has stopped (or the exchange failed): the launch ends by itself
+    // Every chunk has stopped (or the exchange failed): the launch ends by itself.  A 2-chunk launch
+    // also ends when one of its chunks stops: the host continues the other with the 1-chunk kernel,
+    // which is ~1 us per step faster (state goes through the write-back below, x(s) stays in place).
+    if (!any || (PB == 2 && g.shrink && !(act[0] && act[1]))) break;
     const bool act_r = s_act[rb] != 0;
     // attention LSTM: close the rows with the x columns
 #pragma unroll
@@ -425,7 +430,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       const float *gp = s_g + cb * 16 + 4 * cu;
       const float ig = fast_sigmoid(gp[0]), fg = fast_sigmoid(gp[1]), gg = fast_tanh(gp[2]), og = fast_sigmoid(gp[3]);
       const float cn = fmaf(fg, s_cell[tid], ig * gg), hn = og * fast_tanh(cn);
-      publish(g.hatt + (unsigned)((p * PB + cb) * ATT_RNN + 4 * c + cu), want, hn);
+      publish(g.hatt + (unsigned)((p * GS + cb) * ATT_RNN + 4 * c + cu), want, hn);
       s_cell[tid] = cn;
       s_cell[8 * PB + tid] = hn;
     }
@@ -440,7 +445,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       float v[2 * PB];
       unsigned tg[2 * PB];
       lazy_wait(attn ? g.first : g.lazy);  // only the attention role needs h_att at once
-      gather<2 * PB>(g.hatt, (unsigned)(p * PB * ATT_RNN + tid), PT, want, need, v, tg, g.err);
+      gather<2 * PB>(g.hatt, (unsigned)(p * GS * ATT_RNN + tid), PT, want, need, v, tg, g.err);
 #pragma unroll
       for (int i = 0; i < 2 * PB; ++i)
         if (need[i]) s_hatt[TID + PT * i] = v[i];
@@ -471,7 +476,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       e = fmaf(v4.w, fast_tanh(q4.w + l4.w + p4.w), e);
       e += dpp_move<0xB1, 0xf>(0.f, e);  // quad_perm:[1,0,3,2]
       e += dpp_move<0x4E, 0xf>(0.f, e);  // quad_perm:[2,3,0,1]
-      if ((tid & 3) == 0 && t < T) publish(g.ep + (unsigned)(((p * PB + rb) * ATTN_CU + rk) * EP_LD + t), want, e);
+      if ((tid & 3) == 0 && t < T) publish(g.ep + (unsigned)(((p * GS + rb) * ATTN_CU + rk) * EP_LD + t), want, e);
     }
     // decoder LSTM: the h_att columns (off the critical path for everyone but the above)
 #pragma unroll
@@ -498,7 +503,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
         const bool need[2] = {t < T, t < T};
         float v[2];
         unsigned tg[2];
-        gather<2>(g.ep, (unsigned)(((p * PB + rb) * ATTN_CU + 2 * j) * EP_LD + t), EP_LD, want, need, v, tg, g.err);
+        gather<2>(g.ep, (unsigned)(((p * GS + rb) * ATTN_CU + 2 * j) * EP_LD + t), EP_LD, want, need, v, tg, g.err);
         float e = v[0] + v[1];
         e += dpp_move<0xB1, 0xf>(0.f, e);  // quad_perm:[1,0,3,2]
         e += dpp_move<0x4E, 0xf>(0.f, e);  // quad_perm:[2,3,0,1]
@@ -535,7 +540,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
 #pragma unroll
         for (int q = 0; q < NW; ++q) v += s_part[q * 64 + TID];
         s_cown[tid] = v;
-        publish(g.ctx + (unsigned)((p * PB + rb) * EMB + 64 * rk + tid), want, v);
+        publish(g.ctx + (unsigned)((p * GS + rb) * EMB + 64 * rk + tid), want, v);
       }
     }
     PROF_MARK(5);  // attention: wait e_part + softmax + ctx
@@ -545,7 +550,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       float v[PB];
       unsigned tg[PB];
       lazy_wait(g.first);
-      gather<PB>(g.ctx, (unsigned)(p * PB * EMB + tid), EMB, want, act, v, tg, g.err);
+      gather<PB>(g.ctx, (unsigned)(p * GS * EMB + tid), EMB, want, act, v, tg, g.err);
 #pragma unroll
       for (int b = 0; b < PB; ++b)
         if (act[b]) s_ctx[b * EMB + tid] = v[b];
@@ -574,7 +579,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       const float *gp = s_g + cb * 16 + 4 * cu;
       const float ig = fast_sigmoid(gp[0]), fg = fast_sigmoid(gp[1]), gg = fast_tanh(gp[2]), og = fast_sigmoid(gp[3]);
       const float cn = fmaf(fg, s_cell[4 * PB + tid], ig * gg), hn = og * fast_tanh(cn);
-      publish(g.hdec + (unsigned)((p * PB + cb) * DEC_RNN + 4 * c + cu), want, hn);
+      publish(g.hdec + (unsigned)((p * GS + cb) * DEC_RNN + 4 * c + cu), want, hn);
       s_cell[4 * PB + tid] = cn;
       s_cell[12 * PB + tid] = hn;
     }
@@ -590,7 +595,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       float v[2 * PB];
       unsigned tg[2 * PB];
       lazy_wait(pre ? g.first : g.lazy);  // only the projection role needs h_dec at once
-      gather<2 * PB>(g.hdec, (unsigned)(p * PB * DEC_RNN + tid), PT, want, need, v, tg, g.err);
+      gather<2 * PB>(g.hdec, (unsigned)(p * GS * DEC_RNN + tid), PT, want, need, v, tg, g.err);
 #pragma unroll
       for (int i = 0; i < 2 * PB; ++i)
         if (need[i]) s_hdec[TID + PT * i] = v[i];
@@ -604,7 +609,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
 #pragma unroll
       for (int j = 4; j < 6; ++j) a = dot4(lds4(s_pw + 4 * (j * PT + TID)), lds4(s_ctx + rb * EMB + 256 * (j - 4) + L4), a);
       a = wave_sum(a);
-      if (lane == 0) publish(g.mel + (unsigned)((p * PB + rb) * MEL_GL + prow), want, a + s_pb[wave]);
+      if (lane == 0) publish(g.mel + (unsigned)((p * GS + rb) * MEL_GL + prow), want, a + s_pb[wave]);
     }
     dec_bulk_h(L4, false);  // for step s+1
     if (attn && act_r) location(tid);
@@ -633,7 +638,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
           const bool need[1] = {true};
           float v[1];
           unsigned tg[1];
-          gather<1>(g.mel, (unsigned)((p * PB + rb) * MEL_GL + tid), 0, want, need, v, tg, g.err);
+          gather<1>(g.mel, (unsigned)((p * GS + rb) * MEL_GL + tid), 0, want, need, v, tg, g.err);
           s_mel[tid] = v[0];
         }
         __syncthreads();
@@ -676,7 +681,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
         }
       }
       if (lane < 2)
-        publish(g.x + (unsigned)(((p ^ 1) * PB + rb) * PRENET + 16 * rk + wave + NW * lane), (want + 1u) | (nxt ? ACT_BIT : 0u),
+        publish(g.x + (unsigned)(((p ^ 1) * GS + rb) * PRENET + 16 * rk + wave + NW * lane), (want + 1u) | (nxt ? ACT_BIT : 0u),
                 lane ? xo[1] : xo[0]);
     }
     PROF_MARK(10);  // prenet role: wait mel + frame store + prenet + publish x
@@ -719,21 +724,35 @@ void launch_pb(const DecoderBufs &d, const PersistBufs &g, const PersistWeights 
 }  // namespace
 
 size_t persist_granule_words(int B) {
-  return (size_t)2 * B * (PRENET + ATT_RNN + ATTN_CU * EP_LD + EMB + DEC_RNN + MEL_GL);
+  (void)B;
+  return (size_t)2 * GS * (PRENET + ATT_RNN + ATTN_CU * EP_LD + EMB + DEC_RNN + MEL_GL);
 }
 
 PersistBufs persist_bufs(unsigned long long *base, int *err, int B) {
   PersistBufs g{};
   g.x = base;
-  g.hatt = g.x + (size_t)2 * B * PRENET;
-  g.ep = g.hatt + (size_t)2 * B * ATT_RNN;
-  g.ctx = g.ep + (size_t)2 * B * ATTN_CU * EP_LD;
-  g.hdec = g.ctx + (size_t)2 * B * EMB;
-  g.mel = g.hdec + (size_t)2 * B * DEC_RNN;
+  (void)B;
+  g.hatt = g.x + (size_t)2 * GS * PRENET;
+  g.ep = g.hatt + (size_t)2 * GS * ATT_RNN;
+  g.ctx = g.ep + (size_t)2 * GS * ATTN_CU * EP_LD;
+  g.hdec = g.ctx + (size_t)2 * GS * EMB;
+  g.mel = g.hdec + (size_t)2 * GS * DEC_RNN;
   g.err = err;
   g.lazy = PERSIST_LAZY_DEFAULT;
+  g.shrink = 0;
   g.first = 2;  // ~0.4 us: the first polls of a critical consumer cannot succeed earlier (measured: -0.3 us per step)
   return g;
+}
+
+PersistBufs persist_view(const PersistBufs &g, int b0) {
+  PersistBufs v = g;
+  v.x += (size_t)b0 * PRENET;
+  v.hatt += (size_t)b0 * ATT_RNN;
+  v.ep += (size_t)b0 * ATTN_CU * EP_LD;
+  v.ctx += (size_t)b0 * EMB;
+  v.hdec += (size_t)b0 * DEC_RNN;
+  v.mel += (size_t)b0 * MEL_GL;
+  return v;
 }
 
 // The grid must be co-resident: one workgroup per CU on a 256-CU part, nothing else of ours running.

@@ -49,12 +49,15 @@ constexpr int PERSIST_T_MAX = 128;  // encoder steps (the reference's window is 
 struct PersistBufs {
   unsigned long long *x, *hatt, *ep, *ctx, *hdec, *mel;
   int *err;  // set by a workgroup whose bounded spin ran out
+  int shrink;  // 2-chunk launch: end as soon as one chunk stops (the host continues with a 1-chunk launch)
   int first;  // delay before a critical consumer's first poll, x 512 clocks (developer knob)
   int lazy;  // late-poll delay of the off-critical-path consumers, x 512 clocks
   unsigned long long *prof;  // developer profile build only: [256][16] phase clocks, else null
 };
 size_t persist_granule_words(int B);
 PersistBufs persist_bufs(unsigned long long *base, int *err, int B);
+// The same exchange seen by a launch over chunks [b0, b0 + n) of the seeded batch.
+PersistBufs persist_view(const PersistBufs &g, int b0);
 bool decoder_persistent_supported(int device, int B, int T);
 // After launch_decoder_init: clears the exchange and publishes x(0) with the chunks' active bits.
 void launch_persist_seed(const DecoderBufs &d, const PersistBufs &g, const int *limits_dev, hipStream_t s);
