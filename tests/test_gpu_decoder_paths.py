@@ -68,6 +68,26 @@ def test_engines_agree_on_ragged_pair_with_gate(pkg, orc, blob):
     assert out["persistent"][0].shape[1] != out["persistent"][1].shape[1] or out["persistent"][0].shape[1] < 90
 
 
+@pytest.mark.parametrize("steps", [(50, 17), (9, 64), (30, 30), (1, 40)])
+def test_pair_survivor_continues_on_the_one_chunk_kernel(pkg, orc, blob, steps):
+    """A 2-chunk launch ends when its first chunk stops; the other is continued by the 1-chunk kernel
+    from the written-back state.  Either chunk may be the survivor; equal lengths need no hand-off."""
+    lens = [44, 29]
+    ids = [synth_ids(n, seed=21 + i) for i, n in enumerate(lens)]
+    fs = np.asarray(steps, dtype=np.int32)
+    m = pkg.Tacotron2.from_blob(blob)
+    o = pkg.default_opts(dropout_seed=13)
+    out = m.infer_batch(ids, opts=o, fixed_steps=fs)
+    m.close()
+    for b in range(2):
+        padded = np.zeros(100, dtype=np.int64)
+        padded[: lens[b]] = ids[b]
+        mem, pm = orc.encoder(blob, padded)
+        rframes, _ = orc.run_decoder(blob, mem, pm, lens[b], orc.default_opts(fixed_steps=int(steps[b]), dropout_seed=13, item=b))
+        assert out[b].shape == (80, steps[b])
+        assert rms(out[b], orc.postnet(blob, rframes)) <= 1e-5
+
+
 def test_three_and_four_chunks_run_as_two_persistent_launches(pkg, orc, blob):
     """B = 3..4: the persistent engine takes the chunks two at a time over views of the state arrays;
     every chunk must still equal its own single-chunk oracle run (item index = dropout stream)."""
