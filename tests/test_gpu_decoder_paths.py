@@ -133,3 +133,14 @@ def test_persistent_engine_long_sequence_and_dropout_off(pkg, model, orc, blob):
         frames, _ = model.decoder(mem, pm, 95, pkg.default_opts(fixed_steps=300, dropout_seed=4, dropout_mode=dm))
         assert frames.shape == rframes.shape
         assert rms(frames, rframes) <= 1e-4  # north_star tolerance at full length
+
+
+def test_max_decoder_steps_1000_is_reached_without_a_stop(pkg, model, orc, blob):
+    """max_decoder_steps = 1000 (mod.rs:280): the synthetic gate never fires, so the loop runs the
+    full 1000 frames in one persistent launch; parity with the oracle at full length."""
+    mem, pm = encode(orc, blob, 77)
+    rframes, rgates = orc.run_decoder(blob, mem, pm, 77, orc.default_opts(dropout_seed=2))
+    frames, gates = model.decoder(mem, pm, 77, pkg.default_opts(dropout_seed=2))
+    assert frames.shape == rframes.shape == (1000, 80)
+    assert rms(frames, rframes) <= 1e-4 and np.abs(gates - rgates).max() <= 1e-3
+    assert model.last_timings()["steps"] == 1000
