@@ -396,20 +396,28 @@ struct xdtts_tacotron2 {
 #endif
         if (b0 > 0) HIP_CHECK(hipMemsetAsync(d.ctl, 0, sizeof(int), stream));  // step counter of the new launch
         launch_persist_seed(v, g, limits.p + b0, stream);
-        launch_decoder_persistent(v, w, g, sub_lim, stream);
-        if (g.shrink) {
-          // which chunk, if any, is still running?  (ctl[0] = steps executed, nframes[b] = its end)
-          HIP_CHECK(hipMemcpyAsync(host_ctl, d.ctl, sizeof(int) * 2, hipMemcpyDeviceToHost, stream));
-          HIP_CHECK(hipMemcpyAsync(host_ctl + 2, v.nframes, sizeof(int) * n, hipMemcpyDeviceToHost, stream));
-          HIP_CHECK(hipStreamSynchronize(stream));
-          const int done = host_ctl[0];
-          for (int r = 0; r < n; ++r)
-            if (host_ctl[2 + r] > done) {
-              PersistBufs g1 = persist_view(g, r);
-              g1.shrink = 0;
-              launch_decoder_persistent(view(b0 + r, 1), w, g1, lim[b0 + r] - done, stream);
-              break;  // at most one chunk of a pair survives the other
-            }
+        if (g.shrink && !d.use_gate && lim[b0] != lim[b0 + 1]) {
+          // without the gate the host knows which chunk outlives the other: no round trip in between
+          const int first = std::min(lim[b0], lim[b0 + 1]), r = lim[b0] > lim[b0 + 1] ? 0 : 1;
+          g.shrink = 0;
+          launch_decoder_persistent(v, w, g, first, stream);
+          launch_decoder_persistent(view(b0 + r, 1), w, persist_view(g, r), lim[b0 + r] - first, stream);
+        } else {
+          launch_decoder_persistent(v, w, g, sub_lim, stream);
+          if (g.shrink) {
+            // which chunk, if any, is still running?  (ctl[0] = steps executed, nframes[b] = its end)
+            HIP_CHECK(hipMemcpyAsync(host_ctl, d.ctl, sizeof(int) * 2, hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipMemcpyAsync(host_ctl + 2, v.nframes, sizeof(int) * n, hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+            const int done = host_ctl[0];
+            for (int r = 0; r < n; ++r)
+              if (host_ctl[2 + r] > done) {
+                PersistBufs g1 = persist_view(g, r);
+                g1.shrink = 0;
+                launch_decoder_persistent(view(b0 + r, 1), w, g1, lim[b0 + r] - done, stream);
+                break;  // at most one chunk of a pair survives the other
+              }
+          }
         }
 #ifdef XDTTS_PERSIST_PROFILE
         if (const char *path = getenv("XDTTS_PERSIST_PROFILE")) {
