@@ -144,3 +144,24 @@ def test_max_decoder_steps_1000_is_reached_without_a_stop(pkg, model, orc, blob)
     assert frames.shape == rframes.shape == (1000, 80)
     assert rms(frames, rframes) <= 1e-4 and np.abs(gates - rgates).max() <= 1e-3
     assert model.last_timings()["steps"] == 1000
+
+
+def test_lost_workgroup_drains_and_falls_back(pkg, orc, blob, capfd):
+    """The persistent grid must be co-resident.  With one workgroup missing (test hook) every bounded
+    spin runs out or sees the error word, the launch drains, and the handle re-decodes the request on
+    the launch-per-stage engine -- correct frames, a message on stderr, no hang."""
+    mem, pm = encode(orc, blob, 21)
+    rframes, _ = orc.run_decoder(blob, mem, pm, 21, orc.default_opts(fixed_steps=30, dropout_seed=3))
+    os.environ["XDTTS_PERSIST_FAULT"] = "201"   # workgroup 200 returns at once
+    os.environ["XDTTS_PERSIST_SPINS"] = "20000"
+    try:
+        m = pkg.Tacotron2.from_blob(blob)
+        frames, _ = m.decoder(mem, pm, 21, pkg.default_opts(fixed_steps=30, dropout_seed=3))
+        assert "persistent decoder exchange timed out" in capfd.readouterr().err
+        assert frames.shape == rframes.shape and rms(frames, rframes) <= 1e-5
+    finally:
+        del os.environ["XDTTS_PERSIST_FAULT"], os.environ["XDTTS_PERSIST_SPINS"]
+    # the handle stays on the second engine; a fresh handle is persistent again
+    frames2, _ = m.decoder(mem, pm, 21, pkg.default_opts(fixed_steps=30, dropout_seed=3))
+    assert np.array_equal(frames2, frames)
+    m.close()

@@ -388,6 +388,8 @@ struct xdtts_tacotron2 {
         PersistBufs g = persist_bufs(dec_exchange.p, dec_err.p, n);
         if (const char *lz = getenv("XDTTS_LAZY_POLL")) g.lazy = atoi(lz);  // developer tuning knobs
         if (const char *fp = getenv("XDTTS_FIRST_POLL")) g.first = atoi(fp);
+        if (const char *sp = getenv("XDTTS_PERSIST_SPINS")) g.spins = atoi(sp);  // test hooks for the
+        if (const char *ft = getenv("XDTTS_PERSIST_FAULT")) g.fault = atoi(ft);  // lost-workgroup path
         g.shrink = (n == 2 && !no_shrink) ? 1 : 0;
 #ifdef XDTTS_PERSIST_PROFILE
         static DevBuf<unsigned long long> prof;
@@ -437,13 +439,19 @@ struct xdtts_tacotron2 {
       int e = 0;
       HIP_CHECK(hipMemcpyAsync(&e, dec_err.p, sizeof(int), hipMemcpyDeviceToHost, stream));
       fetch();
-      if (e) {
-        HIP_CHECK(hipMemsetAsync(dec_err.p, 0, sizeof(int), stream));
-        fail(XDTTS_ERR_HIP, "persistent decoder: state exchange timed out (grid not co-resident?)");
+      if (!e) {
+        int steps = 0;
+        for (int b = 0; b < d.B; ++b) steps = std::max(steps, host_ctl[2 + b]);
+        return steps;
       }
-      int steps = 0;
-      for (int b = 0; b < d.B; ++b) steps = std::max(steps, host_ctl[2 + b]);
-      return steps;
+      // A bounded spin ran out: the 256-workgroup grid was not co-resident (CUs masked or held by
+      // another process).  Not silent, not fatal: say so, switch this handle to the launch-per-stage
+      // engine for good, and decode this request again from the initial state.
+      HIP_CHECK(hipMemsetAsync(dec_err.p, 0, sizeof(int), stream));
+      persist_state = 0;
+      std::fprintf(stderr, "libxdtts_hip: persistent decoder exchange timed out (grid not co-resident); "
+                           "this handle now uses the launch-per-stage decoder\n");
+      launch_decoder_init(d, limits.p, stream);
     }
     if (!d.use_gate) {  // deterministic work: every chunk runs to its cap
       while (launched < max_lim) {

@@ -63,9 +63,13 @@ __device__ __forceinline__ void publish(u64 *slot, unsigned tag, float v) {
 __device__ __forceinline__ u64 peek(const u64 *slot) {
   return __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ bool give_up(unsigned &spins, int *err) {
-  if (++spins > P_SPIN_LIMIT || ((spins & 127u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-    atomicExch(err, 1);
+struct PollCtl {
+  int *err;
+  unsigned limit;
+};
+__device__ __forceinline__ bool give_up(unsigned &spins, const PollCtl &pc) {
+  if (++spins > pc.limit || ((spins & 127u) == 0 && __hip_atomic_load(pc.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+    atomicExch(pc.err, 1);
     return true;
   }
   __builtin_amdgcn_s_sleep(1);
@@ -76,7 +80,7 @@ __device__ __forceinline__ bool give_up(unsigned &spins, int *err) {
 // live across the step loop).  A timed-out slot reads as {tag 0, 0.0f}.
 template <int N>
 __device__ __forceinline__ void gather(const u64 *base, unsigned idx, unsigned stride, unsigned want,
-                                       const bool (&need)[N], float (&out)[N], unsigned (&tag)[N], int *err) {
+                                       const bool (&need)[N], float (&out)[N], unsigned (&tag)[N], const PollCtl &err) {
   bool done[N];
 #pragma unroll
   for (int i = 0; i < N; ++i) {
@@ -126,7 +130,7 @@ __device__ __forceinline__ unsigned opaque(unsigned v) {
 }
 
 constexpr int persist_lds_floats(int pb) {
-  const int common = pb * (PRENET + EMB + ATT_RNN + DEC_RNN + 16) + 4 + 32 + 16 * pb;
+  const int common = pb * (PRENET + EMB + ATT_RNN + DEC_RNN + 16) + 8 + 32 + 16 * pb;
   const int attn = TP * 64 + 2 * TP * 16 + 2 * TP + 16 + NW * 64 + 2 * WPAD + 62 * 16 + 64 + TP + 16 + 8 * PT * 4;
   const int pre = N_MEL * PRENET + MEL_GL + 2 * PRENET + 8 + 6 * PT * 4;
   return common + (attn > pre ? attn : pre);
@@ -167,6 +171,8 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
   __shared__ __attribute__((aligned(16))) float smem[persist_lds_floats(PB)];
   const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int T = d.T;
+  const PollCtl pc{g.err, g.spins > 0 ? (unsigned)g.spins : P_SPIN_LIMIT};
+  if (g.fault && c == g.fault - 1) return;  // developer fault injection: this workgroup never shows up
   const unsigned L4 = opaque(4u * (unsigned)lane);
   // ---- LDS: state vectors of all chunks, then the role's working set -------------------------
   float *s_x = smem;                     // [PB][256]
@@ -174,8 +180,8 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
   float *s_hatt = s_ctx + PB * EMB;      // [PB][1024]
   float *s_hdec = s_hatt + PB * ATT_RNN; // [PB][1024]
   float *s_g = s_hdec + PB * DEC_RNN;    // [PB][16] gate pre-activations of this workgroup's rows
-  int *s_act = reinterpret_cast<int *>(s_g + PB * 16);  // [2] active at this step, [2..3] alive: not yet seen inactive
-  float *s_bias = s_g + PB * 16 + 4;    // [2][16] b_ih + b_hh of this workgroup's attention / decoder rows
+  int *s_act = reinterpret_cast<int *>(s_g + PB * 16);  // [0..1] active at this step, [2..3] alive: not yet seen inactive, [4] error word
+  float *s_bias = s_g + PB * 16 + 8;    // [2][16] b_ih + b_hh of this workgroup's attention / decoder rows
   float *s_cell = s_bias + 32;           // [4][4 PB] att_c, dec_c, h_att, h_dec of the (chunk, unit) cell threads
   float *role = s_cell + 16 * PB;
   // attention role
@@ -391,13 +397,14 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       float v[2];
       unsigned tg[2];
       lazy_wait(g.first);
-      gather<2>(g.x, (unsigned)((p * GS + b0) * PRENET + i), 2u * PRENET, want, need, v, tg, g.err);
+      gather<2>(g.x, (unsigned)((p * GS + b0) * PRENET + i), 2u * PRENET, want, need, v, tg, pc);
 #pragma unroll
       for (int j = 0; j < 2; ++j)
         if (need[j]) {
           s_x[(b0 + 2 * j) * PRENET + i] = v[j];
           if (i == 0) s_act[b0 + 2 * j] = (tg[j] & ACT_BIT) ? 1 : 0;
         }
+      if (tid == PT - 1) s_act[4] = __hip_atomic_load(g.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     bool act[PB], any = false;
@@ -411,7 +418,8 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
     // Every chunk has stopped (or the exchange failed): the launch ends by itself.  A 2-chunk launch
     // also ends when one of its chunks stops: the host continues the other with the 1-chunk kernel,
     // which is ~1 us per step faster (state goes through the write-back below, x(s) stays in place).
-    if (!any || (PB == 2 && g.shrink && !(act[0] && act[1]))) break;
+    // (and it ends at once when any workgroup has reported a timed-out exchange)
+    if (!any || s_act[4] != 0 || (PB == 2 && g.shrink && !(act[0] && act[1]))) break;
     const bool act_r = s_act[rb] != 0;
     // attention LSTM: close the rows with the x columns
 #pragma unroll
@@ -445,7 +453,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       float v[2 * PB];
       unsigned tg[2 * PB];
       lazy_wait(attn ? g.first : g.lazy);  // only the attention role needs h_att at once
-      gather<2 * PB>(g.hatt, (unsigned)(p * GS * ATT_RNN + tid), PT, want, need, v, tg, g.err);
+      gather<2 * PB>(g.hatt, (unsigned)(p * GS * ATT_RNN + tid), PT, want, need, v, tg, pc);
 #pragma unroll
       for (int i = 0; i < 2 * PB; ++i)
         if (need[i]) s_hatt[TID + PT * i] = v[i];
@@ -503,7 +511,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
         const bool need[2] = {t < T, t < T};
         float v[2];
         unsigned tg[2];
-        gather<2>(g.ep, (unsigned)(((p * GS + rb) * ATTN_CU + 2 * j) * EP_LD + t), EP_LD, want, need, v, tg, g.err);
+        gather<2>(g.ep, (unsigned)(((p * GS + rb) * ATTN_CU + 2 * j) * EP_LD + t), EP_LD, want, need, v, tg, pc);
         float e = v[0] + v[1];
         e += dpp_move<0xB1, 0xf>(0.f, e);  // quad_perm:[1,0,3,2]
         e += dpp_move<0x4E, 0xf>(0.f, e);  // quad_perm:[2,3,0,1]
@@ -550,7 +558,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       float v[PB];
       unsigned tg[PB];
       lazy_wait(g.first);
-      gather<PB>(g.ctx, (unsigned)(p * GS * EMB + tid), EMB, want, act, v, tg, g.err);
+      gather<PB>(g.ctx, (unsigned)(p * GS * EMB + tid), EMB, want, act, v, tg, pc);
 #pragma unroll
       for (int b = 0; b < PB; ++b)
         if (act[b]) s_ctx[b * EMB + tid] = v[b];
@@ -595,7 +603,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       float v[2 * PB];
       unsigned tg[2 * PB];
       lazy_wait(pre ? g.first : g.lazy);  // only the projection role needs h_dec at once
-      gather<2 * PB>(g.hdec, (unsigned)(p * GS * DEC_RNN + tid), PT, want, need, v, tg, g.err);
+      gather<2 * PB>(g.hdec, (unsigned)(p * GS * DEC_RNN + tid), PT, want, need, v, tg, pc);
 #pragma unroll
       for (int i = 0; i < 2 * PB; ++i)
         if (need[i]) s_hdec[TID + PT * i] = v[i];
@@ -638,7 +646,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
           const bool need[1] = {true};
           float v[1];
           unsigned tg[1];
-          gather<1>(g.mel, (unsigned)((p * GS + rb) * MEL_GL + tid), 0, want, need, v, tg, g.err);
+          gather<1>(g.mel, (unsigned)((p * GS + rb) * MEL_GL + tid), 0, want, need, v, tg, pc);
           s_mel[tid] = v[0];
         }
         __syncthreads();
@@ -740,6 +748,8 @@ PersistBufs persist_bufs(unsigned long long *base, int *err, int B) {
   g.err = err;
   g.lazy = PERSIST_LAZY_DEFAULT;
   g.shrink = 0;
+  g.spins = 0;
+  g.fault = 0;
   g.first = 2;  // ~0.4 us: the first polls of a critical consumer cannot succeed earlier (measured: -0.3 us per step)
   return g;
 }

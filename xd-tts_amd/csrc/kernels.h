@@ -49,6 +49,7 @@ constexpr int PERSIST_T_MAX = 128;  // encoder steps (the reference's window is 
 struct PersistBufs {
   unsigned long long *x, *hatt, *ep, *ctx, *hdec, *mel;
   int *err;  // set by a workgroup whose bounded spin ran out
+  int spins, fault;  // developer/test knobs: poll limit (0 = default) and a workgroup (index + 1) that never runs
   int shrink;  // 2-chunk launch: end as soon as one chunk stops (the host continues with a 1-chunk launch)
   int first;  // delay before a critical consumer's first poll, x 512 clocks (developer knob)
   int lazy;  // late-poll delay of the off-critical-path consumers, x 512 clocks
