@@ -153,6 +153,7 @@ struct xdtts_tacotron2 {
   DevBuf<unsigned long long> dec_exchange;  // granule buffers of the persistent decoder
   DevBuf<int> dec_err;
   int persist_state = -1;                   // -1 unknown, 0 unavailable on this device, 1 usable
+  bool coop_ok = true;                      // cooperative encoder BiLSTM usable (cleared after a timed-out exchange)
   static constexpr int COOP_MAX_B = 16;  // 8*B blocks of 1024 threads must be co-resident
   DevBuf<float> att_h, att_c, dec_h, dec_c, aw, awc, ctx, x, loc, e_part, pmel, frames, gates;
   DevBuf<float> ppA, ppB, mel_dev;
@@ -229,7 +230,7 @@ struct xdtts_tacotron2 {
       g.batch = B;
       launch_gemm_nt(g, stream);
     }
-    if (B <= COOP_MAX_B) {
+    if (B <= COOP_MAX_B && coop_ok) {
       enc_exchange.alloc(bilstm_coop_exchange_words(B));
       launch_bilstm_coop(xproj.p, w.enc_whhT[0].p, w.enc_whhT[1].p, memory.p, enc_exchange.p, enc_err.p, B, T, stream);
     } else {
@@ -560,7 +561,15 @@ struct xdtts_tacotron2 {
     DecoderBufs d = decoder_bufs(B, T, memory.p, pmem.p, o);
     if (fixed_per_item || o.fixed_frames_per_id > 0.f) d.use_gate = 0;
     last_steps = run_decoder(d, lim);
-    check_encoder_exchange();
+    if (encoder_exchange_failed()) {
+      // the 4-CU cooperative BiLSTM needs its workgroups co-resident too: same policy as the decoder --
+      // say so, use the single-workgroup recurrence from now on, and run the request again
+      coop_ok = false;
+      std::fprintf(stderr, "libxdtts_hip: encoder BiLSTM exchange timed out (grid not co-resident); "
+                           "this handle now uses the single-workgroup recurrence\n");
+      run_encoder(B, T);
+      last_steps = run_decoder(d, lim);
+    }
     HIP_CHECK(hipEventRecord(ev.e[2], stream));
     std::vector<int> F(B);
     int total = 0;
@@ -580,13 +589,17 @@ struct xdtts_tacotron2 {
   }
 
   // the cooperative BiLSTM bounds its spins; a timeout there must not pass silently
-  void check_encoder_exchange() {
+  bool encoder_exchange_failed() {
     int e = 0;
     HIP_CHECK(hipMemcpyAsync(&e, enc_err.p, sizeof(int), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
-    if (e) {
-      HIP_CHECK(hipMemsetAsync(enc_err.p, 0, sizeof(int), stream));
-      fail(XDTTS_ERR_HIP, "encoder BiLSTM hidden-state exchange timed out");
+    if (e) HIP_CHECK(hipMemsetAsync(enc_err.p, 0, sizeof(int), stream));
+    return e != 0;
+  }
+  void check_encoder_exchange() {
+    if (encoder_exchange_failed()) {
+      coop_ok = false;
+      fail(XDTTS_ERR_HIP, "encoder BiLSTM hidden-state exchange timed out (retry uses the single-workgroup recurrence)");
     }
   }
 
