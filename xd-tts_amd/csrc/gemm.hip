@@ -25,9 +25,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // flight during the multiply.  The f32 MFMA issues at 32 cycles per instruction per SIMD and a single
 // accumulator chain is latency-bound, so what decides a GEMM's time here is (a) independent
 // accumulators per wave -- TM TN chains -- and (b) enough blocks to cover the chip; the launcher
-// picks the largest tile that still gives >= ~500 blocks.  On this path (M = 100..800 rows) that is
-// always the 32x32 tile: measured, the post-net takes 0.38 / 0.49 / 0.79 ms with 32x32 / 32x64 /
-// 64x64 tiles (XDTTS_GEMM_FILL = 200 / 100 / 40) because the larger tiles leave CUs idle.  Every
+// takes a larger tile only when XDTTS_GEMM_FILL (blocks wanted before a larger tile is used) asks
+// for it: measured, the 32x32 tile wins everywhere on this path -- post-net (M <= 800) 0.38 / 0.49 /
+// 0.79 ms with 32x32 / 32x64 / 64x64 tiles; 52-chunk encoder (3328 blocks) 1.83 ms against 2.41 ms
+// with 64x64 -- the f32 MFMA is issue-bound per wave and more, smaller blocks hide its latency better.  Every
 // output element accumulates its K products in ascending order whatever the tile: results do not
 // depend on the tile choice.
 constexpr int BK = 32, LDS_LD = 36;  // 144-byte rows: 16-B aligned float4 reads
@@ -247,7 +248,7 @@ void launch_gemm_nt(const GemmArgs &g, hipStream_t s) {
   auto launch = [&](auto kern, int tm, int tn) {
     hipLaunchKernelGGL(kern, dim3((g.N + 32 * tn - 1) / (32 * tn), (g.M + 32 * tm - 1) / (32 * tm), g.batch), dim3(256), 0, s, g);
   };
-  static const long FILL = getenv("XDTTS_GEMM_FILL") ? atol(getenv("XDTTS_GEMM_FILL")) : 512;  // blocks wanted before a larger tile pays
+  static const long FILL = getenv("XDTTS_GEMM_FILL") ? atol(getenv("XDTTS_GEMM_FILL")) : (1L << 40);  // blocks wanted before a larger tile pays
   if (blocks(2, 2) >= FILL) launch(k_gemm_nt<2, 2>, 2, 2);
   else if (blocks(1, 2) >= FILL) launch(k_gemm_nt<1, 2>, 1, 2);
   else launch(k_gemm_nt<1, 1>, 1, 1);
