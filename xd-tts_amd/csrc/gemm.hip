@@ -8,8 +8,8 @@
 //     (lda = C instead of k*C) -- implicit GEMM with no im2col buffer;
 //   * BiLSTM input projections, the attention memory layer, and the Griffin-Lim mel->linear
 //     product (pinv(mel_basis) . exp(mel)).
-// Tiles of 32x32, 32x64 or 64x64 per 256-thread block (1, 2 or 4 MFMA tiles per wave), K-slab 32
-// through double-buffered LDS.  Within a slab the contraction
+// Tile: 32x32 per 256-thread block (one 16x16 MFMA tile per wave), K-slab 32 through double-buffered
+// LDS, global loads four slabs ahead.  Within a slab the contraction
 // index is permuted (k = 4*(lane>>4) + kk) so each lane fetches its four K values of a tile row
 // with one ds_read_b128.
 #include "kernels.h"
@@ -20,22 +20,17 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Output tile (32 TM) x (32 TN) per 256-thread block: 2 x 2 waves, each TM x TN MFMA tiles of 16x16.
-// K-slab 32 through double-buffered LDS (one barrier per slab) with the next slab's global loads in
-// flight during the multiply.  The f32 MFMA issues at 32 cycles per instruction per SIMD and a single
-// accumulator chain is latency-bound, so what decides a GEMM's time here is (a) independent
-// accumulators per wave -- TM TN chains -- and (b) enough blocks to cover the chip; the launcher
-// takes a larger tile only when XDTTS_GEMM_FILL (blocks wanted before a larger tile is used) asks
-// for it: measured, the 32x32 tile wins everywhere on this path -- post-net (M <= 800) 0.38 / 0.49 /
-// 0.79 ms with 32x32 / 32x64 / 64x64 tiles; 52-chunk encoder (3328 blocks) 1.83 ms against 2.41 ms
-// with 64x64 -- the f32 MFMA is issue-bound per wave and more, smaller blocks hide its latency better.  Every
-// output element accumulates its K products in ascending order whatever the tile: results do not
-// depend on the tile choice.
-constexpr int BK = 32, LDS_LD = 36;  // 144-byte rows: 16-B aligned float4 reads
+// 32x32 output tile per 256-thread block: 2 x 2 waves, one 16x16 MFMA tile each -- measured the
+// fastest shape on this path (larger tiles: post-net 0.49 / 0.79 ms against 0.38 ms; 52-chunk
+// encoder 2.41 against 1.83 ms).  K-slab 32 through double-buffered LDS, one barrier per slab.
+// These GEMMs put only 1-2 blocks on a CU (M = 100..800 rows), a slab's eight MFMAs take ~0.1 us
+// and an L2 round trip ~0.7 us, so the global loads run FOUR slabs ahead in named registers (an
+// indexed ring was demoted to scratch by the compiler), unconditional and clamped into the operand
+// so nothing depends on their data until the slab is staged (the zero fill happens there).  Every
+// output element accumulates its K products in ascending order.
+constexpr int BM = 32, BN = 32, BK = 32, LDS_LD = 36;  // 144-byte rows: 16-B aligned float4 reads
 
-template <int TM, int TN>
 __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs g) {
-  constexpr int BM = 32 * TM, BN = 32 * TN;
   __shared__ __attribute__((aligned(16))) float As[2][BM * LDS_LD];
   __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDS_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -45,92 +40,80 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs g) {
   float *C = g.C + (size_t)z * g.strideC;
   const float *R = g.R ? g.R + (size_t)z * g.strideR : nullptr;
 
-  // global -> LDS assignment: thread loads TM float4 of A and TN of W per slab (rows lr + 32 i)
+  // global -> LDS assignment: thread loads one float4 of A and one of W per slab
   const int lr = tid >> 3, lc = (tid & 7) * 4;
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 pa[TM], pb[TN];
-  auto fetch = [&](int k0) {  // K is a multiple of 16 but not always of 32: zero-fill past K
-    const bool kok = k0 + lc < g.K;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int m = m0 + lr + 32 * i;
-      pa[i] = (kok && m < g.M) ? *reinterpret_cast<const float4 *>(A + (size_t)m * g.lda + k0 + lc) : zero4;
-    }
-#pragma unroll
-    for (int i = 0; i < TN; ++i) {
-      const int n = n0 + lr + 32 * i;
-      pb[i] = (kok && n < g.N) ? *reinterpret_cast<const float4 *>(g.W + (size_t)n * g.K + k0 + lc) : zero4;
-    }
-  };
-  auto stage = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i) *reinterpret_cast<float4 *>(&As[buf][(lr + 32 * i) * LDS_LD + lc]) = pa[i];
-#pragma unroll
-    for (int i = 0; i < TN; ++i) *reinterpret_cast<float4 *>(&Bs[buf][(lr + 32 * i) * LDS_LD + lc]) = pb[i];
-  };
-
-  f32x4 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool a_ok = m0 + lr < g.M, b_ok = n0 + lr < g.N;
+  const float *a_src = A + (size_t)(a_ok ? m0 + lr : g.M - 1) * g.lda + lc;
+  const float *b_src = g.W + (size_t)(b_ok ? n0 + lr : g.N - 1) * g.K + lc;
+  const int nslab = (g.K + BK - 1) / BK;
   const int fi = lane & 15, fg = lane >> 4;
-  fetch(0);
-  stage(0);
-  __syncthreads();
-  int buf = 0;
-  for (int k0 = 0; k0 < g.K; k0 += BK, buf ^= 1) {
-    const bool more = k0 + BK < g.K;
-    if (more) fetch(k0 + BK);  // next slab's loads fly while this one is multiplied
-#pragma unroll
-    for (int kg = 0; kg < BK / 16; ++kg) {
-      float4 af[TM], bf[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-        af[i] = *reinterpret_cast<const float4 *>(&As[buf][((wm * TM + i) * 16 + fi) * LDS_LD + kg * 16 + fg * 4]);
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        bf[j] = *reinterpret_cast<const float4 *>(&Bs[buf][((wn * TN + j) * 16 + fi) * LDS_LD + kg * 16 + fg * 4]);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-    }
-    if (more) stage(buf ^ 1);  // the other buffer was last read before the previous barrier
-    __syncthreads();
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#define GEMM_FETCH(SLAB, QA, QB)                                                            \
+  do {                                                                                      \
+    const int k0_ = ((SLAB) < nslab && (SLAB) * BK + lc < g.K) ? (SLAB) * BK : 0;           \
+    QA = *reinterpret_cast<const float4 *>(a_src + k0_);                                    \
+    QB = *reinterpret_cast<const float4 *>(b_src + k0_);                                    \
+  } while (0)
+#define GEMM_STAGE(SLAB, QA, QB)                                                            \
+  do {                                                                                      \
+    const bool kok_ = (SLAB) * BK + lc < g.K; /* K is a multiple of 16, not always of 32 */ \
+    /* no `cond ? QA : zero4` on the vector class: it selects between ADDRESSES and sends the  \
+       prefetch registers to scratch */                                                      \
+    const float ma_ = (kok_ && a_ok) ? 1.f : 0.f, mb_ = (kok_ && b_ok) ? 1.f : 0.f;         \
+    *reinterpret_cast<float4 *>(&As[(SLAB) & 1][lr * LDS_LD + lc]) =                        \
+        make_float4(ma_ != 0.f ? QA.x : 0.f, ma_ != 0.f ? QA.y : 0.f, ma_ != 0.f ? QA.z : 0.f, ma_ != 0.f ? QA.w : 0.f); \
+    *reinterpret_cast<float4 *>(&Bs[(SLAB) & 1][lr * LDS_LD + lc]) =                        \
+        make_float4(mb_ != 0.f ? QB.x : 0.f, mb_ != 0.f ? QB.y : 0.f, mb_ != 0.f ? QB.z : 0.f, mb_ != 0.f ? QB.w : 0.f); \
+  } while (0)
+#define GEMM_STEP(J, QA, QB, NA, NB)                                                        \
+  if (s0 + (J) < nslab) {                                                                   \
+    GEMM_FETCH(s0 + (J) + 4, QA, QB); /* slot J was staged for this slab already: refill */ \
+    __builtin_amdgcn_sched_barrier(0); /* or the scheduler sinks the loads to their use */  \
+    _Pragma("unroll") for (int kg = 0; kg < BK / 16; ++kg) {                                \
+      const float4 af = *reinterpret_cast<const float4 *>(&As[(J) & 1][(wm * 16 + fi) * LDS_LD + kg * 16 + fg * 4]); \
+      const float4 bf = *reinterpret_cast<const float4 *>(&Bs[(J) & 1][(wn * 16 + fi) * LDS_LD + kg * 16 + fg * 4]); \
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bf.x, acc, 0, 0, 0);                 \
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bf.y, acc, 0, 0, 0);                 \
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bf.z, acc, 0, 0, 0);                 \
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bf.w, acc, 0, 0, 0);                 \
+    }                                                                                       \
+    if (s0 + (J) + 1 < nslab) GEMM_STAGE(s0 + (J) + 1, NA, NB); /* buffer last read before the previous barrier */ \
+    __syncthreads();                                                                        \
   }
+
+  float4 a0, b0, a1, b1, a2, b2, a3, b3;
+  GEMM_FETCH(0, a0, b0);
+  GEMM_FETCH(1, a1, b1);
+  GEMM_FETCH(2, a2, b2);
+  GEMM_FETCH(3, a3, b3);
+  GEMM_STAGE(0, a0, b0);
+  __syncthreads();
+  for (int s0 = 0; s0 < nslab; s0 += 4) {  // slab parity == J parity
+    GEMM_STEP(0, a0, b0, a1, b1)
+    GEMM_STEP(1, a1, b1, a2, b2)
+    GEMM_STEP(2, a2, b2, a3, b3)
+    GEMM_STEP(3, a3, b3, a0, b0)
+  }
+#undef GEMM_STEP
+#undef GEMM_STAGE
+#undef GEMM_FETCH
   // epilogue: D register r of lane l holds row (l>>4)*4 + r, column l&15 of its 16x16 tile
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + (wn * TN + j) * 16 + fi;
-    if (n >= g.N) continue;
+  const int n = n0 + wn * 16 + fi;
+  if (n < g.N) {
     const float bz = g.bias ? g.bias[n] : 0.f;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + (wm * TM + i) * 16 + fg * 4 + r;
-        if (m >= g.M) continue;
-        float v = acc[i][j][r] + bz;
-        if (g.act == 1) v = fmaxf(v, 0.f);
-        else if (g.act == 2) v = tanhf(v);
-        else if (g.act == 3) v = powf(fmaxf(v, 0.f), g.p);
-        if (R) v += R[(size_t)m * g.ldr + n];
-        if (g.transpose_out) C[(size_t)n * g.ldc + m] = v;
-        else C[(size_t)m * g.ldc + n] = v;
-      }
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + wm * 16 + fg * 4 + r;
+      if (m >= g.M) continue;
+      float v = acc[r] + bz;
+      if (g.act == 1) v = fmaxf(v, 0.f);
+      else if (g.act == 2) v = tanhf(v);
+      else if (g.act == 3) v = powf(fmaxf(v, 0.f), g.p);
+      if (R) v += R[(size_t)m * g.ldr + n];
+      if (g.transpose_out) C[(size_t)n * g.ldc + m] = v;
+      else C[(size_t)m * g.ldc + n] = v;
+    }
   }
 }
 
@@ -244,14 +227,7 @@ __global__ void k_transpose(const float *in, float *out, int rows, int cols) {
 
 void launch_gemm_nt(const GemmArgs &g, hipStream_t s) {
   if (g.K % 16 != 0 || g.lda % 4 != 0) fail(XDTTS_ERR_BAD_ARG, "gemm: K=%d lda=%ld not supported", g.K, g.lda);
-  auto blocks = [&](int tm, int tn) { return (long)((g.N + 32 * tn - 1) / (32 * tn)) * ((g.M + 32 * tm - 1) / (32 * tm)) * g.batch; };
-  auto launch = [&](auto kern, int tm, int tn) {
-    hipLaunchKernelGGL(kern, dim3((g.N + 32 * tn - 1) / (32 * tn), (g.M + 32 * tm - 1) / (32 * tm), g.batch), dim3(256), 0, s, g);
-  };
-  static const long FILL = getenv("XDTTS_GEMM_FILL") ? atol(getenv("XDTTS_GEMM_FILL")) : (1L << 40);  // blocks wanted before a larger tile pays
-  if (blocks(2, 2) >= FILL) launch(k_gemm_nt<2, 2>, 2, 2);
-  else if (blocks(1, 2) >= FILL) launch(k_gemm_nt<1, 2>, 1, 2);
-  else launch(k_gemm_nt<1, 1>, 1, 1);
+  hipLaunchKernelGGL(k_gemm_nt, dim3((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.batch), dim3(256), 0, s, g);
   HIP_CHECK(hipGetLastError());
 }
 
