@@ -484,15 +484,23 @@ struct xdtts_tacotron2 {
 
   // postnet.onnx (mod.rs:345-355) for one chunk: frames_dev [F][80] (row stride 80) ->
   // out[m * ldc + t] for m < 80, t < F  (the (80 x F) Array2 layout), residual included.
-  void run_postnet(const float *frames_dev, int F, float *out, long ldc) {
-    const int pad = (POST_K - 1) / 2, FP = F + 2 * pad;
-    ppA.alloc((size_t)FP * POST_CH);
-    ppB.alloc((size_t)FP * POST_CH);
-    HIP_CHECK(hipMemsetAsync(ppA.p, 0, (size_t)FP * POST_CH * sizeof(float), stream));
-    HIP_CHECK(hipMemsetAsync(ppB.p, 0, (size_t)FP * POST_CH * sizeof(float), stream));
-    // layer 0 input: the frames themselves, viewed as a zero-padded [FP][80] buffer
-    HIP_CHECK(hipMemcpyAsync(ppB.p + (size_t)pad * N_MEL, frames_dev, (size_t)F * N_MEL * sizeof(float),
-                             hipMemcpyDeviceToDevice, stream));
+  // postnet.onnx (mod.rs:345-355) for n <= GEMM_RAGGED_MAX chunks in one launch per layer: chunk i has
+  // F[i] frames at frames_dev + i * frame_stride ([F][80], row stride 80) and its (80 x F[i]) result
+  // goes to out + col_off[i] with row stride ldc (the (80 x F_total) Array2 layout), residual included.
+  void run_postnet(const float *frames_dev, size_t frame_stride, const int *F, const int *col_off, int n, float *out,
+                   long ldc) {
+    const int pad = (POST_K - 1) / 2;
+    int Fmax = 0;
+    for (int i = 0; i < n; ++i) Fmax = std::max(Fmax, F[i]);
+    const size_t FP = (size_t)Fmax + 2 * pad, slot = FP * POST_CH;
+    ppA.alloc(slot * n);
+    ppB.alloc(slot * n);
+    HIP_CHECK(hipMemsetAsync(ppA.p, 0, slot * n * sizeof(float), stream));
+    HIP_CHECK(hipMemsetAsync(ppB.p, 0, slot * n * sizeof(float), stream));
+    // layer 0 input: the frames themselves, viewed as zero-padded [FP][80] buffers
+    for (int i = 0; i < n; ++i)
+      HIP_CHECK(hipMemcpyAsync(ppB.p + slot * i + (size_t)pad * N_MEL, frames_dev + frame_stride * i,
+                               (size_t)F[i] * N_MEL * sizeof(float), hipMemcpyDeviceToDevice, stream));
     float *src = ppB.p, *dst = ppA.p;
     for (int i = 0; i < POST_CONVS; ++i) {
       const ConvGemm &c = w.post_conv[i];
@@ -500,15 +508,22 @@ struct xdtts_tacotron2 {
       GemmArgs g{};
       g.A = src;
       g.lda = c.ci;
+      g.strideA = (long)slot;
       g.W = c.w.p;
       g.bias = c.b.p;
-      g.M = F;
+      g.M = Fmax;
       g.N = c.co;
       g.K = c.k * c.ci;
-      g.batch = 1;
+      g.batch = n;
+      g.ragged = 1;
+      for (int z = 0; z < n; ++z) {
+        g.Mz[z] = F[z];
+        g.Cz[z] = last ? col_off[z] : 0;
+      }
       if (!last) {
         g.C = dst + (size_t)pad * c.co;
         g.ldc = c.co;
+        g.strideC = (long)slot;
         g.act = 2;
       } else {
         g.C = out;
@@ -516,11 +531,12 @@ struct xdtts_tacotron2 {
         g.transpose_out = 1;
         g.R = frames_dev;
         g.ldr = N_MEL;
+        g.strideR = (long)frame_stride;
       }
       launch_gemm_nt(g, stream);
       if (i == 0) {
-        // ppB held the 80-channel input; clear it before it becomes a 512-channel buffer
-        HIP_CHECK(hipMemsetAsync(ppB.p, 0, (size_t)FP * POST_CH * sizeof(float), stream));
+        // ppB held the 80-channel inputs; clear it before it becomes a 512-channel buffer
+        HIP_CHECK(hipMemsetAsync(ppB.p, 0, slot * n * sizeof(float), stream));
       }
       std::swap(src, dst);
     }
@@ -578,10 +594,15 @@ struct xdtts_tacotron2 {
       total += F[b];
     }
     mel_dev.alloc((size_t)N_MEL * total);
-    int off = 0;
-    for (int b = 0; b < B; ++b) {
-      run_postnet(d.frames + (size_t)b * d.max_steps * N_MEL, F[b], mel_dev.p + off, total);
+    std::vector<int> col(B);
+    for (int b = 0, off = 0; b < B; ++b) {
+      col[b] = off;
       off += F[b];
+    }
+    for (int b = 0; b < B; b += GEMM_RAGGED_MAX) {
+      const int n = std::min(GEMM_RAGGED_MAX, B - b);
+      run_postnet(d.frames + (size_t)b * d.max_steps * N_MEL, (size_t)d.max_steps * N_MEL, F.data() + b, col.data() + b, n,
+                  mel_dev.p, total);
     }
     HIP_CHECK(hipEventRecord(ev.e[3], stream));
     *F_total = total;
@@ -1029,7 +1050,8 @@ xdtts_status xdtts_tacotron2_postnet(xdtts_tacotron2 *h, const float *frames, in
     h->frames.upload(frames, (size_t)F * N_MEL, h->stream);
     HIP_CHECK(hipStreamSynchronize(h->stream));
     h->mel_dev.alloc((size_t)N_MEL * F);
-    h->run_postnet(h->frames.p, F, h->mel_dev.p, F);
+    const int zero = 0;
+    h->run_postnet(h->frames.p, 0, &F, &zero, 1, h->mel_dev.p, F);
     HIP_CHECK(hipMemcpyAsync(mel_out, h->mel_dev.p, (size_t)N_MEL * F * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipStreamSynchronize(h->stream));
   });

@@ -36,14 +36,16 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN, z = blockIdx.z;
+  const int M = g.ragged ? g.Mz[z] : g.M;
+  if (m0 >= M) return;  // ragged batch: this item has fewer rows than the longest
   const float *A = g.A + (size_t)z * g.strideA;
-  float *C = g.C + (size_t)z * g.strideC;
+  float *C = g.C + (size_t)z * g.strideC + (g.ragged ? g.Cz[z] : 0);
   const float *R = g.R ? g.R + (size_t)z * g.strideR : nullptr;
 
   // global -> LDS assignment: thread loads one float4 of A and one of W per slab
   const int lr = tid >> 3, lc = (tid & 7) * 4;
-  const bool a_ok = m0 + lr < g.M, b_ok = n0 + lr < g.N;
-  const float *a_src = A + (size_t)(a_ok ? m0 + lr : g.M - 1) * g.lda + lc;
+  const bool a_ok = m0 + lr < M, b_ok = n0 + lr < g.N;
+  const float *a_src = A + (size_t)(a_ok ? m0 + lr : M - 1) * g.lda + lc;
   const float *b_src = g.W + (size_t)(b_ok ? n0 + lr : g.N - 1) * g.K + lc;
   const int nslab = (g.K + BK - 1) / BK;
   const int fi = lane & 15, fg = lane >> 4;
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs g) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int m = m0 + wm * 16 + fg * 4 + r;
-      if (m >= g.M) continue;
+      if (m >= M) continue;
       float v = acc[r] + bz;
       if (g.act == 1) v = fmaxf(v, 0.f);
       else if (g.act == 2) v = tanhf(v);
@@ -226,6 +228,7 @@ __global__ void k_transpose(const float *in, float *out, int rows, int cols) {
 }  // namespace
 
 void launch_gemm_nt(const GemmArgs &g, hipStream_t s) {
+  if (g.ragged && g.batch > GEMM_RAGGED_MAX) fail(XDTTS_ERR_BAD_ARG, "gemm: ragged batch of %d", g.batch);
   if (g.K % 16 != 0 || g.lda % 4 != 0) fail(XDTTS_ERR_BAD_ARG, "gemm: K=%d lda=%ld not supported", g.K, g.lda);
   hipLaunchKernelGGL(k_gemm_nt, dim3((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.batch), dim3(256), 0, s, g);
   HIP_CHECK(hipGetLastError());

@@ -78,10 +78,16 @@ struct GemmArgs {
   const float *R;     // residual, indexed like an un-transposed C; or null
   long ldr, strideR;
   int M, N, K, batch;
+  // ragged batches (post-net over chunks of different length): per-item row count and extra element
+  // offset of C, used when ragged != 0 (batch <= GEMM_RAGGED_MAX); blocks past an item's rows exit
+  int ragged;
+  int Mz[16];
+  long Cz[16];
   int act;            // 0 none, 1 relu, 2 tanh, 3 pow(max(x,0), p)
   int transpose_out;  // store C[n*ldc + m]
   float p;
 };
+constexpr int GEMM_RAGGED_MAX = 16;
 void launch_gemm_nt(const GemmArgs &g, hipStream_t s);
 
 // ---- encoder (encoder.onnx, mod.rs:379) ---------------------------------------------------------
