@@ -396,7 +396,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       const bool need[2] = {b0 < PB && s_act[2 + (b0 < PB ? b0 : 0)] != 0, false};  // (PB <= 2: chunk b0 only)
       float v[2];
       unsigned tg[2];
-      lazy_wait(g.first);
+      lazy_wait(pre ? g.first : g.xlazy);  // x(s+1) cannot arrive before the projection / prenet chain has run
       gather<2>(g.x, (unsigned)((p * GS + b0) * PRENET + i), 2u * PRENET, want, need, v, tg, pc);
 #pragma unroll
       for (int j = 0; j < 2; ++j)
@@ -557,7 +557,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
     {
       float v[PB];
       unsigned tg[PB];
-      lazy_wait(g.first);
+      lazy_wait(attn ? g.first : g.clazy);  // ctx(s) cannot arrive before the attention chain has run
       gather<PB>(g.ctx, (unsigned)(p * GS * EMB + tid), EMB, want, act, v, tg, pc);
 #pragma unroll
       for (int b = 0; b < PB; ++b)
@@ -747,6 +747,7 @@ PersistBufs persist_bufs(unsigned long long *base, int *err, int B) {
   g.mel = g.hdec + (size_t)2 * GS * DEC_RNN;
   g.err = err;
   g.lazy = PERSIST_LAZY_DEFAULT;
+  g.xlazy = g.clazy = 2;
   g.shrink = 0;
   g.spins = 0;
   g.fault = 0;

@@ -52,6 +52,7 @@ struct PersistBufs {
   int spins, fault;  // developer/test knobs: poll limit (0 = default) and a workgroup (index + 1) that never runs
   int shrink;  // 2-chunk launch: end as soon as one chunk stops (the host continues with a 1-chunk launch)
   int first;  // delay before a critical consumer's first poll, x 512 clocks (developer knob)
+  int xlazy, clazy;  // first-poll delay of the x / ctx consumers that are not their producers, x 512 clocks
   int lazy;  // late-poll delay of the off-critical-path consumers, x 512 clocks
   unsigned long long *prof;  // developer profile build only: [256][16] phase clocks, else null
 };
