@@ -688,9 +688,15 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
           xo[r] = (drop2 >> r) & 1u ? 0.f : (d.dropout_mode ? 2.f * a : a);
         }
       }
-      if (lane < 2)
-        publish(g.x + (unsigned)(((p ^ 1) * GS + rb) * PRENET + 16 * rk + wave + NW * lane), (want + 1u) | (nxt ? ACT_BIT : 0u),
-                lane ? xo[1] : xo[0]);
+      // The workgroup's 16 columns leave as ONE 128-byte store (lanes 0..15 of wave 0).  Eight waves
+      // writing two granules each into the same 128-byte line cost the x edge ~1 us per step (partial
+      // write-through writes to one line serialise at the memory side); stores to different lines
+      // (the mel rows, 128 B apart) do not show the effect.
+      if (lane < 2) s_mel[MEL_GL - 16 + wave + NW * lane] = lane ? xo[1] : xo[0];  // s_mel[81..95] is unused padding
+      __syncthreads();
+      if (tid < 16)
+        publish(g.x + (unsigned)(((p ^ 1) * GS + rb) * PRENET + 16 * rk + tid), (want + 1u) | (nxt ? ACT_BIT : 0u),
+                s_mel[MEL_GL - 16 + tid]);
     }
     PROF_MARK(10);  // prenet role: wait mel + frame store + prenet + publish x
     }
