@@ -162,6 +162,13 @@ xdtts_status xdtts_griffinlim_infer_linear(xdtts_griffinlim *g, const float *S,
 xdtts_status xdtts_griffinlim_mel_to_linear(xdtts_griffinlim *g, const float *mel,
                                             size_t n_mels, size_t n_frames, float *S_out);
 
+/* Parity hook (teacher-forced): n_iter iterations of the loop inside
+ * GriffinLim::infer (src/lib.rs:141) from a caller-held state, no final ISTFT.  S is n_bins x F;
+ * angles (unit-modulus phase estimate) and rebuilt (the previous iteration's STFT; zeros before
+ * the first) are n_bins x F x 2 (re, im) and are updated in place. */
+xdtts_status xdtts_griffinlim_step(xdtts_griffinlim *g, const float *S, float *angles,
+                                   float *rebuilt, size_t n_frames, size_t n_iter);
+
 /* ms[0] mel->linear, ms[1] iterations, ms[2] total of the last call (HIP events). */
 xdtts_status xdtts_griffinlim_last_timings(const xdtts_griffinlim *g, float ms[3]);
 
@@ -196,6 +203,10 @@ xdtts_status xdtts_audio_to_i16(const float *audio, size_t n, int16_t *pcm);
 /* write_silence -- src/lib.rs:162-176: number of zero samples of an SSML break,
  * round(sample_rate * seconds). */
 size_t xdtts_silence_samples(double seconds, uint32_t sample_rate);
+/* The same from the two integer fields of a Rust `Duration` (what write_silence receives): the
+ * conversion Duration::as_secs_f32 and the product are evaluated in f32 exactly as src/lib.rs:166
+ * does, so the sample count is bit-identical to the reference's at every .5 boundary. */
+size_t xdtts_silence_samples_duration(uint64_t secs, uint32_t nanos, uint32_t sample_rate);
 /* A complete RIFF/WAVE file with the reference's WAV_SPEC (what hound's WavWriter produces for the
  * i16 writer of src/lib.rs:152-157): 44-byte PCM header + little-endian samples. */
 xdtts_status xdtts_wav_write(const char *path, const int16_t *pcm, size_t n, uint32_t sample_rate);

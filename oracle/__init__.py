@@ -82,6 +82,7 @@ class Oracle:
         L.orc_mel_filter_bank.argtypes = [C.c_double, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p]
         L.orc_mel_to_linear.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, self.ct, C.c_void_p]
         L.orc_griffinlim.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, self.ct, C.c_void_p]
+        L.orc_griffinlim_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, self.ct]
         L.orc_dropout_keep.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int]
 
     # ---- helpers -------------------------------------------------------------------------
@@ -209,6 +210,14 @@ class Oracle:
         y = np.empty(hop * (F - 1), dtype=self.dtype)
         self.lib.orc_istft(self._p(spec), F, n_fft, hop, self._p(y))
         return y
+
+    def griffinlim_step(self, S, angles, rebuilt, n_fft=1024, hop=256, iters=1, momentum=0.99):
+        """`iters` iterations from the state (angles, rebuilt), both (n_bins, F, 2); returns the new pair."""
+        S = self._arr(S)
+        a = np.array(angles, dtype=self.dtype, order="C")
+        r = np.array(rebuilt, dtype=self.dtype, order="C")
+        self.lib.orc_griffinlim_step(self._p(S), self._p(a), self._p(r), S.shape[1], n_fft, hop, iters, momentum)
+        return a, r
 
     def griffinlim(self, S, phase0=None, seed=0, n_fft=1024, hop=256, iters=30, momentum=0.99):
         S = self._arr(S)

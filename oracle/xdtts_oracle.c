@@ -747,36 +747,56 @@ void orc_istft(const real *spec, int F, int n_fft, int hop, real *y) {
 /* librosa.griffinlim(S, n_iter, hop, momentum=0.99, init="random"), called through
  * GriffinLim::infer (src/lib.rs:141) with the parameters of src/tacotron2/mod.rs:456:
  * noverlap 768 -> hop 256, 30 iterations, momentum 0.99.                                      */
+/* One iteration of the loop above on a caller-held state: ang (unit-modulus phase estimate) and
+ * reb (the previous iteration's rebuilt STFT, zeros before the first), both [bins][F][2], are
+ * updated in place.  est/inv are scratch of ne*2 and hop*(F-1) reals.                          */
+static void griffinlim_iteration(const real *S, real *ang, real *reb, int F, int n_fft, int hop,
+                                 real alpha, real *prev, real *est, real *inv) {
+  int nb = n_fft / 2 + 1;
+  size_t ne = (size_t)nb * F;
+  int n = hop * (F - 1);
+  memcpy(prev, reb, sizeof(real) * ne * 2);
+  for (size_t i = 0; i < ne; ++i) {
+    est[2 * i] = S[i] * ang[2 * i];
+    est[2 * i + 1] = S[i] * ang[2 * i + 1];
+  }
+  orc_istft(est, F, n_fft, hop, inv);
+  orc_stft(inv, n, n_fft, hop, reb, F);
+  for (size_t i = 0; i < ne; ++i) {
+    real ar = reb[2 * i] - alpha * prev[2 * i], ai = reb[2 * i + 1] - alpha * prev[2 * i + 1];
+    real mag = (real)sqrt((double)(ar * ar + ai * ai)) + (real)1e-16;
+    ang[2 * i] = ar / mag;
+    ang[2 * i + 1] = ai / mag;
+  }
+}
+
+void orc_griffinlim_step(const real *S, real *ang, real *reb, int F, int n_fft, int hop, int iters,
+                         real momentum) {
+  int nb = n_fft / 2 + 1;
+  size_t ne = (size_t)nb * F;
+  int n = hop * (F - 1);
+  real *prev = (real *)malloc(sizeof(real) * ne * 2);
+  real *est = (real *)malloc(sizeof(real) * ne * 2);
+  real *inv = (real *)malloc(sizeof(real) * (size_t)(n > 0 ? n : 1));
+  const real alpha = momentum / ((real)1 + momentum);
+  for (int it = 0; it < iters; ++it) griffinlim_iteration(S, ang, reb, F, n_fft, hop, alpha, prev, est, inv);
+  free(prev);
+  free(est);
+  free(inv);
+}
+
 void orc_griffinlim(const real *S, const real *phase0, uint32_t seed, int F, int n_fft, int hop,
                     int iters, real momentum, real *audio) {
   int nb = n_fft / 2 + 1;
   size_t ne = (size_t)nb * F;
-  int n = hop * (F - 1);
   real *ang = (real *)malloc(sizeof(real) * ne * 2);
   real *reb = (real *)calloc(ne * 2, sizeof(real));
-  real *prev = (real *)malloc(sizeof(real) * ne * 2);
   real *est = (real *)malloc(sizeof(real) * ne * 2);
-  real *inv = (real *)malloc(sizeof(real) * (size_t)(n > 0 ? n : 1));
   if (phase0)
     memcpy(ang, phase0, sizeof(real) * ne * 2);
   else
     orc_phase_init(seed, nb, F, ang);
-  const real alpha = momentum / ((real)1 + momentum);
-  for (int it = 0; it < iters; ++it) {
-    memcpy(prev, reb, sizeof(real) * ne * 2);
-    for (size_t i = 0; i < ne; ++i) {
-      est[2 * i] = S[i] * ang[2 * i];
-      est[2 * i + 1] = S[i] * ang[2 * i + 1];
-    }
-    orc_istft(est, F, n_fft, hop, inv);
-    orc_stft(inv, n, n_fft, hop, reb, F);
-    for (size_t i = 0; i < ne; ++i) {
-      real ar = reb[2 * i] - alpha * prev[2 * i], ai = reb[2 * i + 1] - alpha * prev[2 * i + 1];
-      real mag = (real)sqrt((double)(ar * ar + ai * ai)) + (real)1e-16;
-      ang[2 * i] = ar / mag;
-      ang[2 * i + 1] = ai / mag;
-    }
-  }
+  orc_griffinlim_step(S, ang, reb, F, n_fft, hop, iters, momentum);
   for (size_t i = 0; i < ne; ++i) {
     est[2 * i] = S[i] * ang[2 * i];
     est[2 * i + 1] = S[i] * ang[2 * i + 1];
@@ -784,7 +804,5 @@ void orc_griffinlim(const real *S, const real *phase0, uint32_t seed, int F, int
   orc_istft(est, F, n_fft, hop, audio);
   free(ang);
   free(reb);
-  free(prev);
   free(est);
-  free(inv);
 }

@@ -135,6 +135,11 @@ void orc_istft(const real *spec /* bins x F x 2 */, int F, int n_fft, int hop,
 void orc_griffinlim(const real *S, const real *phase0, uint32_t seed, int F, int n_fft, int hop,
                     int iters, real momentum, real *audio);
 
+/* `iters` iterations of the loop inside orc_griffinlim on a caller-held state (teacher-forced
+ * parity hook): ang and reb are [bins][F][2], updated in place; no final ISTFT. */
+void orc_griffinlim_step(const real *S, real *ang, real *reb, int F, int n_fft, int hop, int iters,
+                         real momentum);
+
 #ifdef __cplusplus
 }
 #endif

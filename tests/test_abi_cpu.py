@@ -216,6 +216,23 @@ def test_silence_length_of_a_break(pkg):
     assert pkg.silence_samples(0.5, 16000) == 8000
 
 
+def test_silence_length_follows_the_f32_arithmetic_of_write_silence(pkg):
+    """src/lib.rs:166: `(sample_rate as f32 * duration.as_secs_f32()).round() as u32` -- every step in
+    f32 (Duration::as_secs_f32 = secs as f32 + nanos as f32 / 1e9).  Restated with numpy float32."""
+    f32 = np.float32
+    rng = np.random.Generator(np.random.PCG64(11))
+    cases = [(0, 0), (1, 0), (0, 250_000_000), (0, 20_000), (3, 999_999_999), (0, 22_675_737), (0, 68_027)]
+    cases += [(int(s), int(n)) for s, n in zip(rng.integers(0, 40, 300), rng.integers(0, 1_000_000_000, 300))]
+    # durations that land on a .5 sample boundary in exact arithmetic (odd multiples of 1/44100 s)
+    cases += [(k // 44100, int(round((k % 44100) / 44100 * 1e9))) for k in range(1, 4001, 2)]
+    for secs, nanos in cases:
+        dur = f32(f32(secs) + f32(f32(nanos) / f32(1e9)))
+        prod = f32(f32(22050) * dur)
+        want = int(np.floor(np.abs(prod) + f32(0.5)))          # f32::round: half away from zero
+        assert pkg.silence_samples_duration(secs, nanos) == want, (secs, nanos)
+        assert pkg.silence_samples(float(dur)) == want, (secs, nanos)
+
+
 def test_wav_file_has_the_reference_spec(pkg, tmp_path):
     import wave
 

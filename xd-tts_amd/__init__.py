@@ -81,6 +81,7 @@ SYMBOLS = {
     "xdtts_griffinlim_infer": (_I32, [_VP, _VP, _SZ, _SZ, C.POINTER(_PF), C.POINTER(_SZ)]),
     "xdtts_griffinlim_infer_linear": (_I32, [_VP, _VP, _VP, _SZ, _SZ, C.POINTER(_PF), C.POINTER(_SZ)]),
     "xdtts_griffinlim_mel_to_linear": (_I32, [_VP, _VP, _SZ, _SZ, _VP]),
+    "xdtts_griffinlim_step": (_I32, [_VP, _VP, _VP, _VP, _SZ, _SZ]),
     "xdtts_griffinlim_last_timings": (_I32, [_VP, C.POINTER(C.c_float * 3)]),
     "xdtts_griffinlim_free": (None, [_VP]),
     "xdtts_synthesize_ids": (_I32, [_VP, _VP, _VP, _SZ, _VP, _SZ, C.POINTER(InferOpts), C.POINTER(_PF), C.POINTER(_SZ), C.POINTER(_PF), C.POINTER(_SZ)]),
@@ -91,6 +92,7 @@ SYMBOLS = {
     "xdtts_find_splits": (_I32, [_VP, _SZ, _SZ, _VP, _SZ, C.POINTER(_SZ)]),
     "xdtts_audio_to_i16": (_I32, [_VP, _SZ, _VP]),
     "xdtts_silence_samples": (_SZ, [C.c_double, _U32]),
+    "xdtts_silence_samples_duration": (_SZ, [C.c_uint64, _U32, _U32]),
     "xdtts_wav_write": (_I32, [C.c_char_p, _VP, _SZ, _U32]),
     "xdtts_npy_write_f32": (_I32, [C.c_char_p, _VP, _SZ, _SZ]),
     "xdtts_real_time_factor": (C.c_double, [C.c_double, _SZ]),
@@ -184,6 +186,11 @@ def audio_to_i16(audio):
 def silence_samples(seconds, sample_rate=SAMPLE_RATE):
     """write_silence (src/lib.rs:162-176)."""
     return int(lib.xdtts_silence_samples(float(seconds), int(sample_rate)))
+
+
+def silence_samples_duration(secs, nanos, sample_rate=SAMPLE_RATE):
+    """write_silence (src/lib.rs:162-176) from a Rust Duration's (secs, subsec_nanos): f32 throughout."""
+    return int(lib.xdtts_silence_samples_duration(int(secs), int(nanos), int(sample_rate)))
 
 
 def write_wav(path, audio, sample_rate=SAMPLE_RATE):
@@ -372,6 +379,15 @@ class GriffinLim:
         audio, n = _PF(), C.c_size_t()
         _check(lib.xdtts_griffinlim_infer_linear(self._h, _ptr(S), None if p0 is None else _ptr(p0), S.shape[1], iters, C.byref(audio), C.byref(n)))
         return _take(audio, n.value, (n.value,))
+
+    def step(self, S, angles, rebuilt, n_iter=1):
+        """Parity hook: n_iter iterations from the state (angles, rebuilt), both (n_bins, F, 2); returns
+        the new (angles, rebuilt)."""
+        S = np.ascontiguousarray(S, dtype=np.float32)
+        a = np.array(angles, dtype=np.float32, order="C")
+        r = np.array(rebuilt, dtype=np.float32, order="C")
+        _check(lib.xdtts_griffinlim_step(self._h, _ptr(S), _ptr(a), _ptr(r), S.shape[1], n_iter))
+        return a, r
 
     def mel_to_linear(self, mel):
         mel = np.ascontiguousarray(mel, dtype=np.float32)

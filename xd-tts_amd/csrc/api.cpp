@@ -84,11 +84,8 @@ struct PinnedPool {
   void put(void *p) {
     std::unique_lock<std::mutex> lk(mu);
     auto it = live.find(p);
-    if (it == live.end()) {  // not ours (or already released): leave it to the runtime
-      lk.unlock();
-      (void)hipHostFree(p);
-      return;
-    }
+    if (it == live.end()) return;  // not ours, or already released (a double xdtts_free): nothing to do --
+                                   // freeing it here could hand a buffer in `spare` back to the runtime
     const size_t cap = it->second;
     live.erase(it);
     if (spare_bytes + cap <= MAX_SPARE) {
@@ -107,6 +104,25 @@ PinnedPool &pinned_pool() {
 }  // namespace
 
 static float *pinned_alloc(size_t n_floats) { return pinned_pool().get(std::max<size_t>(n_floats, 1) * sizeof(float)); }
+
+// Owns a pinned output buffer until the call has succeeded: an exception on the way (a failed
+// copy, a later stage that throws) returns it to the pool instead of leaving it in `live` forever.
+struct PinnedGuard {
+  float *p = nullptr;
+  PinnedGuard() = default;
+  explicit PinnedGuard(size_t n_floats) : p(pinned_alloc(n_floats)) {}
+  PinnedGuard(PinnedGuard &&o) noexcept : p(o.p) { o.p = nullptr; }
+  PinnedGuard(const PinnedGuard &) = delete;
+  PinnedGuard &operator=(const PinnedGuard &) = delete;
+  ~PinnedGuard() {
+    if (p) pinned_pool().put(p);
+  }
+  float *release() {
+    float *r = p;
+    p = nullptr;
+    return r;
+  }
+};
 
 struct Events {
   hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -721,6 +737,14 @@ struct xdtts_griffinlim {
     launch_gemm_nt(a, stream);
   }
 
+  // The iteration engine on the current state (ang, tprev, S in place): n_iter iterations and, when
+  // audio_out is given, the final ISTFT into it.  Returns the buffer holding the final angles.
+  const float2 *run_iterations(const GlBufs &g, int n_iter, float alpha, float *audio_out) {
+    const float2 *fin = launch_gl_iterate(g, n_iter, alpha, stream);
+    if (audio_out) launch_gl_final(g, fin, audio_out, stream);
+    return fin;
+  }
+
   // phase init + iterations + final ISTFT; S already in place.  Result in audio (device).
   void iterate(const GlBufs &g, const float *phase0_dev, int n_iter) {
     launch_gl_phase_init(g, seed, phase0_dev, stream);
@@ -950,14 +974,10 @@ xdtts_status xdtts_tacotron2_infer_ids(xdtts_tacotron2 *h, const int64_t *ids, s
     chunks_from_splits(ids, n, splits, n_splits, o.max_chunk, padded, lens);
     int total = 0;
     h->infer_batch_device(padded.data(), lens.data(), (int)lens.size(), o.max_chunk, o, nullptr, &total);
-    float *host = pinned_alloc((size_t)N_MEL * total);
-    hipError_t e = hipMemcpyAsync(host, h->mel_dev.p, (size_t)N_MEL * total * sizeof(float), hipMemcpyDeviceToHost, h->stream);
-    if (e != hipSuccess) {
-      xdtts_free(host);
-      HIP_CHECK(e);
-    }
+    PinnedGuard host((size_t)N_MEL * total);
+    HIP_CHECK(hipMemcpyAsync(host.p, h->mel_dev.p, (size_t)N_MEL * total * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     h->finish_timings();
-    *mel = host;
+    *mel = host.release();
     *n_frames = (size_t)total;
   });
 }
@@ -984,14 +1004,19 @@ xdtts_status xdtts_tacotron2_infer_batch(xdtts_tacotron2 *h, const int64_t *ids,
     std::vector<float> all((size_t)N_MEL * total);
     HIP_CHECK(hipMemcpyAsync(all.data(), h->mel_dev.p, all.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     h->finish_timings();
+    std::vector<PinnedGuard> out;  // all B buffers exist before the first one is handed over
+    out.reserve((size_t)B);
+    for (int b = 0; b < B; ++b) out.emplace_back((size_t)N_MEL * F[b]);
     int off = 0;
     for (int b = 0; b < B; ++b) {
-      float *m = pinned_alloc((size_t)N_MEL * F[b]);
+      float *m = out[(size_t)b].p;
       for (int r = 0; r < N_MEL; ++r)
         std::memcpy(m + (size_t)r * F[b], all.data() + (size_t)r * total + off, sizeof(float) * F[b]);
-      mels[b] = m;
-      n_frames[b] = (size_t)F[b];
       off += F[b];
+    }
+    for (int b = 0; b < B; ++b) {
+      mels[b] = out[(size_t)b].release();
+      n_frames[b] = (size_t)F[b];
     }
   });
 }
@@ -1143,14 +1168,10 @@ xdtts_status xdtts_griffinlim_set_seed(xdtts_griffinlim *g, uint32_t seed) {
 
 static void gl_fetch_audio(xdtts_griffinlim *g, int F, float **audio, size_t *n_samples) {
   const size_t N = (size_t)g->hop * (size_t)(F - 1);
-  float *host = pinned_alloc(N);
-  hipError_t e = hipMemcpyAsync(host, g->audio.p, N * sizeof(float), hipMemcpyDeviceToHost, g->stream);
-  if (e != hipSuccess) {
-    xdtts_free(host);
-    HIP_CHECK(e);
-  }
+  PinnedGuard host(N);
+  HIP_CHECK(hipMemcpyAsync(host.p, g->audio.p, N * sizeof(float), hipMemcpyDeviceToHost, g->stream));
   g->finish_timings();
-  *audio = host;
+  *audio = host.release();
   *n_samples = N;
 }
 
@@ -1228,6 +1249,34 @@ xdtts_status xdtts_griffinlim_infer_linear(xdtts_griffinlim *g, const float *S, 
   });
 }
 
+// Parity hook: `n_iter` Griffin-Lim iterations (no final ISTFT) from a caller-held state.
+xdtts_status xdtts_griffinlim_step(xdtts_griffinlim *g, const float *S, float *angles, float *rebuilt, size_t n_frames,
+                                   size_t n_iter) {
+  return guard([&] {
+    if (!g || !S || !angles || !rebuilt) fail(XDTTS_ERR_BAD_ARG, "null argument");
+    if (n_frames < 2) fail(XDTTS_ERR_BAD_ARG, "need at least 2 frames, got %zu", n_frames);
+    if (n_iter == 0) n_iter = 1;
+    std::lock_guard<std::mutex> lk(g->mu);
+    HIP_CHECK(hipSetDevice(g->device));
+    const int F = (int)n_frames;
+    const size_t ne = (size_t)F * g->nb;
+    GlBufs b = g->bufs(F);
+    g->frames.upload(S, ne, g->stream);
+    launch_transpose(g->frames.p, g->S.p, g->nb, F, g->stream);
+    g->phase0.alloc(ne * 4);  // staging: angles then rebuilt, (nb x F x 2) each
+    HIP_CHECK(hipMemcpyAsync(g->phase0.p, angles, ne * 2 * sizeof(float), hipMemcpyHostToDevice, g->stream));
+    HIP_CHECK(hipMemcpyAsync(g->phase0.p + ne * 2, rebuilt, ne * 2 * sizeof(float), hipMemcpyHostToDevice, g->stream));
+    launch_gl_state_import(b, g->phase0.p, g->phase0.p + ne * 2, g->stream);
+    launch_gl_prepare(b, g->stream);
+    const float alpha = g->momentum / (1.0f + g->momentum);
+    const float2 *fin = g->run_iterations(b, (int)n_iter, alpha, nullptr);
+    launch_gl_state_export(b, fin, g->phase0.p, g->phase0.p + ne * 2, g->stream);
+    HIP_CHECK(hipMemcpyAsync(angles, g->phase0.p, ne * 2 * sizeof(float), hipMemcpyDeviceToHost, g->stream));
+    HIP_CHECK(hipMemcpyAsync(rebuilt, g->phase0.p + ne * 2, ne * 2 * sizeof(float), hipMemcpyDeviceToHost, g->stream));
+    HIP_CHECK(hipStreamSynchronize(g->stream));
+  });
+}
+
 xdtts_status xdtts_griffinlim_last_timings(const xdtts_griffinlim *g, float ms[3]) {
   return guard([&] {
     if (!g || !ms) fail(XDTTS_ERR_BAD_ARG, "null argument");
@@ -1262,12 +1311,12 @@ xdtts_status xdtts_synthesize_ids(xdtts_tacotron2 *h, xdtts_griffinlim *g, const
     int total = 0;
     h->infer_batch_device(padded.data(), lens.data(), (int)lens.size(), o.max_chunk, o, nullptr, &total);
     if (total < 2) fail(XDTTS_ERR_BAD_ARG, "mel has %d frame(s); the vocoder needs at least 2", total);
-    float *mel_host = pinned_alloc((size_t)N_MEL * total);
-    HIP_CHECK(hipMemcpyAsync(mel_host, h->mel_dev.p, (size_t)N_MEL * total * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    PinnedGuard mel_host((size_t)N_MEL * total);
+    HIP_CHECK(hipMemcpyAsync(mel_host.p, h->mel_dev.p, (size_t)N_MEL * total * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     h->finish_timings();  // stream sync: the mel is complete in HBM before the vocoder stream reads it
     gl_run_from_device_mel(g, h->mel_dev.p, total);
     gl_fetch_audio(g, total, audio, n_samples);
-    *mel = mel_host;
+    *mel = mel_host.release();
     *n_frames = (size_t)total;
   });
 }

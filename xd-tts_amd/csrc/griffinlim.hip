@@ -407,6 +407,28 @@ __global__ void k_exp_transpose(const float *mel, float *out, int n_mels, int F)
   out[i] = expf(mel[(size_t)m * F + f]);
 }
 
+// Parity hook (xdtts_griffinlim_step): the iteration state crosses the boundary in the crate's
+// (n_bins x F x 2) layout; on the device it is [F][nb] float2.
+__global__ void k_state_import(GlBufs g, const float *ang_in, const float *reb_in) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= g.F * g.nb) return;
+  const int f = i / g.nb, k = i % g.nb;
+  const size_t o = ((size_t)k * g.F + f) * 2;
+  g.ang[i] = make_float2(ang_in[o], ang_in[o + 1]);
+  g.tprev[i] = make_float2(reb_in[o], reb_in[o + 1]);
+}
+__global__ void k_state_export(GlBufs g, const float2 *ang, float *ang_out, float *reb_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= g.F * g.nb) return;
+  const int f = i / g.nb, k = i % g.nb;
+  const size_t o = ((size_t)k * g.F + f) * 2;
+  const float2 a = ang[i], r = g.tprev[i];
+  ang_out[o] = a.x;
+  ang_out[o + 1] = a.y;
+  reb_out[o] = r.x;
+  reb_out[o + 1] = r.y;
+}
+
 }  // namespace
 
 void launch_gl_exp_transpose(const float *mel_80xF, float *out_Fx80, int n_mels, int F, hipStream_t s) {
@@ -427,12 +449,24 @@ void launch_gl_prepare(const GlBufs &g, hipStream_t s) {
   HIP_CHECK(hipGetLastError());
 }
 
-// Enqueues n_iter iterations + the final ISTFT into `audio`.  Frame counts of 16 and more run the
-// fused one-launch iteration with the angles ping-ponging between g.ang and g.ang2; tiny inputs
-// (whose reflect padding folds more than once) use the two-kernel iteration in place.
-void launch_gl_iterations(const GlBufs &g, int n_iter, float alpha, float *audio, hipStream_t s) {
+void launch_gl_state_import(const GlBufs &g, const float *ang_in, const float *reb_in, hipStream_t s) {
+  const int n = g.F * g.nb;
+  hipLaunchKernelGGL(k_state_import, dim3((n + 255) / 256), dim3(256), 0, s, g, ang_in, reb_in);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_gl_state_export(const GlBufs &g, const float2 *ang, float *ang_out, float *reb_out, hipStream_t s) {
+  const int n = g.F * g.nb;
+  hipLaunchKernelGGL(k_state_export, dim3((n + 255) / 256), dim3(256), 0, s, g, ang, ang_out, reb_out);
+  HIP_CHECK(hipGetLastError());
+}
+
+// Enqueues n_iter iterations (no final ISTFT) and returns the buffer that holds the final angles.
+// Frame counts of 16 and more run the fused one-launch iteration with the angles ping-ponging
+// between g.ang and g.ang2; tiny inputs (whose reflect padding folds more than once) use the
+// two-kernel iteration in place.
+const float2 *launch_gl_iterate(const GlBufs &g, int n_iter, float alpha, hipStream_t s) {
   const int nblk = (g.F + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK;
-  const int N = g.hop * (g.F - 1);
   const float2 *final_ang = g.ang;
   if (g.F >= 16) {
     constexpr int TF = 4;
@@ -453,9 +487,21 @@ void launch_gl_iterations(const GlBufs &g, int n_iter, float alpha, float *audio
       hipLaunchKernelGGL(k_stft_update, dim3(nblk), dim3(256), 0, s, g, alpha);
     }
   }
-  hipLaunchKernelGGL(k_istft_frames, dim3(nblk), dim3(256), 0, s, g, final_ang);
+  HIP_CHECK(hipGetLastError());
+  return final_ang;
+}
+
+// The final ISTFT of `ang` into `audio`.
+void launch_gl_final(const GlBufs &g, const float2 *ang, float *audio, hipStream_t s) {
+  const int nblk = (g.F + FRAMES_PER_BLOCK - 1) / FRAMES_PER_BLOCK;
+  const int N = g.hop * (g.F - 1);
+  hipLaunchKernelGGL(k_istft_frames, dim3(nblk), dim3(256), 0, s, g, ang);
   hipLaunchKernelGGL(k_overlap_add, dim3((N + 255) / 256), dim3(256), 0, s, g, audio);
   HIP_CHECK(hipGetLastError());
+}
+
+void launch_gl_iterations(const GlBufs &g, int n_iter, float alpha, float *audio, hipStream_t s) {
+  launch_gl_final(g, launch_gl_iterate(g, n_iter, alpha, s), audio, s);
 }
 
 }  // namespace xdtts

@@ -197,8 +197,23 @@ xdtts_status xdtts_audio_to_i16(const float *audio, size_t n, int16_t *pcm) {
 }
 
 size_t xdtts_silence_samples(double seconds, uint32_t sample_rate) {
-  // `(sample_rate as f32 * duration.as_secs_f32()).round() as u32`, src/lib.rs:166
-  const float v = std::round((float)sample_rate * (float)seconds);
+  // `(sample_rate as f32 * duration.as_secs_f32()).round() as u32`, src/lib.rs:166 -- the product
+  // and the rounding are f32 operations (volatile: no contraction or wider evaluation)
+  volatile float sr = (float)sample_rate, secs = (float)seconds;
+  volatile float prod = sr * secs;
+  const float v = std::round(prod);
+  return v > 0.f ? (size_t)v : 0;
+}
+
+size_t xdtts_silence_samples_duration(uint64_t secs, uint32_t nanos, uint32_t sample_rate) {
+  // Duration::as_secs_f32 (Rust std): `(secs as f32) + (nanos as f32) / (NANOS_PER_SEC as f32)`,
+  // every operation in f32; then src/lib.rs:166 as above.
+  volatile float fs = (float)secs, fn = (float)nanos;
+  volatile float frac = fn / 1000000000.0f;
+  volatile float dur = fs + frac;
+  volatile float sr = (float)sample_rate;
+  volatile float prod = sr * dur;
+  const float v = std::round(prod);
   return v > 0.f ? (size_t)v : 0;
 }
 

@@ -119,6 +119,11 @@ void launch_gl_exp_transpose(const float *mel_80xF, float *out_Fx80, int n_mels,
 void launch_gl_phase_init(const GlBufs &g, uint32_t seed, const float *phase0_dev, hipStream_t s);
 void launch_gl_prepare(const GlBufs &g, hipStream_t s);                  // wss_inv for this F
 void launch_gl_iterations(const GlBufs &g, int n_iter, float alpha, float *audio, hipStream_t s);  // + final ISTFT
+const float2 *launch_gl_iterate(const GlBufs &g, int n_iter, float alpha, hipStream_t s);         // iterations only
+void launch_gl_final(const GlBufs &g, const float2 *ang, float *audio, hipStream_t s);            // final ISTFT
+// parity hook: iteration state in the crate's (n_bins x F x 2) layout <-> device [F][nb] float2
+void launch_gl_state_import(const GlBufs &g, const float *ang_in, const float *reb_in, hipStream_t s);
+void launch_gl_state_export(const GlBufs &g, const float2 *ang, float *ang_out, float *reb_out, hipStream_t s);
 void launch_transpose(const float *in, float *out, int rows, int cols, hipStream_t s);
 
 }  // namespace xdtts
