@@ -5,6 +5,17 @@ import sys
 import numpy as np
 import pytest
 
+# Load order matters in a process that uses both PyTorch-ROCm and libxdtts_hip.so: torch's wheel
+# bundles its own libamdhip64 / libhsa-runtime64 and asks for them by file name, so if the system
+# HIP runtime is mapped first (by importing the product package) torch maps a SECOND runtime next to
+# it and the two fight over the device (observed: a device-side error word that the host never sees).
+# With torch first, libxdtts_hip.so's DT_NEEDED libamdhip64.so.7 resolves to the copy already mapped.
+# bench.py imports torch first for the same reason; a process without torch has one runtime anyway.
+try:
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

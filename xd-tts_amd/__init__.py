@@ -19,7 +19,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libxdtts_hip.so")
+LIB_PATH = os.environ.get("XDTTS_LIB") or os.path.join(_HERE, "libxdtts_hip.so")  # XDTTS_LIB: developer builds (profiling)
 
 N_MEL = 80
 EMB = 512

@@ -687,9 +687,20 @@ struct xdtts_griffinlim {
   int graph_iters = -1;
   float graph_alpha = 0.f;
   const float *graph_audio = nullptr;
-  DevBuf<float2> tw, ang, ang2, tprev;
+  DevBuf<float2> tw, ang, ang2, tprev, tprev2;  // tprev2: final rebuilt spectrum of the parity hook
+  // persistent engine (griffinlim.hip: k_gl_persistent)
+  DevBuf<unsigned long long> xch;  // neighbour-overlap granules
+  DevBuf<int> gl_err;
+  int *host_err = nullptr;         // pinned
+  unsigned epoch = 0;              // tag base; tags are never reused while xch lives
+  int persist_state = -1;          // -1 unknown, 0 unavailable / demoted, 1 usable
+  int n_cu = 0;
+  bool last_persistent = false;    // the last run_iterations used the persistent engine
+  int demoted_calls = 0;           // calls since a demotion (the engine is probed again after PROBE_AFTER)
+  static constexpr int PROBE_AFTER = 64;
 
   ~xdtts_griffinlim() {
+    if (host_err) (void)hipHostFree(host_err);
     if (graph) (void)hipGraphExecDestroy(graph);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -737,12 +748,98 @@ struct xdtts_griffinlim {
     launch_gemm_nt(a, stream);
   }
 
+  bool persistent_usable() {
+    const char *e = getenv("XDTTS_GL");
+    if (e && std::string(e) == "launch") return false;  // developer comparison aid: launch-per-iteration engine
+    if (persist_state < 0) persist_state = gl_persistent_supported(device, &n_cu) ? 1 : 0;
+    if (persist_state == 0 && n_cu > 0 && ++demoted_calls >= PROBE_AFTER) {  // a transient cause may be gone
+      demoted_calls = 0;
+      persist_state = 1;
+    }
+    return persist_state == 1;
+  }
+
   // The iteration engine on the current state (ang, tprev, S in place): n_iter iterations and, when
-  // audio_out is given, the final ISTFT into it.  Returns the buffer holding the final angles.
-  const float2 *run_iterations(const GlBufs &g, int n_iter, float alpha, float *audio_out) {
+  // audio_out is given, the final ISTFT into it.  Returns the buffer holding the final angles
+  // (*tprev_fin: the final rebuilt spectrum).  Small-to-medium frame counts run as ONE persistent
+  // launch; the caller holds the chip lock until the stream has drained and then asks
+  // persistent_failed().
+  const float2 *run_iterations(const GlBufs &g, int n_iter, float alpha, float *audio_out, bool want_state = false,
+                               const float2 **tprev_fin = nullptr) {
+    int TF = 0, nblk = 0;
+    last_persistent = false;
+    if (tprev_fin) *tprev_fin = g.tprev;
+    if (persistent_usable() && gl_persistent_plan(g.F, n_cu, &TF, &nblk)) {
+      const size_t words = gl_persistent_xch_words(nblk);
+      if (words > xch.n || epoch > 0x7fff0000u - (unsigned)n_iter) {  // fresh (or wrapped) tags: clear every granule
+        xch.alloc(words);
+        HIP_CHECK(hipMemsetAsync(xch.p, 0, xch.n * sizeof(unsigned long long), stream));
+        epoch = 0;
+      }
+      if (!gl_err.p) {
+        gl_err.alloc(1);
+        HIP_CHECK(hipMemsetAsync(gl_err.p, 0, sizeof(int), stream));
+        HIP_CHECK(hipHostMalloc((void **)&host_err, sizeof(int), hipHostMallocDefault));
+      }
+      GlPersist p{};
+      p.xch = xch.p;
+      p.err = gl_err.p;
+      p.epoch = epoch;
+      p.nblk = nblk;
+      p.TF = TF;
+      if (const char *sp = getenv("XDTTS_GL_SPINS")) p.spins = atoi(sp);  // test hook
+      epoch += (unsigned)n_iter + 2u;
+      if (want_state) {
+        p.ang_out = g.ang2;
+        tprev2.alloc((size_t)g.F * g.nb);
+        p.tprev_out = tprev2.p;
+        if (tprev_fin) *tprev_fin = p.tprev_out;
+      }
+#ifdef XDTTS_GL_PROFILE
+      static DevBuf<unsigned long long> prof;
+      prof.alloc(256 * 8);
+      p.prof = prof.p;
+#endif
+      launch_gl_persistent(g, p, g.ang, g.tprev, n_iter, alpha, audio_out, stream);
+#ifdef XDTTS_GL_PROFILE
+      if (const char *path = getenv("XDTTS_GL_PROFILE")) {
+        std::vector<unsigned long long> hp((size_t)nblk * 8);
+        HIP_CHECK(hipMemcpyAsync(hp.data(), prof.p, hp.size() * 8, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        if (FILE *f = fopen(path, "w")) {
+          fprintf(f, "%d %d\n", nblk, n_iter);
+          for (int c = 0; c < nblk; ++c) {
+            for (int i = 0; i < 8; ++i) fprintf(f, "%llu ", hp[(size_t)c * 8 + i]);
+            fprintf(f, "\n");
+          }
+          fclose(f);
+        }
+      }
+#endif
+      last_persistent = true;
+      return want_state ? g.ang2 : g.ang;
+    }
     const float2 *fin = launch_gl_iterate(g, n_iter, alpha, stream);
     if (audio_out) launch_gl_final(g, fin, audio_out, stream);
     return fin;
+  }
+
+  // After the stream has drained: did a bounded spin of the persistent launch run out (grid not
+  // co-resident)?  If so the handle is demoted to the launch-per-iteration engine (and probes the
+  // persistent one again after PROBE_AFTER calls); the input state is intact, the caller re-runs.
+  bool persistent_failed() {
+    if (!last_persistent) return false;
+    HIP_CHECK(hipMemcpyAsync(host_err, gl_err.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    if (!*host_err) return false;
+    HIP_CHECK(hipMemsetAsync(gl_err.p, 0, sizeof(int), stream));
+    HIP_CHECK(hipMemsetAsync(xch.p, 0, xch.n * sizeof(unsigned long long), stream));
+    epoch = 0;
+    persist_state = 0;
+    demoted_calls = 0;
+    std::fprintf(stderr, "libxdtts_hip: persistent Griffin-Lim exchange timed out (grid not co-resident); "
+                         "this handle uses the launch-per-iteration engine for the next %d calls\n", PROBE_AFTER);
+    return true;
   }
 
   // phase init + iterations + final ISTFT; S already in place.  Result in audio (device).
@@ -750,7 +847,13 @@ struct xdtts_griffinlim {
     launch_gl_phase_init(g, seed, phase0_dev, stream);
     launch_gl_prepare(g, stream);
     const float alpha = momentum / (1.0f + momentum);
-    // the iteration loop is launch-bound (2 short kernels per iteration): replay it as one hipGraph
+    int TF = 0, nblk = 0;
+    if (persistent_usable() && gl_persistent_plan(g.F, n_cu, &TF, &nblk)) {
+      run_iterations(g, n_iter, alpha, audio.p);  // one launch: nothing to capture
+      return;
+    }
+    last_persistent = false;
+    // the launch-per-iteration loop is launch-bound: replay it as one hipGraph
     if (!graph || std::memcmp(&graph_key, &g, sizeof g) != 0 || graph_iters != n_iter || graph_alpha != alpha ||
         graph_audio != audio.p) {
       if (graph) {
@@ -1166,22 +1269,37 @@ xdtts_status xdtts_griffinlim_set_seed(xdtts_griffinlim *g, uint32_t seed) {
   });
 }
 
-static void gl_fetch_audio(xdtts_griffinlim *g, int F, float **audio, size_t *n_samples) {
-  const size_t N = (size_t)g->hop * (size_t)(F - 1);
-  PinnedGuard host(N);
-  HIP_CHECK(hipMemcpyAsync(host.p, g->audio.p, N * sizeof(float), hipMemcpyDeviceToHost, g->stream));
-  g->finish_timings();
-  *audio = host.release();
-  *n_samples = N;
+// Phase init + iterations + final ISTFT on the S in place, then the audio to a pinned host buffer.
+// The persistent engine needs its grid co-resident: the chip lock is held from the launch until the
+// stream has drained; a timed-out exchange demotes the handle and the request runs again on the
+// launch-per-iteration engine (S and the phase seed are intact).
+static void gl_iterate_and_fetch(xdtts_griffinlim *g, const GlBufs &b, const float *phase0_dev, int iters, float **audio,
+                                 size_t *n_samples) {
+  const size_t N = (size_t)g->hop * (size_t)(b.F - 1);
+  std::lock_guard<std::recursive_mutex> chip(chip_mutex(g->device));
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    g->iterate(b, phase0_dev, iters);
+    HIP_CHECK(hipEventRecord(g->ev.e[2], g->stream));
+    PinnedGuard host(N);
+    HIP_CHECK(hipMemcpyAsync(host.p, g->audio.p, N * sizeof(float), hipMemcpyDeviceToHost, g->stream));
+    g->finish_timings();
+    if (g->persistent_failed()) {
+      HIP_CHECK(hipEventRecord(g->ev.e[1], g->stream));  // time the run that counts
+      continue;
+    }
+    *audio = host.release();
+    *n_samples = N;
+    return;
+  }
+  fail(XDTTS_ERR_HIP, "Griffin-Lim: the fallback engine reported an exchange failure");
 }
 
-static void gl_run_from_device_mel(xdtts_griffinlim *g, const float *mel_dev_ptr, int F) {
+static void gl_run_from_device_mel(xdtts_griffinlim *g, const float *mel_dev_ptr, int F, float **audio, size_t *n_samples) {
   GlBufs b = g->bufs(F);
   HIP_CHECK(hipEventRecord(g->ev.e[0], g->stream));
   g->mel_to_linear(mel_dev_ptr, F);
   HIP_CHECK(hipEventRecord(g->ev.e[1], g->stream));
-  g->iterate(b, nullptr, g->iters);
-  HIP_CHECK(hipEventRecord(g->ev.e[2], g->stream));
+  gl_iterate_and_fetch(g, b, nullptr, g->iters, audio, n_samples);
 }
 
 xdtts_status xdtts_griffinlim_infer(xdtts_griffinlim *g, const float *mel, size_t n_mels, size_t n_frames,
@@ -1196,8 +1314,7 @@ xdtts_status xdtts_griffinlim_infer(xdtts_griffinlim *g, const float *mel, size_
     HIP_CHECK(hipSetDevice(g->device));
     g->mel_in.upload(mel, n_mels * n_frames, g->stream);
     HIP_CHECK(hipStreamSynchronize(g->stream));
-    gl_run_from_device_mel(g, g->mel_in.p, (int)n_frames);
-    gl_fetch_audio(g, (int)n_frames, audio, n_samples);
+    gl_run_from_device_mel(g, g->mel_in.p, (int)n_frames, audio, n_samples);
   });
 }
 
@@ -1243,9 +1360,7 @@ xdtts_status xdtts_griffinlim_infer_linear(xdtts_griffinlim *g, const float *S, 
     HIP_CHECK(hipStreamSynchronize(g->stream));
     HIP_CHECK(hipEventRecord(g->ev.e[0], g->stream));
     HIP_CHECK(hipEventRecord(g->ev.e[1], g->stream));
-    g->iterate(b, p0, iters ? (int)iters : g->iters);
-    HIP_CHECK(hipEventRecord(g->ev.e[2], g->stream));
-    gl_fetch_audio(g, F, audio, n_samples);
+    gl_iterate_and_fetch(g, b, p0, iters ? (int)iters : g->iters, audio, n_samples);
   });
 }
 
@@ -1269,8 +1384,21 @@ xdtts_status xdtts_griffinlim_step(xdtts_griffinlim *g, const float *S, float *a
     launch_gl_state_import(b, g->phase0.p, g->phase0.p + ne * 2, g->stream);
     launch_gl_prepare(b, g->stream);
     const float alpha = g->momentum / (1.0f + g->momentum);
-    const float2 *fin = g->run_iterations(b, (int)n_iter, alpha, nullptr);
-    launch_gl_state_export(b, fin, g->phase0.p, g->phase0.p + ne * 2, g->stream);
+    std::lock_guard<std::recursive_mutex> chip(chip_mutex(g->device));
+    for (int attempt = 0;; ++attempt) {
+      const float2 *tp = nullptr;
+      const float2 *fin = g->run_iterations(b, (int)n_iter, alpha, nullptr, true, &tp);
+      if (!g->last_persistent) {  // the launch engine updates the state in place
+        launch_gl_state_export(b, fin, b.tprev, g->phase0.p, g->phase0.p + ne * 2, g->stream);
+        break;
+      }
+      HIP_CHECK(hipStreamSynchronize(g->stream));
+      if (!g->persistent_failed()) {
+        launch_gl_state_export(b, fin, tp, g->phase0.p, g->phase0.p + ne * 2, g->stream);
+        break;
+      }
+      if (attempt) fail(XDTTS_ERR_HIP, "Griffin-Lim step: exchange failure");
+    }
     HIP_CHECK(hipMemcpyAsync(angles, g->phase0.p, ne * 2 * sizeof(float), hipMemcpyDeviceToHost, g->stream));
     HIP_CHECK(hipMemcpyAsync(rebuilt, g->phase0.p + ne * 2, ne * 2 * sizeof(float), hipMemcpyDeviceToHost, g->stream));
     HIP_CHECK(hipStreamSynchronize(g->stream));
@@ -1314,8 +1442,7 @@ xdtts_status xdtts_synthesize_ids(xdtts_tacotron2 *h, xdtts_griffinlim *g, const
     PinnedGuard mel_host((size_t)N_MEL * total);
     HIP_CHECK(hipMemcpyAsync(mel_host.p, h->mel_dev.p, (size_t)N_MEL * total * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     h->finish_timings();  // stream sync: the mel is complete in HBM before the vocoder stream reads it
-    gl_run_from_device_mel(g, h->mel_dev.p, total);
-    gl_fetch_audio(g, total, audio, n_samples);
+    gl_run_from_device_mel(g, h->mel_dev.p, total, audio, n_samples);
     *mel = mel_host.release();
     *n_frames = (size_t)total;
   });

@@ -373,6 +373,319 @@ __global__ __launch_bounds__(64 * (TF + 6)) void k_gl_fused(GlBufs g, const floa
   stft_update_store(g, ang_out, f, lane, buf, alpha, pv);
 }
 
+// ================================================================================================
+// Persistent Griffin-Lim: ALL iterations and the final ISTFT in ONE launch.
+//
+// The per-iteration launch above is bound by latency, not bytes: a frame is one wave's dependent
+// inverse-FFT -> overlap-add -> FFT chain, the halo makes every block redo 2.5x the inverse
+// transforms, S / angles / tprev make a round trip through HBM per iteration and every iteration
+// pays a launch boundary.  Here a workgroup owns 3..TF consecutive frames for the whole call
+// (wave w = frame f0 + w) and keeps their S, angles and previous rebuilt spectrum in LDS; what
+// crosses workgroups per iteration is only the overlap of the windowed time frames with the two
+// neighbours' sample ranges: 768 pre-summed samples each way (at hop = n_fft/4 a sample is covered
+// by four frames, so a block's range [256 f0, 256 (f0 + n) + 768) takes three frames' tails from
+// the left neighbour and three frames' heads from the right one).  They travel as data-tagged
+// 8-byte granules {tag = epoch + iteration + 1, value} -- one relaxed agent-scope store each, the
+// reader re-reads until the tag matches (MI355X_MICROARCH.md hand-off recipe R2, the decoder's
+// scheme): no flags, no fences, no grid barrier, placement-independent; two slots by iteration
+// parity (a slot is rewritten two iterations later, after its reader has published the iteration
+// in between, which the writer had to wait for).  Per iteration and frame there is exactly one
+// inverse and one forward transform, and the window-sum division happens once per sample.
+//
+// Rounding: identical to the launch-per-iteration kernels except for the overlap-add order of a
+// sample whose frames span two workgroups: the left neighbour's (ascending) partial sum, then the
+// own frames ascending, then the right neighbour's partial sum.
+// ================================================================================================
+typedef unsigned long long u64;
+constexpr int GLP_HALO = 768;
+constexpr unsigned GLP_SPIN_LIMIT = 1u << 20;
+
+__device__ __forceinline__ int glp_fstart(int b, int F, int nblk) { return (int)(((long long)b * F) / nblk); }
+
+__device__ __forceinline__ bool glp_give_up(unsigned &spins, int *err, unsigned limit) {
+  if (++spins > limit || ((spins & 63u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+    atomicExch(err, 1);
+    return true;
+  }
+  __builtin_amdgcn_s_sleep(1);
+  return false;
+}
+
+// W = waves per workgroup the instantiation is compiled for (its register budget): 4 -> one wave per
+// SIMD with the whole 512-register file, 8 -> two per SIMD.
+// Developer build (-DXDTTS_GL_PROFILE): thread 0 of every workgroup accumulates the 100 MHz wall clock
+// between phase markers into p.prof[workgroup][8] (tools/gl_profile.py).
+#ifdef XDTTS_GL_PROFILE
+#define GLP_MARK(i)                     \
+  do {                                  \
+    if (tid == 0) {                     \
+      const u64 now_ = wall_clock64();  \
+      prof_acc[i] += now_ - prof_last;  \
+      prof_last = now_;                 \
+    }                                   \
+  } while (0)
+#else
+#define GLP_MARK(i) do { } while (0)
+#endif
+
+template <int W>
+__global__ __launch_bounds__(64 * W) void k_gl_persistent(GlBufs g, GlPersist p, const float2 *__restrict__ ang_in,
+                                                         const float2 *__restrict__ tprev_in, int n_iter, float alpha,
+                                                         float *__restrict__ audio) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int TF = p.TF, nthr = 64 * TF;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+  const int F = g.F, N = HOP * (F - 1);
+  const int f0 = glp_fstart(b, F, p.nblk), nb_own = glp_fstart(b + 1, F, p.nblk) - f0;
+  const int range = (nb_own + 3) * HOP, Q0 = f0 * HOP;
+  float *sS = smem;                                             // [TF][516]  magnitudes
+  float2 *sA = reinterpret_cast<float2 *>(sS + TF * 516);       // [TF][513]  unit-modulus phase estimate
+  float2 *sP = sA + TF * 513;                                   // [TF][513]  previous rebuilt spectrum
+  float *fb = reinterpret_cast<float *>(sP + TF * 513);         // [TF][1024] windowed time frames (= each wave's FFT scratch)
+  float *yb = fb + TF * NFFT;                                   // [(TF+3) 256] overlap-added, normalised signal of the block's range
+  float *ws = yb + (TF + 3) * HOP;                              // [(TF+3) 256] window sum-square divisor
+  int *s_err = reinterpret_cast<int *>(ws + (TF + 3) * HOP);    // [1] error word as seen by thread 0 at this iteration
+  const bool own = wave < nb_own;
+  const int f = f0 + wave;
+  const unsigned limit = p.spins > 0 ? (unsigned)p.spins : GLP_SPIN_LIMIT;
+
+  // ---- per-lane constants, once: FFT twiddles, the split/merge twiddles e^{-2 pi i k / 1024} and the
+  // window at this lane's 8 packed positions ----
+  const Twiddles tws = load_twiddles(g.tw, lane);
+  float2 twk[8], wn[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    twk[r] = g.tw[lane + 64 * r];
+    wn[r] = reinterpret_cast<const float2 *>(g.win)[lane + 64 * r];
+  }
+  // ---- state of this block's frames into LDS ----
+  if (own) {
+    const float *S = g.S + (size_t)f * g.nb;
+    const float2 *A = ang_in + (size_t)f * g.nb, *P = tprev_in + (size_t)f * g.nb;
+    for (int k = lane; k < 513; k += 64) {
+      sS[wave * 516 + k] = S[k];
+      sA[wave * 513 + k] = A[k];
+      sP[wave * 513 + k] = P[k];
+    }
+  }
+  for (int j = tid; j < range; j += nthr) {
+    const int q = Q0 + j, jb = q >> 8, r = q & (HOP - 1);
+    float wss = 0.f;
+#pragma unroll
+    for (int k = 3; k >= 0; --k) {
+      const int fr = jb - k;
+      const float w = g.win[r + k * HOP];
+      wss = (fr >= 0 && fr < F) ? wss + w * w : wss;
+    }
+    ws[j] = wss > 1.17549435e-38f ? wss : 1.0f;
+  }
+  __syncthreads();
+
+  u64 *inL = p.xch + (size_t)b * 4 * GLP_HALO, *outL = b > 0 ? p.xch + ((size_t)(b - 1) * 4 + 1) * GLP_HALO : nullptr;
+  u64 *outR = b + 1 < p.nblk ? p.xch + (size_t)(b + 1) * 4 * GLP_HALO : nullptr;
+  // slot layout per block: [parity][side: 0 = from the left neighbour, 1 = from the right neighbour][768]
+  float2 *buf = reinterpret_cast<float2 *>(fb + wave * NFFT);
+
+#ifdef XDTTS_GL_PROFILE
+  u64 prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  u64 prof_last = wall_clock64();
+#endif
+  for (int it = 0; it <= n_iter; ++it) {
+    const unsigned want = p.epoch + (unsigned)it + 1u;
+    const int par = it & 1;
+    GLP_MARK(0);  // loop overhead
+    // ---- A: inverse transform of the own frame: irfft(1024) of S * angles, synthesis window -> fb ----
+    if (own) {
+      const float *S = sS + wave * 516;
+      const float2 *A = sA + wave * 513;
+      float2 v[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int k = lane + 64 * r, kc = 512 - k;
+        float2 xk = A[k], xc = A[kc];
+        const float sk = S[k], sc = S[kc];
+        xk = make_float2(xk.x * sk, xk.y * sk);
+        xc = make_float2(xc.x * sc, xc.y * sc);
+        if (k == 0) {  // irfft ignores the imaginary part of DC and Nyquist
+          xk.y = 0.f;
+          xc.y = 0.f;
+        }
+        const float2 e = make_float2(0.5f * (xk.x + xc.x), 0.5f * (xk.y - xc.y));
+        const float2 d = make_float2(0.5f * (xk.x - xc.x), 0.5f * (xk.y + xc.y));
+        const float2 o = cmul(d, cconj(twk[r]));
+        v[r] = make_float2(e.x - o.y, -(e.y + o.x));
+      }
+      fft512(v, buf, tws, lane);
+      const float sc = 1.0f / 512.0f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) buf[lane + 64 * r] = make_float2(v[r].x * sc * wn[r].x, -v[r].y * sc * wn[r].y);
+    }
+    GLP_MARK(1);  // A: inverse transform
+    __syncthreads();
+    GLP_MARK(2);  // barrier after A
+    // ---- B: publish the overlap with the neighbours' ranges, overlap-add the own range ----
+    for (int k = tid; k < GLP_HALO; k += nthr) {
+      if (outL) {  // own frames 0..2 over the left neighbour's last 768 samples (= own local [0, 768))
+        float v = fb[k];
+        if (k >= HOP) v += fb[NFFT + k - HOP];
+        if (k >= 2 * HOP) v += fb[2 * NFFT + k - 2 * HOP];
+        __hip_atomic_store(outL + (size_t)par * 2 * GLP_HALO + k, ((u64)want << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (outR) {  // own last three frames over the right neighbour's first 768 samples (own local 256 n + k)
+        const float *l1 = fb + (nb_own - 1) * NFFT + HOP + k, *l2 = fb + (nb_own - 2) * NFFT + 2 * HOP + k;
+        float v;  // ascending frame order: ((n-3) + (n-2)) + (n-1)
+        if (k < HOP) v = (fb[(nb_own - 3) * NFFT + 3 * HOP + k] + *l2) + *l1;
+        else if (k < 2 * HOP) v = *l2 + *l1;
+        else v = *l1;
+        __hip_atomic_store(outR + (size_t)par * 2 * GLP_HALO + k, ((u64)want << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    GLP_MARK(3);  // publish
+    {
+      // own frames' partial sum for local sample j, ascending frame order
+      auto own_sum = [&](int j) {
+        const int hi = min(nb_own - 1, j >> 8);
+        int i = max(0, (j >> 8) - 3);
+        float a = fb[i * NFFT + j - HOP * i];
+        for (++i; i <= hi; ++i) a += fb[i * NFFT + j - HOP * i];
+        return a;
+      };
+      // samples no neighbour reaches: [768, 256 n)
+      for (int j = GLP_HALO + tid; j < HOP * nb_own; j += nthr) yb[j] = own_sum(j) / ws[j];
+      // the two 768-sample edges: thread -> the same k on both sides, granules polled together
+      constexpr int U = 3;  // ceil(768 / threads) for 256..512 threads
+      float pl[U], pr[U], hl[U], hr[U];
+      bool dl[U], dr[U];
+      const bool has_l = b > 0, has_r = outR != nullptr;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = tid + u * nthr;
+        const bool in = k < GLP_HALO;
+        pl[u] = in ? own_sum(k) : 0.f;
+        pr[u] = in ? own_sum(HOP * nb_own + k) : 0.f;
+        hl[u] = hr[u] = 0.f;
+        dl[u] = !(in && has_l);
+        dr[u] = !(in && has_r);
+      }
+      const u64 *gl_ = inL + (size_t)par * 2 * GLP_HALO, *gr_ = gl_ + GLP_HALO;
+      unsigned spins = 0;
+      GLP_MARK(4);  // own partial sums
+      for (;;) {
+        u64 vl[U], vr[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (!dl[u]) vl[u] = __hip_atomic_load(gl_ + tid + u * nthr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (!dr[u]) vr[u] = __hip_atomic_load(gr_ + tid + u * nthr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        bool all = true;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (!dl[u]) {
+            if ((unsigned)(vl[u] >> 32) == want) {
+              hl[u] = __uint_as_float((unsigned)vl[u]);
+              dl[u] = true;
+            } else {
+              all = false;
+            }
+          }
+          if (!dr[u]) {
+            if ((unsigned)(vr[u] >> 32) == want) {
+              hr[u] = __uint_as_float((unsigned)vr[u]);
+              dr[u] = true;
+            } else {
+              all = false;
+            }
+          }
+        }
+        if (all || glp_give_up(spins, p.err, limit)) break;
+      }
+      GLP_MARK(5);  // wait for the neighbours' overlaps
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int k = tid + u * nthr;
+        if (k < GLP_HALO) {
+          // left neighbour's frames come first in ascending order, the right neighbour's last.  When the
+          // block has 3 frames the two edges meet at j = 768 and never overlap (256 n >= 768).
+          yb[k] = (has_l ? hl[u] + pl[u] : pl[u]) / ws[k];
+          const int j = HOP * nb_own + k;
+          yb[j] = (has_r ? pr[u] + hr[u] : pr[u]) / ws[j];
+        }
+      }
+      if (tid == 0) *s_err = __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    GLP_MARK(6);  // finalise + barrier after B
+    if (*s_err) return;  // an exchange timed out somewhere: the whole launch drains, the host falls back
+    if (it == n_iter) {
+      // ---- final ISTFT: the block's share of the centre-trimmed signal ----
+      if (audio) {
+        const int lo = b == 0 ? 0 : 384, hi = b + 1 == p.nblk ? range : 384 + HOP * nb_own;
+        for (int j = lo + tid; j < hi; j += nthr) {
+          const int n = Q0 + j - NFFT / 2;
+          if (n >= 0 && n < N) audio[n] = yb[j];
+        }
+      }
+      break;
+    }
+    // ---- C: forward transform of the own frame from the block's signal, phase update ----
+    if (own) {
+      float2 v[8];
+      if (f >= 2 && f <= F - 3) {
+        const float2 *y2 = reinterpret_cast<const float2 *>(yb + HOP * wave);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const float2 y = y2[lane + 64 * r];
+          v[r] = make_float2(y.x * wn[r].x, y.y * wn[r].y);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int base = f * HOP + 2 * (lane + 64 * r) - NFFT / 2;
+          const float y0 = yb[reflect_index(base, N) + NFFT / 2 - Q0], y1 = yb[reflect_index(base + 1, N) + NFFT / 2 - Q0];
+          v[r] = make_float2(y0 * wn[r].x, y1 * wn[r].y);
+        }
+      }
+      fft512(v, buf, tws, lane);
+      wave_lds_sync();
+#pragma unroll
+      for (int r = 0; r < 8; ++r) buf[lane + 64 * r] = v[r];
+      wave_lds_sync();
+      float2 *A = sA + wave * 513, *P = sP + wave * 513;
+#pragma unroll
+      for (int r = 0; r <= 8; ++r) {
+        const int k = lane + 64 * r;
+        if (r == 8 && lane != 0) break;
+        const float2 zk = buf[k & 511], zc = buf[(512 - k) & 511];
+        const float2 e = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
+        const float2 o = make_float2(0.5f * (zk.y + zc.y), 0.5f * (zc.x - zk.x));
+        const float2 tw = r == 8 ? make_float2(-1.f, 0.f) : twk[r & 7];
+        const float2 x = cadd(e, cmul(tw, o));
+        const float2 pv = P[k];
+        P[k] = x;
+        const float2 a = make_float2(fmaf(-alpha, pv.x, x.x), fmaf(-alpha, pv.y, x.y));
+        const float mag = sqrtf(fmaf(a.x, a.x, a.y * a.y)) + 1e-16f;
+        A[k] = make_float2(a.x / mag, a.y / mag);
+      }
+      wave_lds_sync();
+    }
+    GLP_MARK(7);  // C: forward transform + phase update
+  }
+#ifdef XDTTS_GL_PROFILE
+  if (p.prof && tid == 0)
+    for (int i = 0; i < 8; ++i) p.prof[b * 8 + i] = prof_acc[i];
+#endif
+  // ---- state write-back (parity hook only) ----
+  if (p.ang_out && own) {
+    float2 *A = p.ang_out + (size_t)f * g.nb, *P = p.tprev_out + (size_t)f * g.nb;
+    for (int k = lane; k < 513; k += 64) {
+      A[k] = sA[wave * 513 + k];
+      P[k] = sP[wave * 513 + k];
+    }
+  }
+}
+
 // Final ISTFT output: overlap-add + normalisation + centre trim for every sample.
 __global__ void k_overlap_add(GlBufs g, float *y) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -417,12 +730,12 @@ __global__ void k_state_import(GlBufs g, const float *ang_in, const float *reb_i
   g.ang[i] = make_float2(ang_in[o], ang_in[o + 1]);
   g.tprev[i] = make_float2(reb_in[o], reb_in[o + 1]);
 }
-__global__ void k_state_export(GlBufs g, const float2 *ang, float *ang_out, float *reb_out) {
+__global__ void k_state_export(GlBufs g, const float2 *ang, const float2 *tprev, float *ang_out, float *reb_out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= g.F * g.nb) return;
   const int f = i / g.nb, k = i % g.nb;
   const size_t o = ((size_t)k * g.F + f) * 2;
-  const float2 a = ang[i], r = g.tprev[i];
+  const float2 a = ang[i], r = tprev[i];
   ang_out[o] = a.x;
   ang_out[o + 1] = a.y;
   reb_out[o] = r.x;
@@ -455,9 +768,54 @@ void launch_gl_state_import(const GlBufs &g, const float *ang_in, const float *r
   HIP_CHECK(hipGetLastError());
 }
 
-void launch_gl_state_export(const GlBufs &g, const float2 *ang, float *ang_out, float *reb_out, hipStream_t s) {
+void launch_gl_state_export(const GlBufs &g, const float2 *ang, const float2 *tprev, float *ang_out, float *reb_out,
+                            hipStream_t s) {
   const int n = g.F * g.nb;
-  hipLaunchKernelGGL(k_state_export, dim3((n + 255) / 256), dim3(256), 0, s, g, ang, ang_out, reb_out);
+  hipLaunchKernelGGL(k_state_export, dim3((n + 255) / 256), dim3(256), 0, s, g, ang, tprev, ang_out, reb_out);
+  HIP_CHECK(hipGetLastError());
+}
+
+// ---- persistent engine: plan, resources, launch ----
+bool gl_persistent_plan(int F, int n_cu, int *TF, int *nblk) {
+  if (F < 16) return false;  // reflect padding folds more than once: two-kernel path
+  int tf = std::max(4, (F + n_cu - 1) / n_cu);
+  if (tf > GLP_TF_MAX) return false;
+  const int nb = (F + tf - 1) / tf;
+  if (nb > n_cu || F / nb < 3) return false;  // one workgroup per CU; every block needs >= 3 frames
+  *TF = tf;
+  *nblk = nb;
+  return true;
+}
+size_t gl_persistent_lds_bytes(int TF) { return sizeof(float) * ((size_t)TF * (516 + 2 * 1026 + NFFT) + 2 * (size_t)(TF + 3) * HOP + 4); }
+size_t gl_persistent_xch_words(int nblk) { return (size_t)nblk * 4 * GLP_HALO; }
+
+bool gl_persistent_supported(int device, int *n_cu) {
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return false;
+  const size_t lds4 = gl_persistent_lds_bytes(4), lds8 = gl_persistent_lds_bytes(GLP_TF_MAX);
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_gl_persistent<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4) !=
+          hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void *>(k_gl_persistent<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8) !=
+          hipSuccess)
+    return false;
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gl_persistent<4>, 256, lds4) != hipSuccess || per_cu < 1) return false;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gl_persistent<8>, 512, lds8) != hipSuccess || per_cu < 1) return false;
+  *n_cu = prop.multiProcessorCount;
+  return true;
+}
+
+// All n_iter iterations and (audio != null) the final ISTFT in one launch.  The state is read from
+// ang_in / tprev_in and left untouched, so a failed exchange (p.err set) can be retried on the
+// launch-per-iteration path; p.ang_out / p.tprev_out (parity hook) receive the final state.
+void launch_gl_persistent(const GlBufs &g, const GlPersist &p, const float2 *ang_in, const float2 *tprev_in, int n_iter,
+                          float alpha, float *audio, hipStream_t s) {
+  if (p.TF <= 4)
+    hipLaunchKernelGGL(k_gl_persistent<4>, dim3(p.nblk), dim3(64 * p.TF), gl_persistent_lds_bytes(p.TF), s, g, p, ang_in, tprev_in,
+                       n_iter, alpha, audio);
+  else
+    hipLaunchKernelGGL(k_gl_persistent<8>, dim3(p.nblk), dim3(64 * p.TF), gl_persistent_lds_bytes(p.TF), s, g, p, ang_in, tprev_in,
+                       n_iter, alpha, audio);
   HIP_CHECK(hipGetLastError());
 }
 

@@ -115,6 +115,24 @@ struct GlBufs {
   const float2 *tw;        // [n_fft]        exp(-2*pi*i*k/n_fft)
   const float *win;        // [n_fft]        periodic hann
 };
+// Persistent Griffin-Lim (griffinlim.hip: k_gl_persistent): all iterations + the final ISTFT in one
+// launch, one workgroup per CU owning 3..TF consecutive frames, state in LDS, 768-sample overlaps
+// exchanged with the two neighbours as tagged 8-byte granules.
+constexpr int GLP_TF_MAX = 8;  // frames per workgroup (LDS: 10.3 KB of state + 4 KB of frame each; 8 waves = 2 per SIMD)
+struct GlPersist {
+  unsigned long long *xch;  // [nblk][2 parities][2 sides][768] granules
+  int *err;                 // set when a bounded spin ran out
+  unsigned epoch;           // tag base of this call (tags = epoch + iteration + 1; never reused within the buffer's life)
+  int nblk, TF;
+  int spins;                // test hook: poll limit (0 = default)
+  float2 *ang_out, *tprev_out;  // parity hook: final state, or null
+  unsigned long long *prof;     // developer profile build only: [nblk][8] phase clocks, else null
+};
+bool gl_persistent_plan(int F, int n_cu, int *TF, int *nblk);
+size_t gl_persistent_xch_words(int nblk);
+bool gl_persistent_supported(int device, int *n_cu);
+void launch_gl_persistent(const GlBufs &g, const GlPersist &p, const float2 *ang_in, const float2 *tprev_in, int n_iter,
+                          float alpha, float *audio, hipStream_t s);
 void launch_gl_exp_transpose(const float *mel_80xF, float *out_Fx80, int n_mels, int F, hipStream_t s);
 void launch_gl_phase_init(const GlBufs &g, uint32_t seed, const float *phase0_dev, hipStream_t s);
 void launch_gl_prepare(const GlBufs &g, hipStream_t s);                  // wss_inv for this F
@@ -123,7 +141,8 @@ const float2 *launch_gl_iterate(const GlBufs &g, int n_iter, float alpha, hipStr
 void launch_gl_final(const GlBufs &g, const float2 *ang, float *audio, hipStream_t s);            // final ISTFT
 // parity hook: iteration state in the crate's (n_bins x F x 2) layout <-> device [F][nb] float2
 void launch_gl_state_import(const GlBufs &g, const float *ang_in, const float *reb_in, hipStream_t s);
-void launch_gl_state_export(const GlBufs &g, const float2 *ang, float *ang_out, float *reb_out, hipStream_t s);
+void launch_gl_state_export(const GlBufs &g, const float2 *ang, const float2 *tprev, float *ang_out, float *reb_out,
+                            hipStream_t s);
 void launch_transpose(const float *in, float *out, int rows, int cols, hipStream_t s);
 
 }  // namespace xdtts
