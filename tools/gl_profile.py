@@ -1,5 +1,5 @@
 """Per-phase wall clocks of the persistent Griffin-Lim kernel.  Needs a -DXDTTS_GL_PROFILE build of
-libxdtts_hip.so:   make -C xd-tts_amd clean && make -C xd-tts_amd -j8 CXXFLAGS="-O3 -std=c++17 -fPIC -DXDTTS_GL_PROFILE"
+libxdtts_hip.so:   make -C xd-tts_amd prof   (-> libxdtts_hip_prof.so; run with XDTTS_LIB=xd-tts_amd/libxdtts_hip_prof.so)
 """
 import importlib, os, sys
 import numpy as np
@@ -19,7 +19,7 @@ t = voc.last_timings()
 rows = open(path).read().split("\n")
 nblk, n_iter = map(int, rows[0].split())
 a = np.array([[int(x) for x in r.split()] for r in rows[1:1 + nblk]], dtype=np.float64) * 0.01 / (n_iter + 1)   # us per iteration
-names = ["loop", "A inverse FFT", "barrier A", "publish", "own sums", "wait neighbours", "finalise+barrier", "C forward FFT+update"]
+names = ["loop", "A inverse FFT", "barrier A", "B1 own overlap-add", "B2 middle samples", "B2 wait neighbours", "B2 finalise + barrier", "C gather + window", "C forward FFT", "C unpack + update", "B0 publish", "-"]
 print("F=%d iters=%d: %d workgroups, device %.3f ms (%.2f us per iteration incl. profiling overhead)" % (F, iters, nblk, t["iterations_ms"], t["iterations_ms"] * 1e3 / (iters + 1)))
 print("%-24s %8s %8s %8s   (us per iteration, over workgroups)" % ("phase", "mean", "min", "max"))
 for i, n in enumerate(names):

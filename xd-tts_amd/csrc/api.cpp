@@ -797,19 +797,19 @@ struct xdtts_griffinlim {
       }
 #ifdef XDTTS_GL_PROFILE
       static DevBuf<unsigned long long> prof;
-      prof.alloc(256 * 8);
+      prof.alloc(256 * 12);
       p.prof = prof.p;
 #endif
       launch_gl_persistent(g, p, g.ang, g.tprev, n_iter, alpha, audio_out, stream);
 #ifdef XDTTS_GL_PROFILE
       if (const char *path = getenv("XDTTS_GL_PROFILE")) {
-        std::vector<unsigned long long> hp((size_t)nblk * 8);
+        std::vector<unsigned long long> hp((size_t)nblk * 12);
         HIP_CHECK(hipMemcpyAsync(hp.data(), prof.p, hp.size() * 8, hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
         if (FILE *f = fopen(path, "w")) {
           fprintf(f, "%d %d\n", nblk, n_iter);
           for (int c = 0; c < nblk; ++c) {
-            for (int i = 0; i < 8; ++i) fprintf(f, "%llu ", hp[(size_t)c * 8 + i]);
+            for (int i = 0; i < 12; ++i) fprintf(f, "%llu ", hp[(size_t)c * 12 + i]);
             fprintf(f, "\n");
           }
           fclose(f);

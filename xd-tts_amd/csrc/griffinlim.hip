@@ -111,6 +111,41 @@ __device__ __forceinline__ void fft512(float2 (&v)[8], float2 *buf, const Twiddl
   fft8(v);
 }
 
+// The same transform with the exchange buffer addressed through phys(i) = i + (i >> 4) (544 float2
+// per wave): the stride-8 stores of pass 1 (float2 slots 8 lane + r: two distinct 16-slot bank
+// positions per 16-lane group, an 8-way conflict) and the stride-64 lane groups of pass 2 become
+// conflict-free; all offsets stay compile-time per r.  Used where one wave per SIMD runs the
+// transform and every LDS cycle is exposed latency (the persistent kernel).
+constexpr int FFT_SWZ_F2 = 544;
+__device__ __forceinline__ void fft512s(float2 (&v)[8], float2 *buf, const Twiddles &t, int lane) {
+  fft8(v);
+  {
+    float2 *w = buf + 8 * lane + (lane >> 1);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) w[r] = v[r];
+  }
+  wave_lds_sync();
+  const float2 *rd = buf + lane + (lane >> 4);
+  {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = rd[68 * r];
+#pragma unroll
+    for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], t.p8[r - 1]);
+    fft8(v);
+    wave_lds_sync();
+    const int j0 = (lane >> 3) * 64 + (lane & 7);
+    float2 *w = buf + j0 + (j0 >> 4);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) w[8 * r + (r >> 1)] = v[r];
+  }
+  wave_lds_sync();
+#pragma unroll
+  for (int r = 0; r < 8; ++r) v[r] = rd[68 * r];
+#pragma unroll
+  for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], t.p64[r - 1]);
+  fft8(v);
+}
+
 constexpr int FRAMES_PER_BLOCK = 4;  // one wave per frame
 
 // Spectrum of frame f -> the packed 512-point input of the inverse transform, in registers:
@@ -398,6 +433,7 @@ __global__ __launch_bounds__(64 * (TF + 6)) void k_gl_fused(GlBufs g, const floa
 // ================================================================================================
 typedef unsigned long long u64;
 constexpr int GLP_HALO = 768;
+constexpr int FBS = 2 * FFT_SWZ_F2;  // floats per frame row of fb: 1024 samples, 1088 as swizzled FFT scratch
 constexpr unsigned GLP_SPIN_LIMIT = 1u << 20;
 
 __device__ __forceinline__ int glp_fstart(int b, int F, int nblk) { return (int)(((long long)b * F) / nblk); }
@@ -414,7 +450,7 @@ __device__ __forceinline__ bool glp_give_up(unsigned &spins, int *err, unsigned 
 // W = waves per workgroup the instantiation is compiled for (its register budget): 4 -> one wave per
 // SIMD with the whole 512-register file, 8 -> two per SIMD.
 // Developer build (-DXDTTS_GL_PROFILE): thread 0 of every workgroup accumulates the 100 MHz wall clock
-// between phase markers into p.prof[workgroup][8] (tools/gl_profile.py).
+// between phase markers into p.prof[workgroup][12] (tools/gl_profile.py).
 #ifdef XDTTS_GL_PROFILE
 #define GLP_MARK(i)                     \
   do {                                  \
@@ -439,11 +475,11 @@ __global__ __launch_bounds__(64 * W) void k_gl_persistent(GlBufs g, GlPersist p,
   const int f0 = glp_fstart(b, F, p.nblk), nb_own = glp_fstart(b + 1, F, p.nblk) - f0;
   const int range = (nb_own + 3) * HOP, Q0 = f0 * HOP;
   float *sS = smem;                                             // [TF][516]  magnitudes
-  float2 *sA = reinterpret_cast<float2 *>(sS + TF * 516);       // [TF][513]  unit-modulus phase estimate
+  float2 *sA = reinterpret_cast<float2 *>(sS + TF * 516);       // [TF][513]  S * (unit-modulus phase estimate): the spectrum the next ISTFT inverts
   float2 *sP = sA + TF * 513;                                   // [TF][513]  previous rebuilt spectrum
   float *fb = reinterpret_cast<float *>(sP + TF * 513);         // [TF][1024] windowed time frames (= each wave's FFT scratch)
-  float *yb = fb + TF * NFFT;                                   // [(TF+3) 256] overlap-added, normalised signal of the block's range
-  float *ws = yb + (TF + 3) * HOP;                              // [(TF+3) 256] window sum-square divisor
+  float *yb = fb + TF * FBS;                                   // [(TF+3) 256] overlap-added, normalised signal of the block's range
+  float *ws = yb + (TF + 3) * HOP;                              // [(TF+3) 256] 1 / window sum-square
   int *s_err = reinterpret_cast<int *>(ws + (TF + 3) * HOP);    // [1] error word as seen by thread 0 at this iteration
   const bool own = wave < nb_own;
   const int f = f0 + wave;
@@ -463,8 +499,10 @@ __global__ __launch_bounds__(64 * W) void k_gl_persistent(GlBufs g, GlPersist p,
     const float *S = g.S + (size_t)f * g.nb;
     const float2 *A = ang_in + (size_t)f * g.nb, *P = tprev_in + (size_t)f * g.nb;
     for (int k = lane; k < 513; k += 64) {
-      sS[wave * 516 + k] = S[k];
-      sA[wave * 513 + k] = A[k];
+      const float sk = S[k];
+      const float2 ak = A[k];
+      sS[wave * 516 + k] = sk;
+      sA[wave * 513 + k] = make_float2(ak.x * sk, ak.y * sk);
       sP[wave * 513 + k] = P[k];
     }
   }
@@ -477,17 +515,17 @@ __global__ __launch_bounds__(64 * W) void k_gl_persistent(GlBufs g, GlPersist p,
       const float w = g.win[r + k * HOP];
       wss = (fr >= 0 && fr < F) ? wss + w * w : wss;
     }
-    ws[j] = wss > 1.17549435e-38f ? wss : 1.0f;
+    ws[j] = wss > 1.17549435e-38f ? 1.0f / wss : 1.0f;  // reciprocal of the divisor: one multiply per sample and iteration
   }
   __syncthreads();
 
   u64 *inL = p.xch + (size_t)b * 4 * GLP_HALO, *outL = b > 0 ? p.xch + ((size_t)(b - 1) * 4 + 1) * GLP_HALO : nullptr;
   u64 *outR = b + 1 < p.nblk ? p.xch + (size_t)(b + 1) * 4 * GLP_HALO : nullptr;
   // slot layout per block: [parity][side: 0 = from the left neighbour, 1 = from the right neighbour][768]
-  float2 *buf = reinterpret_cast<float2 *>(fb + wave * NFFT);
+  float2 *buf = reinterpret_cast<float2 *>(fb + wave * FBS);
 
 #ifdef XDTTS_GL_PROFILE
-  u64 prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  u64 prof_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   u64 prof_last = wall_clock64();
 #endif
   for (int it = 0; it <= n_iter; ++it) {
@@ -496,16 +534,12 @@ __global__ __launch_bounds__(64 * W) void k_gl_persistent(GlBufs g, GlPersist p,
     GLP_MARK(0);  // loop overhead
     // ---- A: inverse transform of the own frame: irfft(1024) of S * angles, synthesis window -> fb ----
     if (own) {
-      const float *S = sS + wave * 516;
-      const float2 *A = sA + wave * 513;
+      const float2 *X = sA + wave * 513;
       float2 v[8];
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         const int k = lane + 64 * r, kc = 512 - k;
-        float2 xk = A[k], xc = A[kc];
-        const float sk = S[k], sc = S[kc];
-        xk = make_float2(xk.x * sk, xk.y * sk);
-        xc = make_float2(xc.x * sc, xc.y * sc);
+        float2 xk = X[k], xc = X[kc];
         if (k == 0) {  // irfft ignores the imaginary part of DC and Nyquist
           xk.y = 0.f;
           xc.y = 0.f;
@@ -515,7 +549,7 @@ __global__ __launch_bounds__(64 * W) void k_gl_persistent(GlBufs g, GlPersist p,
         const float2 o = cmul(d, cconj(twk[r]));
         v[r] = make_float2(e.x - o.y, -(e.y + o.x));
       }
-      fft512(v, buf, tws, lane);
+      fft512s(v, buf, tws, lane);
       const float sc = 1.0f / 512.0f;
 #pragma unroll
       for (int r = 0; r < 8; ++r) buf[lane + 64 * r] = make_float2(v[r].x * sc * wn[r].x, -v[r].y * sc * wn[r].y);
@@ -523,38 +557,60 @@ __global__ __launch_bounds__(64 * W) void k_gl_persistent(GlBufs g, GlPersist p,
     GLP_MARK(1);  // A: inverse transform
     __syncthreads();
     GLP_MARK(2);  // barrier after A
-    // ---- B: publish the overlap with the neighbours' ranges, overlap-add the own range ----
-    for (int k = tid; k < GLP_HALO; k += nthr) {
-      if (outL) {  // own frames 0..2 over the left neighbour's last 768 samples (= own local [0, 768))
-        float v = fb[k];
-        if (k >= HOP) v += fb[NFFT + k - HOP];
-        if (k >= 2 * HOP) v += fb[2 * NFFT + k - 2 * HOP];
-        __hip_atomic_store(outL + (size_t)par * 2 * GLP_HALO + k, ((u64)want << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-      }
-      if (outR) {  // own last three frames over the right neighbour's first 768 samples (own local 256 n + k)
-        const float *l1 = fb + (nb_own - 1) * NFFT + HOP + k, *l2 = fb + (nb_own - 2) * NFFT + 2 * HOP + k;
-        float v;  // ascending frame order: ((n-3) + (n-2)) + (n-1)
-        if (k < HOP) v = (fb[(nb_own - 3) * NFFT + 3 * HOP + k] + *l2) + *l1;
-        else if (k < 2 * HOP) v = *l2 + *l1;
-        else v = *l1;
-        __hip_atomic_store(outR + (size_t)par * 2 * GLP_HALO + k, ((u64)want << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
+    // ---- B0: what the neighbours lack, straight from the frames and before anything else so that the
+    // granules travel while the own range is summed: the first 768 samples of the range get own frames
+    // 0..2, the last 768 own frames n-3..n-1 (ascending; bitwise the same sums as B1 forms below) ----
+    {
+      const bool has_l = b > 0, has_r = outR != nullptr;
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int k = tid + u * nthr;
+        if (k < GLP_HALO) {
+          if (has_l) {
+            float v = fb[k];
+            if (k >= HOP) v += fb[FBS + k - HOP];
+            if (k >= 2 * HOP) v += fb[2 * FBS + k - 2 * HOP];
+            __hip_atomic_store(outL + (size_t)par * 2 * GLP_HALO + k, ((u64)want << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+          }
+          if (has_r) {
+            const float l1 = fb[(nb_own - 1) * FBS + HOP + k];
+            float v = l1;
+            if (k < HOP) v = (fb[(nb_own - 3) * FBS + 3 * HOP + k] + fb[(nb_own - 2) * FBS + 2 * HOP + k]) + l1;
+            else if (k < 2 * HOP) v = fb[(nb_own - 2) * FBS + 2 * HOP + k] + l1;
+            __hip_atomic_store(outR + (size_t)par * 2 * GLP_HALO + k, ((u64)want << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
       }
     }
-    GLP_MARK(3);  // publish
+    GLP_MARK(10);  // B0: publish
+    // ---- B1: overlap-add of the own frames over the block's range (not yet normalised) -> yb.
+    // float4 per thread; the 256-sample chunk index is wave-uniform, so the frame loop does not diverge.
     {
-      // own frames' partial sum for local sample j, ascending frame order
-      auto own_sum = [&](int j) {
-        const int hi = min(nb_own - 1, j >> 8);
-        int i = max(0, (j >> 8) - 3);
-        float a = fb[i * NFFT + j - HOP * i];
-        for (++i; i <= hi; ++i) a += fb[i * NFFT + j - HOP * i];
-        return a;
-      };
-      // samples no neighbour reaches: [768, 256 n)
-      for (int j = GLP_HALO + tid; j < HOP * nb_own; j += nthr) yb[j] = own_sum(j) / ws[j];
-      // the two 768-sample edges: thread -> the same k on both sides, granules polled together
+      const float4 *fb4 = reinterpret_cast<const float4 *>(fb);
+      float4 *yb4 = reinterpret_cast<float4 *>(yb);
+      for (int q4 = tid; q4 < (nb_own + 3) * (HOP / 4); q4 += nthr) {
+        const int c = q4 >> 6, lo = max(0, c - 3), hi = min(nb_own - 1, c);
+        float4 a = fb4[lo * (FBS / 4) + q4 - (HOP / 4) * lo];
+        for (int i = lo + 1; i <= hi; ++i) {  // ascending frame order
+          const float4 t = fb4[i * (FBS / 4) + q4 - (HOP / 4) * i];
+          a.x += t.x;
+          a.y += t.y;
+          a.z += t.z;
+          a.w += t.w;
+        }
+        if (c >= 3 && c < nb_own) {  // samples no neighbour reaches ([768, 256 n)): normalise now
+          const float4 w = reinterpret_cast<const float4 *>(ws)[q4];
+          a = make_float4(a.x * w.x, a.y * w.y, a.z * w.z, a.w * w.w);
+        }
+        yb4[q4] = a;
+      }
+    }
+    __syncthreads();
+    GLP_MARK(3);  // own overlap-add
+    // ---- B2: take the neighbours' contributions to the first / last 768 samples, normalise ----
+    {
       constexpr int U = 3;  // ceil(768 / threads) for 256..512 threads
       float pl[U], pr[U], hl[U], hr[U];
       bool dl[U], dr[U];
@@ -563,15 +619,15 @@ __global__ __launch_bounds__(64 * W) void k_gl_persistent(GlBufs g, GlPersist p,
       for (int u = 0; u < U; ++u) {
         const int k = tid + u * nthr;
         const bool in = k < GLP_HALO;
-        pl[u] = in ? own_sum(k) : 0.f;
-        pr[u] = in ? own_sum(HOP * nb_own + k) : 0.f;
+        pl[u] = in ? yb[k] : 0.f;
+        pr[u] = in ? yb[HOP * nb_own + k] : 0.f;
         hl[u] = hr[u] = 0.f;
         dl[u] = !(in && has_l);
         dr[u] = !(in && has_r);
       }
       const u64 *gl_ = inL + (size_t)par * 2 * GLP_HALO, *gr_ = gl_ + GLP_HALO;
       unsigned spins = 0;
-      GLP_MARK(4);  // own partial sums
+      GLP_MARK(4);  // middle samples
       for (;;) {
         u64 vl[U], vr[U];
 #pragma unroll
@@ -608,9 +664,9 @@ __global__ __launch_bounds__(64 * W) void k_gl_persistent(GlBufs g, GlPersist p,
         if (k < GLP_HALO) {
           // left neighbour's frames come first in ascending order, the right neighbour's last.  When the
           // block has 3 frames the two edges meet at j = 768 and never overlap (256 n >= 768).
-          yb[k] = (has_l ? hl[u] + pl[u] : pl[u]) / ws[k];
+          yb[k] = (has_l ? hl[u] + pl[u] : pl[u]) * ws[k];
           const int j = HOP * nb_own + k;
-          yb[j] = (has_r ? pr[u] + hr[u] : pr[u]) / ws[j];
+          yb[j] = (has_r ? pr[u] + hr[u] : pr[u]) * ws[j];
         }
       }
       if (tid == 0) *s_err = __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -647,42 +703,87 @@ __global__ __launch_bounds__(64 * W) void k_gl_persistent(GlBufs g, GlPersist p,
           v[r] = make_float2(y0 * wn[r].x, y1 * wn[r].y);
         }
       }
-      fft512(v, buf, tws, lane);
+      GLP_MARK(7);  // C: gather + window
+      fft512s(v, buf, tws, lane);
+      GLP_MARK(8);  // C: forward FFT
       wave_lds_sync();
 #pragma unroll
       for (int r = 0; r < 8; ++r) buf[lane + 64 * r] = v[r];
       wave_lds_sync();
-      float2 *A = sA + wave * 513, *P = sP + wave * 513;
+      // Unpack the 512-point spectrum Z of the packed real frame into the 513 bins X and update the
+      // phase: bins k and 512 - k share everything up to one complex product,
+      //   X[k] = e + w o,  X[512-k] = conj(e - w o),  e = (Z[k] + conj Z[512-k]) / 2,
+      //   o = (Z[k] - conj Z[512-k]) / 2i,  w = e^{-2 pi i k / 1024},
+      // so a lane takes the pair (k, 512-k) for k = lane + 64 r < 256; k = 256 is its own partner
+      // (X[256] = conj Z[256]) and goes to lane 0 afterwards.  a = X - alpha * previous X;
+      // angles = a / (|a| + 1e-16) through v_sqrt_f32 / v_rcp_f32 (1 ulp each); the stored value is
+      // S * angles, what the next inverse transform needs.
+      // All LDS loads first, all stores last: the compiler cannot tell the state arrays apart (they are
+      // carved from one buffer), so interleaved loads and stores would serialise into ~27 dependent LDS
+      // round trips per iteration.
+      float2 *X = sA + wave * 513, *P = sP + wave * 513;
+      const float *S = sS + wave * 516;
+      float2 *ang_g = (p.ang_out && it == n_iter - 1) ? p.ang_out + (size_t)f * g.nb : nullptr;  // parity hook
+      float2 zk[4], zc[4], pv[9];
+      float sk[9];
 #pragma unroll
-      for (int r = 0; r <= 8; ++r) {
+      for (int r = 0; r < 4; ++r) {
         const int k = lane + 64 * r;
-        if (r == 8 && lane != 0) break;
-        const float2 zk = buf[k & 511], zc = buf[(512 - k) & 511];
-        const float2 e = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
-        const float2 o = make_float2(0.5f * (zk.y + zc.y), 0.5f * (zc.x - zk.x));
-        const float2 tw = r == 8 ? make_float2(-1.f, 0.f) : twk[r & 7];
-        const float2 x = cadd(e, cmul(tw, o));
-        const float2 pv = P[k];
-        P[k] = x;
-        const float2 a = make_float2(fmaf(-alpha, pv.x, x.x), fmaf(-alpha, pv.y, x.y));
-        const float mag = sqrtf(fmaf(a.x, a.x, a.y * a.y)) + 1e-16f;
-        A[k] = make_float2(a.x / mag, a.y / mag);
+        zk[r] = buf[k];
+        zc[r] = buf[(512 - k) & 511];
+        pv[2 * r] = P[k];
+        pv[2 * r + 1] = P[512 - k];
+        sk[2 * r] = S[k];
+        sk[2 * r + 1] = S[512 - k];
+      }
+      const float2 z256 = buf[256];
+      pv[8] = P[256];
+      sk[8] = S[256];
+      float2 xs[9], xo[9];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float2 e = make_float2(0.5f * (zk[r].x + zc[r].x), 0.5f * (zk[r].y - zc[r].y));
+        const float2 o = make_float2(0.5f * (zk[r].y + zc[r].y), 0.5f * (zc[r].x - zk[r].x));
+        const float2 t = cmul(twk[r], o);
+        xs[2 * r] = cadd(e, t);
+        xs[2 * r + 1] = make_float2(e.x - t.x, t.y - e.y);
+      }
+      xs[8] = make_float2(z256.x, -z256.y);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        const float2 a = make_float2(fmaf(-alpha, pv[i].x, xs[i].x), fmaf(-alpha, pv[i].y, xs[i].y));
+        const float inv = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(fmaf(a.x, a.x, a.y * a.y)) + 1e-16f);
+        xo[i] = make_float2(a.x * inv, a.y * inv);  // the unit-modulus angle
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = lane + 64 * r;
+        if (ang_g) {
+          ang_g[k] = xo[2 * r];
+          ang_g[512 - k] = xo[2 * r + 1];
+        }
+        P[k] = xs[2 * r];
+        P[512 - k] = xs[2 * r + 1];
+        X[k] = make_float2(xo[2 * r].x * sk[2 * r], xo[2 * r].y * sk[2 * r]);
+        X[512 - k] = make_float2(xo[2 * r + 1].x * sk[2 * r + 1], xo[2 * r + 1].y * sk[2 * r + 1]);
+      }
+      if (lane == 0) {
+        if (ang_g) ang_g[256] = xo[8];
+        P[256] = xs[8];
+        X[256] = make_float2(xo[8].x * sk[8], xo[8].y * sk[8]);
       }
       wave_lds_sync();
     }
-    GLP_MARK(7);  // C: forward transform + phase update
+    GLP_MARK(9);  // C: unpack + phase update
   }
 #ifdef XDTTS_GL_PROFILE
   if (p.prof && tid == 0)
-    for (int i = 0; i < 8; ++i) p.prof[b * 8 + i] = prof_acc[i];
+    for (int i = 0; i < 12; ++i) p.prof[b * 12 + i] = prof_acc[i];
 #endif
-  // ---- state write-back (parity hook only) ----
-  if (p.ang_out && own) {
-    float2 *A = p.ang_out + (size_t)f * g.nb, *P = p.tprev_out + (size_t)f * g.nb;
-    for (int k = lane; k < 513; k += 64) {
-      A[k] = sA[wave * 513 + k];
-      P[k] = sP[wave * 513 + k];
-    }
+  // ---- state write-back (parity hook only; the angles were stored by the last update) ----
+  if (p.tprev_out && own) {
+    float2 *P = p.tprev_out + (size_t)f * g.nb;
+    for (int k = lane; k < 513; k += 64) P[k] = sP[wave * 513 + k];
   }
 }
 
@@ -786,7 +887,7 @@ bool gl_persistent_plan(int F, int n_cu, int *TF, int *nblk) {
   *nblk = nb;
   return true;
 }
-size_t gl_persistent_lds_bytes(int TF) { return sizeof(float) * ((size_t)TF * (516 + 2 * 1026 + NFFT) + 2 * (size_t)(TF + 3) * HOP + 4); }
+size_t gl_persistent_lds_bytes(int TF) { return sizeof(float) * ((size_t)TF * (516 + 2 * 1026 + FBS) + 2 * (size_t)(TF + 3) * HOP + 4); }
 size_t gl_persistent_xch_words(int nblk) { return (size_t)nblk * 4 * GLP_HALO; }
 
 bool gl_persistent_supported(int device, int *n_cu) {

@@ -126,7 +126,7 @@ struct GlPersist {
   int nblk, TF;
   int spins;                // test hook: poll limit (0 = default)
   float2 *ang_out, *tprev_out;  // parity hook: final state, or null
-  unsigned long long *prof;     // developer profile build only: [nblk][8] phase clocks, else null
+  unsigned long long *prof;     // developer profile build only: [nblk][12] phase clocks, else null
 };
 bool gl_persistent_plan(int F, int n_cu, int *TF, int *nblk);
 size_t gl_persistent_xch_words(int nblk);
