@@ -8,9 +8,19 @@ encoder -> decoder loop -> post-net -> mel->linear -> Griffin-Lim -> audio.
 
     python bench.py --gpus N --steps K --warmup W
 
-N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL); utterances
-are independent, so ranks shard them with no data-path collective ("scaling": "weak").
-Rank 0 prints ONE JSON line.
+N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL).  Utterances
+are independent (src/tacotron2/mod.rs:422-434), so the N*K utterances of the
+timed region are assigned to ranks by xd-tts_amd/shard.py with no data-path collective
+("scaling": "weak": K utterances per GPU whatever N is).  Rank 0 prints ONE JSON line.
+
+Besides the headline the line carries `extra` blocks for the other BASELINE.json configs, measured
+after the timed region (each a few tens of ms of GPU time):
+  extra.config3  configs[2]: 32 variable-length utterances (40-200 ids) -> <=100-id chunks decoded as one
+                 padded/masked lock-step batch (decoder-only figures + roofline of the batched LSTM kernels)
+  extra.config4  configs[3]: 32 utterances per GPU (256 at N = 8), length-sorted round-robin over the ranks,
+                 end to end (batched mel-gen + per-utterance vocoder); counters all-gathered over RCCL
+  extra.config5  configs[4]: Griffin-Lim only, 1000 frames, 30/60/120 iterations, with its HBM roofline
+and `cpu_baseline` (N = 1 only): the CPU port of the same algorithm on the host cores.
 """
 import argparse
 import importlib
@@ -25,76 +35,80 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 SAMPLE_RATE = 22050.0
-HOP = 256
-N_IDS = 120
-TOTAL_FRAMES = 800            # gate disabled, 800 frames for 120 phonemes
 GL_ITERS = 60                 # BASELINE.json configs[1]
-WEIGHT_SEED = 20240327
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_F32_PEAK_TF = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak
 
-# Algorithmic bytes of one decoder step: the fp32 decoder_iter parameters are
+# Algorithmic work of one decoder step: the fp32 decoder_iter parameters are
 # streamed once per lock-step iteration, plus per ACTIVE chunk the encoder memory + processed memory
-# (T x (512+128) x 4) and the recurrent state read+write.
+# (T x (512+128) x 4) and the recurrent state read+write; 2 (18 167 296 + 6 720 T) flops per chunk.
 DECODER_PARAM_BYTES = 18_189_969 * 4
 T_ENC = 100
+GL_BYTES_PER_FRAME_ITER = 12308.0   # fused minimum per frame per iteration
 
 
 def per_item_bytes(T):
     return T * (512 + 128) * 4 + 2 * (4 * 1024 + 2 * T + 512 + 80) * 4
 
 
+def per_item_flops(T):
+    return 2.0 * (18_167_296 + 6_720 * T)
+
+
 def pmc_traffic():
-    """HBM bytes of the decoder launches of one utterance (its whole frame loop) from the committed rocprofv3
-    PMC passes of this same command (profiles/): counters cannot be read from inside the process,
-    so the figure is the profiled one."""
+    """HBM bytes of the decoder launches of one utterance (its whole frame loop) from the committed
+    rocprofv3 PMC passes of this same command (profiles/): counters cannot be read from inside the
+    process, so the figure is the profiled one, stamped with the commit it was profiled at."""
     import glob
 
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
     if not files:
-        return None
-    return json.load(open(files[-1])).get("decoder_launch_traffic_bytes")
+        return None, None
+    d = json.load(open(files[-1]))
+    return d.get("decoder_launch_traffic_bytes"), {"file": os.path.relpath(files[-1], ROOT), "profiled_at": d.get("git_head", "round 1")}
 
 
-def synth_ids(n, seed=1):
-    rng = np.random.Generator(np.random.PCG64(seed))
-    ids = 64 + rng.integers(0, 84, size=n)
-    ids[5::6] = 11
-    ids[-1] = 7
-    return ids.astype(np.int64)
+def cpu_baseline():
+    """The CPU ports of the same algorithm on this box's host cores, each on the full config-2 utterance
+    once (oracle/cpu_baseline.py, one process per leg with a hard timeout): the single-thread C oracle
+    (the reference's execution model), the same source with OpenMP, and a torch-CPU restatement.  The
+    multi-threaded legs use min(host cores, 32) threads: the step is a 72 MB GEMV stream, which a few
+    memory channels' worth of cores saturate."""
+    import subprocess
+
+    ncpu = os.cpu_count() or 1
+    nthr = min(ncpu, 32)
+
+    def leg(name, threads):
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), name, str(threads)], capture_output=True, text=True, timeout=150)
+            if r.returncode != 0:
+                return {"error": r.stderr.strip().splitlines()[-1] if r.stderr.strip() else "rc %d" % r.returncode}
+            return json.loads(r.stdout.strip().splitlines()[-1])
+        except subprocess.TimeoutExpired:
+            return {"error": "timed out after 150 s"}
+        except Exception as e:   # a baseline leg must never take the bench line down
+            return {"error": repr(e)}
+
+    out = leg("c1", 1)
+    log("cpu baseline: 1 thread done")
+    out["kind"] = "port"
+    out["host_cores"] = ncpu
+    if "frames" in out:
+        out["sample"] = "the full config-2 utterance once: 120 ids -> %d frames, %d-iteration Griffin-Lim, %d samples" % (out["frames"], GL_ITERS, out["samples"])
+    out["all_cores_openmp"] = leg("omp", nthr)
+    log("cpu baseline: OpenMP done")
+    out["all_cores_torch"] = leg("torch", nthr)
+    log("cpu baseline: torch done")
+    return out
 
 
-def cpu_baseline(ids, splits, chunk_steps):
-    """The CPU oracle (single-thread C port of the same algorithm) on the same utterance, once."""
-    import oracle
+def log(msg):
+    """progress on stderr (the JSON line is the only thing on stdout)"""
+    print("[bench %.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
 
-    orc = oracle.Oracle("f32")
-    blob = orc.weights_synthetic(seed=WEIGHT_SEED)
-    basis = orc.mel_filter_bank()
-    pinv = orc.pinv(basis)
-    t0 = time.perf_counter()
-    mels = []
-    start = 0
-    for item, (end, steps) in enumerate(zip(splits, chunk_steps)):
-        o = orc.default_opts(fixed_steps=int(steps), dropout_seed=0, item=item)
-        mels.append(orc.infer_chunk(blob, ids[start:end], o, window=T_ENC))
-        start = end
-    mel = np.concatenate(mels, axis=1)
-    t1 = time.perf_counter()
-    S = orc.mel_to_linear(pinv, mel, power=1.7)
-    audio = orc.griffinlim(S, seed=0, iters=GL_ITERS)
-    t2 = time.perf_counter()
-    frames = mel.shape[1]
-    return {
-        "value": frames / (t2 - t0),
-        "unit": "mel-frames/s",
-        "cores": 1,
-        "kind": "port",
-        "sample": "the full config-2 utterance once: %d ids -> %d frames, %d-iteration Griffin-Lim, %d samples"
-        % (len(ids), frames, GL_ITERS, audio.size),
-        "mel_gen_s": t1 - t0,
-        "vocoder_s": t2 - t1,
-        "rtf": (t2 - t0) / (audio.size / SAMPLE_RATE),
-    }
+
+_T0 = time.perf_counter()
 
 
 def main():
@@ -103,9 +117,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline only (profiling runs)")
     args = ap.parse_args()
 
-    import torch
+    import torch   # before the product library: see tests/conftest.py on the load order of the HIP runtime
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -121,21 +136,13 @@ def main():
         torch.cuda.set_device(local_rank)
 
     pkg = importlib.import_module("xd-tts_amd")
+    wl = importlib.import_module("xd-tts_amd.workloads")
+    shard = importlib.import_module("xd-tts_amd.shard")
     if pkg.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: libxdtts_hip has no CPU path")
 
-    ids = synth_ids(N_IDS)
-    splits = list(pkg.find_splits(ids, T_ENC))
-    if not splits or splits[-1] != len(ids):
-        splits.append(len(ids))          # src/tacotron2/mod.rs:412-414
-    lens = np.diff([0] + splits)
-    fpi = TOTAL_FRAMES / float(N_IDS)
-    chunk_steps = [int(np.floor(fpi * n + 0.5)) for n in lens]   # lround, as the library does
-
-    model = pkg.Tacotron2.synthetic(seed=WEIGHT_SEED, rec_scale=1.0, device_id=local_rank)
+    model = pkg.Tacotron2.synthetic(seed=wl.WEIGHT_SEED, rec_scale=1.0, device_id=local_rank)
     vocoder = pkg.create_griffin_lim(device_id=local_rank, iters=GL_ITERS, seed=0)
-    opts = pkg.default_opts(fixed_frames_per_id=fpi, dropout_seed=0, item_base=0)
-    sp = np.asarray(splits, dtype=np.int64)
 
     def barrier():
         torch.cuda.synchronize()
@@ -143,15 +150,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ---- headline: configs[1], K utterances per rank -------------------------------------------------
+    K = args.steps
+    utterances = [wl.synth_ids(120, seed=1 + g) for g in range(world * K)]        # N*K distinct utterances
+    mine = shard.shard_utterances([len(u) for u in utterances], rank, world)       # K of them for this rank
+    _ids0, chunks0, chunk_steps = wl.config2(pkg)
+    lens = [len(c) for c in chunks0]
+    sp = np.cumsum(lens).astype(np.int64)       # spaces sit at fixed positions: every utterance splits 95 + 25
+    opts = pkg.default_opts(fixed_frames_per_id=wl.FRAMES_PER_ID, dropout_seed=0, item_base=0)
     for _ in range(args.warmup):
-        pkg.synthesize(model, vocoder, ids, splits=sp, opts=opts)
+        pkg.synthesize(model, vocoder, utterances[mine[0]], splits=sp, opts=opts)
 
     dec_ms = gl_ms = enc_ms = post_ms = m2l_ms = 0.0
     dec_steps = 0
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        mel, audio = pkg.synthesize(model, vocoder, ids, splits=sp, opts=opts)   # synchronous: returns host buffers
+    for g in mine:
+        mel, audio = pkg.synthesize(model, vocoder, utterances[g], splits=sp, opts=opts)   # synchronous: returns host buffers
         tt, tg = model.last_timings(), vocoder.last_timings()
         enc_ms += tt["encoder_ms"]
         dec_ms += tt["decoder_ms"]
@@ -160,28 +182,21 @@ def main():
         m2l_ms += tg["mel_to_linear_ms"]
         gl_ms += tg["iterations_ms"]
     barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0)
 
     frames = mel.shape[1]
     samples = audio.size
-    K = args.steps
-    total_frames = frames * K * world
-    value = total_frames / elapsed
+    value = frames * K * world / elapsed
 
     # roofline of the dominant kernel: the persistent decoder (k_decoder_persistent<2> while both chunks
     # run, continued by k_decoder_persistent<1> for the longer one; HIP events around the pair on the
-    # library's stream, summed over the timed region).  Its algorithmic bytes are SURVEY 8(d)'s
-    # per-step figure x the steps executed: every decoder parameter once per step + per-chunk
-    # memory/state for the chunks still active at that step.
+    # library's stream, summed over the timed region).  Algorithmic bytes = SURVEY 8(d)'s per-step
+    # figure x the steps executed.
     steps_per_utt = dec_steps / K
     active = sum(min(s, int(steps_per_utt)) for s in chunk_steps)          # sum over steps of #active chunks
     bytes_per_utt = steps_per_utt * DECODER_PARAM_BYTES + active * per_item_bytes(T_ENC)
-    step_us = dec_ms / dec_steps * 1e3
     achieved = bytes_per_utt / (dec_ms / K * 1e-3) / 1e9
+    traffic, traffic_src = pmc_traffic()
     out = {
         "metric": "mel-frames/s per GPU, 120-phoneme utterance (Tacotron2 decoder+postnet + %d-iter Griffin-Lim), end-to-end" % GL_ITERS,
         "value": value,
@@ -194,12 +209,12 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic (seeded fp32 weights of the NVIDIA Tacotron2 shapes, seeded 120-id utterance)",
+        "data": "synthetic (seeded fp32 weights of the NVIDIA Tacotron2 shapes, seeded 120-id utterances)",
         "config": {
             "workload": "BASELINE.json configs[1]: batch=1 utterance, 120 phoneme ids -> chunks %s (window 100) -> %d mel frames (gate disabled) -> %d-iter Griffin-Lim -> %d samples"
-            % (list(map(int, lens)), frames, GL_ITERS, samples),
+            % (lens, frames, GL_ITERS, samples),
             "utterances_per_gpu_per_step": 1,
-            "parallelism": "utterance-shard x%d" % world,
+            "parallelism": "utterance-shard x%d (xd-tts_amd/shard.py, no data-path collective)" % world,
         },
         "audio_samples_per_s": samples * K * world / elapsed,
         "rtf": (elapsed / K) / (samples / SAMPLE_RATE),
@@ -212,24 +227,94 @@ def main():
             "griffinlim_iterations": gl_ms / K,
         },
         "roofline": {
-            "kernel": "k_decoder_persistent (<2> for the %d steps both chunks run, then <1>: %d lock-step decoder steps per utterance in two launches; weights stay in registers, so HBM traffic is far below the algorithmic bytes and the bound in practice is the 6 state-exchange edges per step, DESIGN.md section 4)" % (min(chunk_steps), int(steps_per_utt)),
+            "kernel": "k_decoder_persistent (<2> for the %d steps both chunks run, then <1>: %d lock-step decoder steps per utterance in two launches)" % (min(chunk_steps), int(steps_per_utt)),
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": pmc_traffic(),
+            "traffic": traffic,
+            "traffic_source": traffic_src,
+            # the weights stay in registers, so `achieved` is ALGORITHMIC bytes per second (every parameter
+            # counted once per step as SURVEY 8(d) defines), not bytes moved: what limits the kernel in
+            # practice is the latency of the 6 state-exchange edges per step
+            "limiter": "inter-CU exchange latency (6 all-gather edges per step), not HBM bandwidth",
+            "hbm_traffic_GBs": (traffic / (dec_ms / K * 1e-3) / 1e9) if traffic else None,
             "us_per_launch": dec_ms / K * 1e3,
             "algorithmic_bytes_per_launch": bytes_per_utt,
             "launches_per_utterance": 2,
             "steps_per_launch": steps_per_utt,
-            "us_per_step": step_us,
+            "us_per_step": dec_ms / dec_steps * 1e3,
             "algorithmic_bytes_per_step": bytes_per_utt / steps_per_utt,
         },
     }
+
+    log("headline done: %.0f frames/s" % value)
+    extra = {}
+    if not args.no_extras:
+        # ---- configs[2] / configs[3]: this rank's share of 32*N utterances as one lock-step batch -------
+        all_utts = wl.config4(pkg, n_batches=world)
+        share, chunks, steps, owner = shard.plan_share(lambda ids: wl.chunk_utterance(pkg, ids), all_utts, rank, world, wl.FRAMES_PER_ID_BATCH)
+        bo = pkg.default_opts(dropout_seed=1, item_base=0)
+        shard.run_share(model, vocoder, share, chunks, steps, owner, bo)      # warm-up
+        barrier()
+        res = shard.run_share(model, vocoder, share, chunks, steps, owner, bo)
+        barrier()
+        log("config3/4 share done")
+        fr, t_mel, tm, voc_ms = res["frames"], res["mel_gen_seconds"], res["timings"], res["vocoder_seconds"] * 1e3
+        totals, max_s, per_rank = shard.gather_counters(res, dist, device="cuda" if dist else "cpu")
+        it = tm["steps"]
+        act = float(sum(steps))                                                    # active chunk-steps of this rank
+        dsec = tm["decoder_ms"] * 1e-3
+        c3_bytes = it * DECODER_PARAM_BYTES + act * per_item_bytes(T_ENC)
+        c3_flops = act * per_item_flops(T_ENC)
+        extra["config3"] = {
+            "workload": "BASELINE.json configs[2]: %d utterances (40-200 ids) -> %d chunks in one padded/masked lock-step batch, %d frames, %d lock-step iterations (this rank)"
+            % (len(share), len(chunks), fr, it),
+            "mel_frames_per_s_mel_gen": fr / t_mel,
+            "ms": {"encoder": tm["encoder_ms"], "decoder_loop": tm["decoder_ms"], "postnet": tm["postnet_ms"], "wall_mel_gen": t_mel * 1e3},
+            "us_per_lockstep_iteration": tm["decoder_ms"] * 1e3 / it,
+            "roofline": {
+                "kernel": "the decoder iteration of the batched path (k_lstm_mfma x2 + prenet/energies/context/location kernels)",
+                "bound": "mfma",
+                "achieved": c3_flops / dsec / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": c3_flops / dsec / 1e12 / MFMA_F32_PEAK_TF,
+                "hbm_achieved_GBs": c3_bytes / dsec / 1e9, "hbm_frac": c3_bytes / dsec / 1e9 / HBM_PEAK_GBS,
+                "note": "at 52 chunks the step is balanced between the two roofs (1.0 GFLOP and 73 MB per iteration: 6.6 us of fp32 MFMA, 9.1 us of HBM); traffic: profiles/",
+            },
+        }
+        extra["config4"] = {
+            "workload": "BASELINE.json configs[3]: %d utterances, %d per GPU (length-sorted round-robin, xd-tts_amd/shard.py), batched mel-gen + per-utterance %d-iter Griffin-Lim"
+            % (len(all_utts), len(share), GL_ITERS),
+            "utterances_per_s": len(all_utts) / max_s,
+            "mel_frames_per_s": totals["frames"] / max_s,
+            "audio_samples_per_s": totals["samples"] / max_s,
+            "rtf": max_s / (totals["samples"] / SAMPLE_RATE),
+            "seconds_max_over_ranks": max_s,
+            "vocoder_ms_this_rank": voc_ms,
+            "per_rank": per_rank,
+        }
+        # ---- configs[4]: Griffin-Lim only, 1000 frames ------------------------------------------------
+        if rank == 0:
+            rng = np.random.default_rng(5)
+            F5 = 1000
+            S5 = np.abs(rng.standard_normal((513, F5))).astype(np.float32)   # timing does not depend on the values
+            c5 = {"workload": "BASELINE.json configs[4]: Griffin-Lim only, 513 x %d magnitude input (255 744 samples)" % F5, "runs": []}
+            for iters in (30, 60, 120):
+                for _ in range(3):
+                    a5 = vocoder.infer_linear(S5, iters=iters)
+                ms = vocoder.last_timings()["iterations_ms"]
+                gbs = GL_BYTES_PER_FRAME_ITER * F5 * iters / (ms * 1e-3) / 1e9
+                c5["runs"].append({"iterations": iters, "device_ms": ms, "us_per_iteration": ms * 1e3 / (iters + 1), "audio_samples_per_s": a5.size / (ms * 1e-3),
+                                   "roofline": {"kernel": "k_gl_persistent<4> (one launch: all iterations + final ISTFT)", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                                                "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}})
+            c5["note"] = "state (S, angles, previous spectrum) lives in LDS for the whole call, so `achieved` is algorithmic bytes per second (12 308 B per frame per iteration, SURVEY 8d); measured HBM traffic: profiles/"
+            extra["config5"] = c5
+            log("config5 done")
+        out["extra"] = extra
+
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(ids, splits, chunk_steps)
+            out["cpu_baseline"] = cpu_baseline()
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

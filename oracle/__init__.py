@@ -17,7 +17,7 @@ N_MEL, EMB, ATT_DIM, T_MAX = 80, 512, 128, 512
 def build(force=False):
     """gcc-compile liboracle_f32.so / liboracle_f64.so next to the sources."""
     src = [os.path.join(_HERE, f) for f in ("xdtts_oracle.c", "xdtts_oracle.h")]
-    out = [os.path.join(_HERE, f) for f in ("liboracle_f32.so", "liboracle_f64.so")]
+    out = [os.path.join(_HERE, f) for f in ("liboracle_f32.so", "liboracle_f64.so", "liboracle_f32_omp.so")]
     stale = force or any(
         (not os.path.exists(o)) or os.path.getmtime(o) < max(os.path.getmtime(s) for s in src) for o in out
     )
@@ -56,12 +56,16 @@ def _state_struct(ct):
 class Oracle:
     """One precision flavour of the oracle: Oracle('f32') or Oracle('f64')."""
 
-    def __init__(self, precision="f32"):
+    def __init__(self, precision="f32", omp=False):
+        """omp=True: the same f32 source compiled with -fopenmp (all host cores; identical results) --
+        bench.py's all-cores CPU baseline.  Thread count: OMP_NUM_THREADS / the runtime's default."""
         build()
+        if omp and precision != "f32":
+            raise ValueError("the OpenMP build exists for f32 only")
         self.precision = precision
         self.dtype = np.float32 if precision == "f32" else np.float64
         self.ct = C.c_float if precision == "f32" else C.c_double
-        self.lib = C.CDLL(os.path.join(_HERE, "liboracle_%s.so" % precision))
+        self.lib = C.CDLL(os.path.join(_HERE, "liboracle_%s%s.so" % (precision, "_omp" if omp else "")))
         self.State = _state_struct(self.ct)
         L = self.lib
         L.orc_rng_u32.restype = C.c_uint32

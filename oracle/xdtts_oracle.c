@@ -228,6 +228,10 @@ real orc_sigmoid(real x) {
 static void lstm_cell(const float *wih, const float *whh, const float *bih, const float *bhh,
                       const real *x, int nin, real *h, real *c, int hid) {
   real *g = (real *)malloc(sizeof(real) * 4 * hid);
+  /* The OpenMP pragmas in this file only split loops whose iterations are independent, so the
+   * all-cores build (liboracle_f32_omp.so, bench.py's cpu_baseline) computes bit-identical results;
+   * the checker builds are compiled without -fopenmp and ignore them. */
+#pragma omp parallel for schedule(static)
   for (int r = 0; r < 4 * hid; ++r)
     g[r] = dotw(wih + (size_t)r * nin, x, nin) + (real)bih[r] +
            (dotw(whh + (size_t)r * hid, h, hid) + (real)bhh[r]);
@@ -251,6 +255,7 @@ static void conv1d_bn(const float *w, const float *b, const float *bn_w, const f
   for (int o = 0; o < co; ++o)
     for (int c = 0; c < ci; ++c)
       for (int j = 0; j < k; ++j) wt[((size_t)o * k + j) * ci + c] = w[((size_t)o * ci + c) * k + j];
+#pragma omp parallel for schedule(static)
   for (int t = 0; t < T; ++t)
     for (int o = 0; o < co; ++o) {
       real s = 0;
@@ -382,6 +387,7 @@ void orc_decoder_step(const float *blob, const real *memory, const real *pmem, i
   real e[ORC_T_MAX];
   real emax = -INFINITY;
   const int pad = (ORC_LOC_K - 1) / 2;
+#pragma omp parallel for schedule(static)
   for (int t = 0; t < T; ++t) {
     real lc[ORC_LOC_F];
     for (int f = 0; f < ORC_LOC_F; ++f) {
@@ -404,8 +410,9 @@ void orc_decoder_step(const float *blob, const real *memory, const real *pmem, i
     }
     /* mask: true (=> -inf) for t >= unpadded length, src/tacotron2/mod.rs:219-220 */
     e[t] = t >= n_valid ? -INFINITY : en;
-    if (e[t] > emax) emax = e[t];
   }
+  for (int t = 0; t < T; ++t)
+    if (e[t] > emax) emax = e[t];
   real den = 0;
   for (int t = 0; t < T; ++t) {
     e[t] = (real)exp((double)(e[t] - emax));
@@ -415,6 +422,7 @@ void orc_decoder_step(const float *blob, const real *memory, const real *pmem, i
     s->aw[t] = e[t] / den;
     s->awc[t] += s->aw[t];
   }
+#pragma omp parallel for schedule(static)
   for (int c = 0; c < ORC_EMB; ++c) {
     real acc = 0;
     for (int t = 0; t < T; ++t) acc += s->aw[t] * memory[(size_t)t * ORC_EMB + c];
@@ -603,8 +611,9 @@ int orc_pinv(const float *basis, int n_mels, int n_bins, float *out) {
  * librosa mel_to_stft exponent 1/power (power = 1.7, src/tacotron2/mod.rs:456).               */
 void orc_mel_to_linear(const float *pinv, int n_mels, int n_bins, const real *mel, int F,
                        real power, real *S) {
-  real *col = (real *)malloc(sizeof(real) * n_mels);
+#pragma omp parallel for schedule(static)
   for (int t = 0; t < F; ++t) {
+    real col[512];
     for (int m = 0; m < n_mels; ++m) col[m] = (real)exp((double)mel[(size_t)m * F + t]);
     for (int b = 0; b < n_bins; ++b) {
       real v = 0;
@@ -613,7 +622,6 @@ void orc_mel_to_linear(const float *pinv, int n_mels, int n_bins, const real *me
       S[(size_t)b * F + t] = (real)pow((double)v, 1.0 / (double)power);
     }
   }
-  free(col);
 }
 
 void orc_phase_init(uint32_t seed, int n_bins, int F, real *phase0) {
@@ -626,9 +634,9 @@ void orc_phase_init(uint32_t seed, int n_bins, int F, real *phase0) {
 }
 
 /* in-place iterative radix-2 complex FFT, n power of two; sign -1 forward, +1 inverse (unscaled) */
-static void fft_c(real *re, real *im, int n, int sign) {
-  static int cached_n = 0;
-  static double *tw_c = NULL, *tw_s = NULL;
+static int cached_n = 0;
+static double *tw_c = NULL, *tw_s = NULL;
+static void fft_tables(int n) { /* called before any (possibly parallel) loop of fft_c calls */
   if (cached_n != n) {
     free(tw_c);
     free(tw_s);
@@ -640,6 +648,8 @@ static void fft_c(real *re, real *im, int n, int sign) {
     }
     cached_n = n;
   }
+}
+static void fft_c(real *re, real *im, int n, int sign) {
   for (int i = 1, j = 0; i < n; ++i) {
     int bit = n >> 1;
     for (; j & bit; bit >>= 1) j ^= bit;
@@ -676,9 +686,11 @@ static void hann_periodic(int n, real *w) {
 void orc_stft(const real *y, int n, int n_fft, int hop, real *out, int F) {
   int nb = n_fft / 2 + 1, half = n_fft / 2;
   real *win = (real *)malloc(sizeof(real) * n_fft);
-  real *re = (real *)malloc(sizeof(real) * n_fft), *im = (real *)malloc(sizeof(real) * n_fft);
   hann_periodic(n_fft, win);
+  fft_tables(n_fft);
+#pragma omp parallel for schedule(static)
   for (int t = 0; t < F; ++t) {
+    real *re = (real *)malloc(sizeof(real) * 2 * n_fft), *im = re + n_fft;
     for (int i = 0; i < n_fft; ++i) {
       /* numpy "reflect" padding: mirror without repeating the edge sample, period 2(n-1)
        * (a single mirror for the usual n > n_fft/2; folds repeatedly for very short signals) */
@@ -699,10 +711,9 @@ void orc_stft(const real *y, int n, int n_fft, int hop, real *out, int F) {
       out[((size_t)b * F + t) * 2 + 0] = re[b];
       out[((size_t)b * F + t) * 2 + 1] = im[b];
     }
+    free(re);
   }
   free(win);
-  free(re);
-  free(im);
 }
 
 /* librosa.istft(center=True, length=None): irfft each column, window, overlap-add, divide by
@@ -711,11 +722,14 @@ void orc_istft(const real *spec, int F, int n_fft, int hop, real *y) {
   int nb = n_fft / 2 + 1, half = n_fft / 2;
   int full = n_fft + hop * (F - 1);
   real *win = (real *)malloc(sizeof(real) * n_fft);
-  real *re = (real *)malloc(sizeof(real) * n_fft), *im = (real *)malloc(sizeof(real) * n_fft);
+  real *rows = (real *)malloc(sizeof(real) * (size_t)F * n_fft); /* irfft of every column */
   real *acc = (real *)calloc((size_t)full, sizeof(real));
   real *wss = (real *)calloc((size_t)full, sizeof(real));
   hann_periodic(n_fft, win);
+  fft_tables(n_fft);
+#pragma omp parallel for schedule(static)
   for (int t = 0; t < F; ++t) {
+    real *re = rows + (size_t)t * n_fft, *im = (real *)malloc(sizeof(real) * n_fft);
     for (int b = 0; b < nb; ++b) {
       re[b] = spec[((size_t)b * F + t) * 2 + 0];
       im[b] = spec[((size_t)b * F + t) * 2 + 1];
@@ -727,6 +741,10 @@ void orc_istft(const real *spec, int F, int n_fft, int hop, real *y) {
       im[n_fft - b] = -im[b];
     }
     fft_c(re, im, n_fft, +1);
+    free(im);
+  }
+  for (int t = 0; t < F; ++t) { /* overlap-add in ascending frame order (serial: the sums overlap) */
+    const real *re = rows + (size_t)t * n_fft;
     for (int i = 0; i < n_fft; ++i) {
       acc[(size_t)t * hop + i] += win[i] * (re[i] / (real)n_fft);
       wss[(size_t)t * hop + i] += win[i] * win[i];
@@ -738,8 +756,7 @@ void orc_istft(const real *spec, int F, int n_fft, int hop, real *y) {
     y[i] = w > tiny ? v / w : v;
   }
   free(win);
-  free(re);
-  free(im);
+  free(rows);
   free(acc);
   free(wss);
 }
@@ -762,6 +779,7 @@ static void griffinlim_iteration(const real *S, real *ang, real *reb, int F, int
   }
   orc_istft(est, F, n_fft, hop, inv);
   orc_stft(inv, n, n_fft, hop, reb, F);
+#pragma omp parallel for schedule(static)
   for (size_t i = 0; i < ne; ++i) {
     real ar = reb[2 * i] - alpha * prev[2 * i], ai = reb[2 * i + 1] - alpha * prev[2 * i + 1];
     real mag = (real)sqrt((double)(ar * ar + ai * ai)) + (real)1e-16;

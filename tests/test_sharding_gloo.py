@@ -54,6 +54,60 @@ def test_two_rank_sharding_covers_every_utterance_once(tmp_path):
     assert tot[2] == 0.75 and tot[3] == 2  # time = MAX over ranks
 
 
+class _StubModel:
+    """Stands in for the Tacotron2 handle (no GPU here): frames of the right shapes, tagged with the
+    chunk's first id so the per-utterance concatenation order can be checked."""
+
+    def infer_batch(self, chunks, opts=None, fixed_steps=None):
+        self.n = len(chunks)
+        return [np.full((80, s), float(c[0]), dtype=np.float32) for c, s in zip(chunks, fixed_steps)]
+
+    def last_timings(self):
+        return {"encoder_ms": 0.0, "decoder_ms": 1.0, "postnet_ms": 0.0, "total_ms": 1.0, "steps": 1}
+
+
+class _StubVocoder:
+    def infer(self, mel):
+        assert mel.shape[0] == 80
+        return np.zeros(256 * (mel.shape[1] - 1), dtype=np.float32)
+
+
+def _share_worker(rank, world, port, out_dir):
+    """The code path bench.py runs for BASELINE.json configs[3] (extra.config4): config4 utterances ->
+    plan_share -> run_share -> gather_counters, with stub handles instead of the GPU library."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = importlib.import_module("xd-tts_amd")            # host-side chunker only (find_splits needs no device)
+    wl = importlib.import_module("xd-tts_amd.workloads")
+    shard = importlib.import_module("xd-tts_amd.shard")
+    utts = wl.config4(pkg, n_batches=world)
+    share, chunks, steps, owner = shard.plan_share(lambda ids: wl.chunk_utterance(pkg, ids), utts, rank, world, wl.FRAMES_PER_ID_BATCH)
+    res = shard.run_share(_StubModel(), _StubVocoder(), share, chunks, steps, owner, None)
+    ok = all(len(c) <= 100 for c in chunks) and sorted(set(owner)) == sorted(share)
+    for u in share:  # chunks of an utterance stay in order and cover it exactly
+        ok = ok and np.array_equal(np.concatenate([c for c, o in zip(chunks, owner) if o == u]), utts[u])
+        ok = ok and res["audio"][u].size == 256 * (sum(s for s, o in zip(steps, owner) if o == u) - 1)
+    totals, max_s, per_rank = shard.gather_counters(res, dist)
+    np.save(os.path.join(out_dir, "s%d.npy" % rank), np.array([int(ok), len(share), len(chunks), res["frames"], res["samples"]]))
+    if rank == 0:
+        np.save(os.path.join(out_dir, "stot.npy"), np.array([totals["frames"], totals["samples"], len(per_rank), len(utts)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_config4_share_pipeline(tmp_path):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.environ["PYTHONPATH"] = root + os.pathsep + os.environ.get("PYTHONPATH", "")
+    world = 2
+    mp.spawn(_share_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    a, b, tot = np.load(tmp_path / "s0.npy"), np.load(tmp_path / "s1.npy"), np.load(tmp_path / "stot.npy")
+    assert a[0] == 1 and b[0] == 1
+    assert a[1] == b[1] == 32 and tot[3] == 64            # 32 utterances per rank (weak scaling)
+    assert tot[0] == a[3] + b[3] and tot[1] == a[4] + b[4] and tot[2] == 2
+    assert abs(int(a[3]) - int(b[3])) <= 0.05 * int(a[3])  # length-sorted round-robin balances the frames
+
+
 def test_single_process_path():
     shard = importlib.import_module("xd-tts_amd.shard")
     assert shard.shard_utterances([5, 9, 7], 0, 1) == [1, 2, 0]

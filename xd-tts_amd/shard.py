@@ -35,3 +35,39 @@ def gather_counters(local, dist=None, device="cpu"):
     totals = {k: sum(r[k] for r in per_rank) for k in ("frames", "samples")}
     max_seconds = max(r["seconds"] for r in per_rank)
     return totals, max_seconds, per_rank
+
+
+def plan_share(chunker, utterances, rank, world, frames_per_id):
+    """This rank's share of `utterances` (id arrays) as a lock-step batch: returns (share, chunks, steps,
+    owner) -- utterance indices (longest first), their <=window-id chunks in order (`chunker(ids)` is
+    find_splits + the trailing split, src/tacotron2/mod.rs:399,412-414), the fixed frame count of each
+    chunk (round(frames_per_id * len)), and the owning utterance of each chunk."""
+    share = shard_utterances([len(u) for u in utterances], rank, world)
+    chunks, steps, owner = [], [], []
+    for u in share:
+        for c in chunker(utterances[u]):
+            chunks.append(c)
+            steps.append(int(np.floor(frames_per_id * len(c) + 0.5)))
+            owner.append(u)
+    return share, chunks, steps, owner
+
+
+def run_share(model, vocoder, share, chunks, steps, owner, opts):
+    """XdTts::infer (src/lib.rs:110-159) for every utterance of a rank's share: all chunks through ONE
+    batched mel-gen call (chunks are independent, src/tacotron2/mod.rs:422-434), then per utterance the
+    chunk mels concatenated on the time axis (mod.rs:430) and the vocoder (lib.rs:141).  Returns the
+    counters gather_counters() takes plus the mel-gen / vocoder split."""
+    import time
+
+    t0 = time.perf_counter()
+    mels = model.infer_batch(chunks, opts=opts, fixed_steps=steps)
+    timings = model.last_timings()
+    t1 = time.perf_counter()
+    samples, audio = 0, {}
+    for u in share:
+        m = np.concatenate([mels[i] for i in range(len(chunks)) if owner[i] == u], axis=1)
+        audio[u] = vocoder.infer(m)
+        samples += audio[u].size
+    t2 = time.perf_counter()
+    return {"frames": int(sum(m.shape[1] for m in mels)), "samples": int(samples), "seconds": t2 - t0, "mel_gen_seconds": t1 - t0,
+            "vocoder_seconds": t2 - t1, "timings": timings, "mels": mels, "audio": audio}
