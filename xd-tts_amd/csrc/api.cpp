@@ -172,6 +172,8 @@ struct xdtts_tacotron2 {
   bool coop_ok = true;                      // cooperative encoder BiLSTM usable (cleared after a timed-out exchange)
   static constexpr int COOP_MAX_B = 16;  // 8*B blocks of 1024 threads must be co-resident
   DevBuf<float> att_h, att_c, dec_h, dec_c, aw, awc, ctx, x, loc, e_part, pmel, frames, gates;
+  DevBuf<float> frag;       // batched mode: MFMA-operand copies of x, ctx, att_h[2], dec_h[2]
+  DevBuf<int> item_perm;    // batched mode: dropout-stream index of the (length-sorted) chunks
   DevBuf<float> ppA, ppB, mel_dev;
   int *host_ctl = nullptr;  // pinned: [0..1] ctl, [2..] nframes
 
@@ -313,6 +315,18 @@ struct xdtts_tacotron2 {
     d.dropout_mode = o.dropout_mode;
     d.dropout_seed = o.dropout_seed;
     d.item_base = o.item_base;
+    if (B >= BATCH_MFMA_MIN) {  // MFMA B-operand copies [K/4][Bpad][4] of the vectors the LSTM GEMMs consume
+      const int Bpad = (B + 15) / 16 * 16;
+      frag.alloc((size_t)Bpad * (PRENET + EMB + 2 * ATT_RNN + 2 * DEC_RNN) + (size_t)B * T);
+      d.Bpad = Bpad;
+      d.xf = frag.p;
+      d.ctxf = d.xf + (size_t)Bpad * PRENET;
+      d.att_hf[0] = d.ctxf + (size_t)Bpad * EMB;
+      d.att_hf[1] = d.att_hf[0] + (size_t)Bpad * ATT_RNN;
+      d.dec_hf[0] = d.att_hf[1] + (size_t)Bpad * ATT_RNN;
+      d.dec_hf[1] = d.dec_hf[0] + (size_t)Bpad * DEC_RNN;
+      d.awc2 = d.dec_hf[1] + (size_t)Bpad * DEC_RNN;
+    }
     return d;
   }
 
@@ -577,22 +591,42 @@ struct xdtts_tacotron2 {
     }
     HIP_CHECK(hipSetDevice(device));
     HIP_CHECK(hipEventRecord(ev.e[0], stream));
-    ids.upload(ids_host, (size_t)B * T, stream);
-    n_valid.upload(lens, B, stream);
-    HIP_CHECK(hipStreamSynchronize(stream));  // ids_host may be a caller temporary
-    std::lock_guard<std::recursive_mutex> chip(chip_mutex(device));  // released after run_decoder's final sync
-    run_encoder(B, T);
-    HIP_CHECK(hipEventRecord(ev.e[1], stream));
-    std::vector<int> lim(B);
+    // Step caps per chunk, then (batched mode) the lock-step order: longest first, so that the chunks
+    // still running always fill a prefix of the 16-chunk MFMA tiles and finished tiles are skipped.
+    // order[j] = caller's index of the chunk decoded in slot j; everything below works on slots.
+    std::vector<int> lim0(B), order(B);
     for (int b = 0; b < B; ++b) {
       int l = o.max_steps;
       if (fixed_per_item) l = fixed_per_item[b];
       else if (o.fixed_steps > 0) l = o.fixed_steps;
       else if (o.fixed_frames_per_id > 0.f) l = (int)std::lround((double)o.fixed_frames_per_id * lens[b]);
-      lim[b] = std::min(std::max(l, 1), o.max_steps);
+      lim0[b] = std::min(std::max(l, 1), o.max_steps);
+      order[b] = b;
     }
+    const bool gate_off = fixed_per_item || o.fixed_steps > 0 || o.fixed_frames_per_id > 0.f;
+    if (B >= BATCH_MFMA_MIN)
+      std::stable_sort(order.begin(), order.end(), [&](int a, int c) {
+        return gate_off ? lim0[a] > lim0[c] : lens[a] > lens[c];  // with the gate on, length is the proxy for duration
+      });
+    std::vector<int64_t> ids_sorted((size_t)B * T);
+    std::vector<int> lens_sorted(B), lim(B);
+    for (int j = 0; j < B; ++j) {
+      std::copy(ids_host + (size_t)order[j] * T, ids_host + (size_t)(order[j] + 1) * T, ids_sorted.begin() + (size_t)j * T);
+      lens_sorted[j] = lens[order[j]];
+      lim[j] = lim0[order[j]];
+    }
+    ids_host = ids_sorted.data();
+    lens = lens_sorted.data();
+    ids.upload(ids_host, (size_t)B * T, stream);
+    n_valid.upload(lens, B, stream);
+    if (B >= BATCH_MFMA_MIN) item_perm.upload(order.data(), B, stream);
+    HIP_CHECK(hipStreamSynchronize(stream));  // ids_host may be a caller temporary
+    std::lock_guard<std::recursive_mutex> chip(chip_mutex(device));  // released after run_decoder's final sync
+    run_encoder(B, T);
+    HIP_CHECK(hipEventRecord(ev.e[1], stream));
     if (B >= BATCH_MFMA_MIN) w.ensure_batched_layout(blob, stream);
     DecoderBufs d = decoder_bufs(B, T, memory.p, pmem.p, o);
+    if (B >= BATCH_MFMA_MIN) d.item_perm = item_perm.p;
     if (fixed_per_item || o.fixed_frames_per_id > 0.f) d.use_gate = 0;
     last_steps = run_decoder(d, lim);
     if (encoder_exchange_failed()) {
@@ -605,21 +639,23 @@ struct xdtts_tacotron2 {
       last_steps = run_decoder(d, lim);
     }
     HIP_CHECK(hipEventRecord(ev.e[2], stream));
-    std::vector<int> F(B);
+    std::vector<int> Fs(B), F(B);  // frames per slot / per caller index
     int total = 0;
-    for (int b = 0; b < B; ++b) {
-      F[b] = host_ctl[2 + b];
-      total += F[b];
+    for (int j = 0; j < B; ++j) {
+      Fs[j] = host_ctl[2 + j];
+      F[order[j]] = Fs[j];
+      total += Fs[j];
     }
     mel_dev.alloc((size_t)N_MEL * total);
-    std::vector<int> col(B);
+    std::vector<int> col0(B), col(B);  // the final mel keeps the caller's chunk order on the time axis (mod.rs:430)
     for (int b = 0, off = 0; b < B; ++b) {
-      col[b] = off;
+      col0[b] = off;
       off += F[b];
     }
+    for (int j = 0; j < B; ++j) col[j] = col0[order[j]];
     for (int b = 0; b < B; b += GEMM_RAGGED_MAX) {
       const int n = std::min(GEMM_RAGGED_MAX, B - b);
-      run_postnet(d.frames + (size_t)b * d.max_steps * N_MEL, (size_t)d.max_steps * N_MEL, F.data() + b, col.data() + b, n,
+      run_postnet(d.frames + (size_t)b * d.max_steps * N_MEL, (size_t)d.max_steps * N_MEL, Fs.data() + b, col.data() + b, n,
                   mel_dev.p, total);
     }
     HIP_CHECK(hipEventRecord(ev.e[3], stream));

@@ -77,6 +77,17 @@ __global__ void k_decoder_init(DecoderBufs d, const int *limits) {
     d.nframes[b] = limits[b];
     if (b == 0) d.ctl[0] = 0;
   }
+  if (d.xf && b == 0) {  // batched mode: the MFMA-operand copies, padding columns included
+    const int n = blockDim.x, t = threadIdx.x;
+    for (int i = t; i < PRENET * d.Bpad; i += n) d.xf[i] = 0.f;
+    for (int i = t; i < EMB * d.Bpad; i += n) d.ctxf[i] = 0.f;
+    for (int i = t; i < ATT_RNN * d.Bpad; i += n) {
+      d.att_hf[0][i] = 0.f;
+      d.att_hf[1][i] = 0.f;
+      d.dec_hf[0][i] = 0.f;
+      d.dec_hf[1][i] = 0.f;
+    }
+  }
 }
 
 __global__ void k_advance(DecoderBufs d, int n) { d.ctl[0] += n; }
@@ -90,32 +101,40 @@ __global__ void k_advance(DecoderBufs d, int n) { d.ctl[0] += n; }
 // windows are the only LDS operands of the conv.
 constexpr int LOC_TT = 8;  // time steps per location block
 
-__device__ __forceinline__ void location_role(const DecoderBufs &d, int b, int tile,
-                                              const float *__restrict__ loc_convT,
-                                              const float *__restrict__ loc_denseT) {
+struct LocWeights {
+  float cw[2 * LOC_K];  // conv taps of filter tid & 31 (conv role)
+  float wd[LOC_F];      // dense weights of attention dim tid & 127 (dense role)
+};
+__device__ __forceinline__ void location_weights(LocWeights &lw, const float *__restrict__ loc_convT,
+                                                 const float *__restrict__ loc_denseT) {
+  const int tid = threadIdx.x, f = tid & 31, a = tid & 127;
+#pragma unroll
+  for (int j = 0; j < 2 * LOC_K; ++j) lw.cw[j] = loc_convT[j * LOC_F + f];
+#pragma unroll
+  for (int g = 0; g < LOC_F; ++g) lw.wd[g] = loc_denseT[g * ATT_DIM + a];
+}
+// One LOC_TT-step tile of chunk b from the chunk's attention weights aw / awc (length T; global or LDS).
+__device__ __forceinline__ void location_tile(const DecoderBufs &d, int b, int tile, const float *aw, const float *awc,
+                                              const LocWeights &lw) {
   constexpr int TT = LOC_TT, PADK = (LOC_K - 1) / 2, WIN = TT + 2 * PADK;
   const int t0 = tile * TT, tid = threadIdx.x;
   __shared__ __attribute__((aligned(16))) float s_w[2][WIN + 2], s_lc[TT][LOC_F];
   const int f = tid & 31, tl = tid >> 5;     // conv role: one (t, filter) output per thread
   const int a = tid & 127, th = tid >> 7;    // dense role: attention dim a, 4 time steps
-  float cw[2 * LOC_K];
-#pragma unroll
-  for (int j = 0; j < 2 * LOC_K; ++j) cw[j] = loc_convT[j * LOC_F + f];
-  float wd[LOC_F];
-#pragma unroll
-  for (int g = 0; g < LOC_F; ++g) wd[g] = loc_denseT[g * ATT_DIM + a];
+  (void)f;
+  __syncthreads();  // a previous tile's readers are done with s_w / s_lc
   if (tid < 2 * WIN) {
     const int c = tid / WIN, i = tid % WIN, t = t0 - PADK + i;
-    const float *src = c ? d.awc : d.aw;  // channel 0 = previous weights, 1 = cumulative
-    s_w[c][i] = (t >= 0 && t < d.T) ? src[b * d.T + t] : 0.f;
+    const float *src = c ? awc : aw;  // channel 0 = previous weights, 1 = cumulative
+    s_w[c][i] = (t >= 0 && t < d.T) ? src[t] : 0.f;
   }
   __syncthreads();
   {
     float acc = 0.f;
 #pragma unroll
-    for (int k = 0; k < LOC_K; ++k) acc = fmaf(cw[k], s_w[0][tl + k], acc);
+    for (int k = 0; k < LOC_K; ++k) acc = fmaf(lw.cw[k], s_w[0][tl + k], acc);
 #pragma unroll
-    for (int k = 0; k < LOC_K; ++k) acc = fmaf(cw[LOC_K + k], s_w[1][tl + k], acc);
+    for (int k = 0; k < LOC_K; ++k) acc = fmaf(lw.cw[LOC_K + k], s_w[1][tl + k], acc);
     s_lc[tl][f] = acc;
   }
   __syncthreads();
@@ -125,9 +144,16 @@ __device__ __forceinline__ void location_role(const DecoderBufs &d, int b, int t
     if (t >= d.T) break;
     float acc = 0.f;
 #pragma unroll
-    for (int g = 0; g < LOC_F; ++g) acc = fmaf(wd[g], s_lc[tloc][g], acc);
+    for (int g = 0; g < LOC_F; ++g) acc = fmaf(lw.wd[g], s_lc[tloc][g], acc);
     d.loc[((size_t)b * d.T + t) * ATT_DIM + a] = acc;
   }
+}
+__device__ __forceinline__ void location_role(const DecoderBufs &d, int b, int tile,
+                                              const float *__restrict__ loc_convT,
+                                              const float *__restrict__ loc_denseT) {
+  LocWeights lw;
+  location_weights(lw, loc_convT, loc_denseT);
+  location_tile(d, b, tile, d.aw + b * d.T, d.awc + b * d.T, lw);
 }
 
 // D5 + D6 + D1.  First launch of step s.
@@ -184,7 +210,7 @@ __global__ __launch_bounds__(256) void k_prenet(DecoderBufs d, int i, int flush,
   const float bias = tid < N_MEL + 1 ? proj_b[tid] : 0.f;
   const int step = d.ctl[0] + i;
   const int nf = d.nframes[b];
-  const uint32_t item = d.item_base + (uint32_t)b;
+  const uint32_t item = d.item_base + (uint32_t)(d.item_perm ? d.item_perm[b] : b);
   if (m4 < MEL_LD / 4) *reinterpret_cast<float4 *>(&s_red[part][4 * m4]) = racc;
   __syncthreads();
   const bool have_prev = step >= 1 && step - 1 < nf;  // the chunk was active at the previous step
@@ -251,6 +277,129 @@ __global__ __launch_bounds__(256) void k_prenet(DecoderBufs d, int i, int flush,
     if (d.dropout_mode)
       o = (rng_u32(d.dropout_seed, 0x1001u + 2u * item, (uint32_t)step * 256u + (uint32_t)j) >> 31) ? 0.f : 2.f * o;
     d.x[b * PRENET + j] = o;
+    if (d.xf) d.xf[((size_t)(j >> 2) * d.Bpad + b) * 4 + (j & 3)] = o;
+  }
+}
+
+// Batched form of k_prenet (B >= BATCH_MFMA_MIN).  With 16 blocks per chunk every block re-reads the
+// chunk's 264 partial-mel rows (88 KB) and all of W0 (80 KB): 150 MB of L2 reads per step at 52 chunks.
+// Here a chunk is PRENET_SPLIT blocks of 1024 threads: the partial rows, W0 and half of W1 are read
+// once per block (22 MB per step in total), all of them in flight at kernel entry.
+constexpr int PRENET_SPLIT = 2, PRENET_BT = 1024;
+__global__ __launch_bounds__(PRENET_BT) void k_prenet_b(DecoderBufs d, int i, int flush, const float *__restrict__ W0T,
+                                                        const float *__restrict__ W1T, const float *__restrict__ proj_b) {
+  constexpr int HALF = PRENET / PRENET_SPLIT;          // layer-2 columns of this block
+  constexpr int NPART = PRENET_BT / 32;                // 32 row groups of the partial-mel reduction
+  constexpr int ROWS = (PM_ROWS + NPART - 1) / NPART;  // 9 rows per group
+  constexpr int KG1 = PRENET_BT / 64, IN1 = N_MEL / KG1;       // layer 1: 16 input groups of 5
+  constexpr int KG2 = PRENET_BT / (HALF / 4), IN2 = PRENET / KG2;  // layer 2: 32 input groups of 8
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / PRENET_SPLIT, half = blockIdx.x % PRENET_SPLIT;
+  __shared__ __attribute__((aligned(16))) float s_red[NPART][MEL_LD], s_mel[MEL_LD], s_p1[KG1][PRENET], s_x1[PRENET], s_p2[KG2][HALF];
+  // ---- every global load of the kernel, issued before anything is waited for ----
+  const int m4 = tid & 31, part = tid >> 5;
+  const float4 *pm = reinterpret_cast<const float4 *>(d.pmel + (size_t)b * PM_ROWS * MEL_LD);
+  float4 rv[ROWS];
+#pragma unroll
+  for (int k = 0; k < ROWS; ++k) {
+    const int row = part + NPART * k;
+    rv[k] = (m4 < MEL_LD / 4 && row < PM_ROWS) ? pm[(size_t)row * (MEL_LD / 4) + m4] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int o4 = tid & 63, kg1 = tid >> 6;       // layer 1: outputs 4 o4 .. +3, inputs IN1 kg1 .. +IN1
+  const int c4 = tid % (HALF / 4), kg2 = tid / (HALF / 4);  // layer 2: columns HALF half + 4 c4 .. +3, inputs IN2 kg2 .. +IN2
+  float4 w0[IN1], w1[IN2];
+  if (!flush) {
+#pragma unroll
+    for (int k = 0; k < IN1; ++k) w0[k] = reinterpret_cast<const float4 *>(W0T)[(size_t)(kg1 * IN1 + k) * (PRENET / 4) + o4];
+#pragma unroll
+    for (int k = 0; k < IN2; ++k) w1[k] = reinterpret_cast<const float4 *>(W1T)[((size_t)(kg2 * IN2 + k) * PRENET + HALF * half) / 4 + c4];
+  }
+  const float bias = tid < N_MEL + 1 ? proj_b[tid] : 0.f;
+  const int step = d.ctl[0] + i;
+  const int nf = d.nframes[b];
+  const uint32_t item = d.item_base + (uint32_t)(d.item_perm ? d.item_perm[b] : b);
+  // ---- projection of the previous step: sum of the 264 partial rows in a fixed order ----
+  {
+    float4 r = rv[0];
+#pragma unroll
+    for (int k = 1; k < ROWS; ++k) {
+      r.x += rv[k].x;
+      r.y += rv[k].y;
+      r.z += rv[k].z;
+      r.w += rv[k].w;
+    }
+    if (m4 < MEL_LD / 4) *reinterpret_cast<float4 *>(&s_red[part][4 * m4]) = r;
+  }
+  __syncthreads();
+  const bool have_prev = step >= 1 && step - 1 < nf;  // the chunk was active at the previous step
+  if (tid < MEL_LD) {
+    float v = 0.f;
+    if (have_prev && tid < N_MEL + 1) {
+      v = bias;
+#pragma unroll
+      for (int k = 0; k < NPART; ++k) v += s_red[k][tid];
+    }
+    s_mel[tid] = v;  // step 0: decoder_input = 0 (mod.rs:208)
+  }
+  __syncthreads();
+  const float gate = s_mel[N_MEL];
+  const bool fired = have_prev && d.use_gate && gate_sigmoid(gate) > d.gate_threshold;
+  if (half == 0 && have_prev) {
+    if (tid < N_MEL) d.frames[((size_t)b * d.max_steps + (step - 1)) * N_MEL + tid] = s_mel[tid];
+    if (tid == 0) {
+      d.gates[(size_t)b * d.max_steps + (step - 1)] = gate;
+      if (fired) d.nframes[b] = step;  // frame step-1 is the last one (mod.rs:319-324)
+    }
+  }
+  if (flush || fired || step >= nf) return;
+  // ---- prenet layer 1 (every block, all 256 outputs) ----
+  {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < IN1; ++k) {
+      const float m = s_mel[kg1 * IN1 + k];
+      acc.x = fmaf(w0[k].x, m, acc.x);
+      acc.y = fmaf(w0[k].y, m, acc.y);
+      acc.z = fmaf(w0[k].z, m, acc.z);
+      acc.w = fmaf(w0[k].w, m, acc.w);
+    }
+    *reinterpret_cast<float4 *>(&s_p1[kg1][4 * o4]) = acc;
+  }
+  __syncthreads();
+  if (tid < PRENET) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < KG1; ++k) v += s_p1[k][tid];
+    v = fmaxf(v, 0.f);
+    if (d.dropout_mode)
+      v = (rng_u32(d.dropout_seed, 0x1000u + 2u * item, (uint32_t)step * 256u + (uint32_t)tid) >> 31) ? 0.f : 2.f * v;
+    s_x1[tid] = v;
+  }
+  __syncthreads();
+  // ---- prenet layer 2, this block's HALF columns ----
+  {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < IN2; ++k) {
+      const float m = s_x1[kg2 * IN2 + k];
+      acc.x = fmaf(w1[k].x, m, acc.x);
+      acc.y = fmaf(w1[k].y, m, acc.y);
+      acc.z = fmaf(w1[k].z, m, acc.z);
+      acc.w = fmaf(w1[k].w, m, acc.w);
+    }
+    *reinterpret_cast<float4 *>(&s_p2[kg2][4 * c4]) = acc;
+  }
+  __syncthreads();
+  if (tid < HALF) {
+    float o = 0.f;
+#pragma unroll
+    for (int k = 0; k < KG2; ++k) o += s_p2[k][tid];
+    o = fmaxf(o, 0.f);
+    const int j = HALF * half + tid;
+    if (d.dropout_mode)
+      o = (rng_u32(d.dropout_seed, 0x1001u + 2u * item, (uint32_t)step * 256u + (uint32_t)j) >> 31) ? 0.f : 2.f * o;
+    d.x[b * PRENET + j] = o;
+    d.xf[((size_t)(j >> 2) * d.Bpad + b) * 4 + (j & 3)] = o;
   }
 }
 
@@ -353,14 +502,6 @@ __global__ __launch_bounds__(256) void k_lstm(DecoderBufs d, int i, int cur, con
   }
 }
 
-// Batched mode: the location features of all chunks as their own launch (hundreds of small blocks;
-// as leading blocks of the 1024-thread GEMM launch they would delay it).
-__global__ __launch_bounds__(256) void k_location(DecoderBufs d, const float *__restrict__ loc_convT,
-                                                  const float *__restrict__ loc_denseT) {
-  const int tiles = (d.T + LOC_TT - 1) / LOC_TT;
-  location_role(d, blockIdx.x / tiles, blockIdx.x % tiles, loc_convT, loc_denseT);
-}
-
 // D2 / D4 for batches (B >= BATCH_MFMA_MIN chunks in lock-step): the LSTM pre-activations become
 // a GEMM  G[16 rows of a block][B chunks] = W[16 x K] . X^T[K x B]  on the exact-fp32 matrix
 // cores (v_mfma_f32_16x16x4_f32).  Still weight-streaming: a block owns the same 4 hidden units
@@ -371,105 +512,157 @@ __global__ __launch_bounds__(256) void k_location(DecoderBufs d, const float *__
 // unit lane/16) -- exactly the MFMA D layout -- and does the cell update in place.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int NCOLS, int KIND, int NT>  // NT = 16-chunk tiles per pass (compile-time: no branches around the MFMAs)
-__global__ __launch_bounds__(64 * MFMA_WAVES) void k_lstm_mfma(DecoderBufs d, int i, int cur, const float4 *__restrict__ Wm,
-                                                   const float *__restrict__ bias,
-                                                   const float4 *__restrict__ Wepi,
-                                                   const float *__restrict__ loc_convT,
-                                                   const float *__restrict__ loc_denseT) {
+// Operands: the weights in MFMA A-fragment order (weights.h) stream from HBM, one 16-byte load per
+// lane = the A operands of four MFMAs, the wave's whole slab in flight at kernel entry; the
+// activations come from the [K/4][Bpad][4] copies (kernels.h) with fully coalesced 16-byte loads,
+// software-pipelined three k-steps deep so that L2 latency hides behind the other tiles' MFMAs.
+// Tiles whose 16 chunks have all stopped are skipped (the batch is sorted by length, so the active
+// tiles form a prefix): NTA = active tiles of this pass, a compile-time count per code path.
+template <int NCOLS, int KIND, int NTA>
+__device__ __forceinline__ void lstm_mfma_pass(const DecoderBufs &d, int n0, int cur, int step, int blk, const float4 *__restrict__ wsrc,
+                                               const float4 bz, const float4 we, float *s_acc, float *s_h, unsigned long long d_probe_entry = 0) {
   constexpr int NW = MFMA_WAVES, KW = NCOLS / NW, JJ = KW / 16;
   constexpr int N0 = KIND == 0 ? PRENET : ATT_RNN, N1 = EMB;
-  const int blk = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fi = lane & 15, fg = lane >> 4;
-  const float4 *wsrc = Wm + ((size_t)(blk * NW + wave) * JJ) * 64 + lane;
-  const float4 bz = *reinterpret_cast<const float4 *>(bias + (blk * 4 + fg) * 4);  // unit fg's i,f,g,o biases
-  const int step = d.ctl[0] + i;
-  // the whole weight slab of this wave (16 rows x KW columns = 28..40 KB) goes in flight at once,
-  // like the GEMV kernels: HBM latency needs tens of KB in flight per CU to stream at full rate
-  float4 wreg[JJ];
+  const float4 *seg0 = reinterpret_cast<const float4 *>(KIND == 0 ? d.xf : d.att_hf[cur ^ 1]);
+  const float4 *seg1 = reinterpret_cast<const float4 *>(d.ctxf);
+  const float4 *seg2 = reinterpret_cast<const float4 *>(KIND == 0 ? d.att_hf[cur] : d.dec_hf[cur]);
+  auto src = [&](int jj) {  // first 16-byte vector of this lane for k-step jj (wave-uniform segment choice)
+    const int col = wave * KW + 16 * jj;
+    const float4 *sb = col < N0 ? seg0 + (size_t)(col >> 2) * d.Bpad
+                                : (col < N0 + N1 ? seg1 + (size_t)((col - N0) >> 2) * d.Bpad : seg2 + (size_t)((col - N0 - N1) >> 2) * d.Bpad);
+    return sb + (size_t)fg * d.Bpad + n0 + fi;
+  };
+#ifdef XDTTS_LSTM_PROBE
+  unsigned long long tp[6];
+  tp[0] = wall_clock64();
+#define PROBE(i) tp[i] = wall_clock64()
+#else
+#define PROBE(i) do { } while (0)
+#endif
+  f32x4 acc[NTA];
 #pragma unroll
-  for (int jj = 0; jj < JJ; ++jj) wreg[jj] = ld_stream(wsrc + (size_t)jj * 64);
-  __shared__ __attribute__((aligned(16))) float s_acc[NW][NT][64][4];  // [K-slice][tile][lane][gate]
-  __shared__ __attribute__((aligned(16))) float s_h[64][4];           // [chunk in super-tile][unit]
-  const float *seg0 = KIND == 0 ? d.x : d.att_h[cur ^ 1];
-  const float *seg1 = d.ctx;
-  const float *seg2 = KIND == 0 ? d.att_h[cur] : d.dec_h[cur];
+  for (int t = 0; t < NTA; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // A wave's loads retire in issue order (vmcnt), so the weight stream must NOT be issued as one block
+  // ahead of the activations -- the first activation vector would then wait for the wave's last weight,
+  // i.e. for the whole 42 MB HBM stream, and the MFMAs could not overlap it (measured: 5-12 us from kernel
+  // entry to the first MFMA).  Both streams are issued in consumption order instead: weights three
+  // k-steps ahead (HBM latency), activations two (L2).
+  float4 ring[3][NTA], wring[4];
+  constexpr int DW = 3, DX = 2;
+#pragma unroll
+  for (int p = 0; p < DW && p < JJ; ++p) {
+    wring[p] = ld_stream(wsrc + (size_t)p * 64);
+    if (p < DX) {
+      const float4 *sp = src(p);
+#pragma unroll
+      for (int t = 0; t < NTA; ++t) ring[p][t] = sp[16 * t];
+    }
+    asm volatile("" ::: "memory");
+  }
+#pragma unroll
+  for (int jj = 0; jj < JJ; ++jj) {
+    if (jj + DW < JJ) wring[(jj + DW) % 4] = ld_stream(wsrc + (size_t)(jj + DW) * 64);
+    if (jj + DX < JJ) {
+      const float4 *sp = src(jj + DX);
+#pragma unroll
+      for (int t = 0; t < NTA; ++t) ring[(jj + DX) % 3][t] = sp[16 * t];
+    }
+    asm volatile("" ::: "memory");
+    const float4 wv = wring[jj % 4];
+    const float4(&xv)[NTA] = ring[jj % 3];
+    // interleave the tiles so consecutive MFMAs hit different accumulators (40-cycle dependent latency)
+#pragma unroll
+    for (int t = 0; t < NTA; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, xv[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NTA; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, xv[t].y, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NTA; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.z, xv[t].z, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NTA; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, xv[t].w, acc[t], 0, 0, 0);
+  }
+  PROBE(1);
+  // [K-slice][tile][lane][gate]
+#pragma unroll
+  for (int t = 0; t < NTA; ++t) *reinterpret_cast<f32x4 *>(s_acc + ((size_t)(wave * 4 + t) * 64 + lane) * 4) = acc[t];
+  __syncthreads();
+  PROBE(2);
   float *h_out = KIND == 0 ? d.att_h[cur ^ 1] : d.dec_h[cur ^ 1];
+  float *hf_out = KIND == 0 ? d.att_hf[cur ^ 1] : d.dec_hf[cur ^ 1];
   float *cst = KIND == 0 ? d.att_c : d.dec_c;
-  for (int n0 = 0; n0 < d.B; n0 += 16 * NT) {
-    int nt[NT];  // chunk of this lane per tile (clamped: tiles past B recompute the last chunk, unused)
+  if (wave < NTA) {  // wave t finalises chunk tile t: lane = (chunk fi, unit fg), regs = gates i,f,g,o
+    f32x4 g = *reinterpret_cast<const f32x4 *>(s_acc + ((size_t)wave * 64 + lane) * 4);
 #pragma unroll
-    for (int t = 0; t < NT; ++t) nt[t] = min(n0 + 16 * t + fi, d.B - 1);
-    f32x4 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int jj = 0; jj < JJ; ++jj) {
-      const int col = wave * KW + 16 * jj;  // wave-uniform; segment boundaries are multiples of 16
-      const float4 wv = wreg[jj];
-      const float *sb;
-      int stride, off;
-      if (col < N0) {
-        sb = seg0;
-        stride = N0;
-        off = col;
-      } else if (col < N0 + N1) {
-        sb = seg1;
-        stride = N1;
-        off = col - N0;
-      } else {
-        sb = seg2;
-        stride = ATT_RNN;
-        off = col - N0 - N1;
+    for (int q = 1; q < NW; ++q) g += *reinterpret_cast<const f32x4 *>(s_acc + ((size_t)(q * 4 + wave) * 64 + lane) * 4);
+    const int n = n0 + 16 * wave + fi, unit = blk * 4 + fg;
+    float hn = 0.f;
+    if (n < d.B) {
+      const float c_old = cst[(size_t)n * ATT_RNN + unit];
+      // hardware exp2 / rcp forms (device_utils.h), as in the persistent engine: this tail runs on NTA of
+      // the 16 waves while the others wait
+      const float ig = fast_sigmoid(g[0] + bz.x), fgt = fast_sigmoid(g[1] + bz.y);
+      const float gg = fast_tanh(g[2] + bz.z), og = fast_sigmoid(g[3] + bz.w);
+      const float cn = fmaf(fgt, c_old, ig * gg);
+      hn = og * fast_tanh(cn);
+      if (step < d.nframes[n]) {
+        cst[(size_t)n * ATT_RNN + unit] = cn;
+        h_out[(size_t)n * ATT_RNN + unit] = hn;
+        hf_out[((size_t)blk * d.Bpad + n) * 4 + fg] = hn;
       }
-      float4 xv[NT];
-#pragma unroll
-      for (int t = 0; t < NT; ++t) xv[t] = *reinterpret_cast<const float4 *>(sb + (size_t)nt[t] * stride + off + 4 * fg);
-      // interleave the tiles so consecutive MFMAs hit different accumulators (40-cycle dependent latency)
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, xv[t].x, acc[t], 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, xv[t].y, acc[t], 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.z, xv[t].z, acc[t], 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, xv[t].w, acc[t], 0, 0, 0);
     }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) *reinterpret_cast<f32x4 *>(s_acc[wave][t][lane]) = acc[t];
+    s_h[(16 * wave + fi) * 4 + fg] = hn;
+  }
+  PROBE(3);
+  if (KIND == 1) {  // partial mel of this block's four hidden units, for every chunk of the active tiles
     __syncthreads();
-    if (wave < NT) {  // wave t finalises chunk tile t: lane = (chunk fi, unit fg), regs = gates i,f,g,o
-      f32x4 g = *reinterpret_cast<const f32x4 *>(s_acc[0][wave][lane]);
-#pragma unroll
-      for (int q = 1; q < NW; ++q) g += *reinterpret_cast<const f32x4 *>(s_acc[q][wave][lane]);
-      const int n = n0 + 16 * wave + fi, unit = blk * 4 + fg;
-      float hn = 0.f;
-      if (n < d.B) {
-        const float c_old = cst[(size_t)n * ATT_RNN + unit];
-        const float ig = sigmoidf_(g[0] + bz.x), fgt = sigmoidf_(g[1] + bz.y);
-        const float gg = tanhf(g[2] + bz.z), og = sigmoidf_(g[3] + bz.w);
-        const float cn = fmaf(fgt, c_old, ig * gg);
-        hn = og * tanhf(cn);
-        if (step < d.nframes[n]) {
-          cst[(size_t)n * ATT_RNN + unit] = cn;
-          h_out[(size_t)n * ATT_RNN + unit] = hn;
-        }
-      }
-      s_h[16 * wave + fi][fg] = hn;
-    }
-    if (KIND == 1) {  // partial mel of this block's four hidden units, for every chunk of the super-tile
-      __syncthreads();
-      const int nb = min(16 * NT, d.B - n0);
-      for (int idx = tid; idx < nb * MEL_LD; idx += 64 * NW) {
-        const int bl = idx / MEL_LD, m = idx % MEL_LD;
-        const float4 we = Wepi[(size_t)blk * MEL_LD + m];
-        const float4 h4 = *reinterpret_cast<const float4 *>(s_h[bl]);
+    const int nb = min(16 * NTA, d.B - n0);
+    // thread -> mel row m = tid % 84 (its four weights were fetched at kernel entry), chunks tid / 84 + 12 j
+    const int m = tid % MEL_LD;
+    if (tid < MEL_LD * (64 * NW / MEL_LD))
+      for (int bl = tid / MEL_LD; bl < nb; bl += 64 * NW / MEL_LD) {
+        const float4 h4 = *reinterpret_cast<const float4 *>(s_h + 4 * bl);
         if (step < d.nframes[n0 + bl])
           d.pmel[((size_t)(n0 + bl) * PM_ROWS + CTX_BLOCKS + blk) * MEL_LD + m] =
               fmaf(we.w, h4.w, fmaf(we.z, h4.z, fmaf(we.y, h4.y, we.x * h4.x)));
       }
-    }
-    __syncthreads();
+  }
+  __syncthreads();
+  PROBE(4);
+#ifdef XDTTS_LSTM_PROBE
+  if ((blk == 3 || blk == 200) && (tid == 0 || tid == 64 * 9) && (step == 100 || step == 101))
+    printf("probe kind %d blk %d wave %d step %d NTA %d: entry->loop %llu  loop %llu  store+sync %llu  cell %llu  pmel+sync %llu (x10ns)\n", KIND, blk, wave, step, NTA,
+           tp[0] - d_probe_entry, tp[1] - tp[0], tp[2] - tp[1], tp[3] - tp[2], tp[4] - tp[3]);
+#endif
+}
+
+template <int NCOLS, int KIND>
+__global__ __launch_bounds__(64 * MFMA_WAVES) void k_lstm_mfma(DecoderBufs d, int i, int cur, const float4 *__restrict__ Wm,
+                                                               const float *__restrict__ bias, const float4 *__restrict__ Wepi) {
+  constexpr int NW = MFMA_WAVES, KW = NCOLS / NW, JJ = KW / 16;
+#ifdef XDTTS_LSTM_PROBE
+  const unsigned long long t_entry = wall_clock64();
+#else
+  const unsigned long long t_entry = 0;
+#endif
+  const int blk = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fg = lane >> 4;
+  const float4 *wsrc = Wm + ((size_t)(blk * NW + wave) * JJ) * 64 + lane;
+  const int n0 = 64 * blockIdx.y;  // 64 chunks (four MFMA tiles) per block row; B > 64 adds rows that stream the weights again
+  const int step = d.ctl[0] + i;
+  // active tiles (wave-uniform, identical in every wave): lane -> chunk n0 + lane
+  const bool a = n0 + lane < d.B && step < d.nframes[min(n0 + lane, d.B - 1)];
+  const unsigned long long m = __ballot(a);
+  const int nta = m ? (63 - __clzll((long long)m)) / 16 + 1 : 0;
+  const float4 bz = *reinterpret_cast<const float4 *>(bias + (blk * 4 + fg) * 4);  // unit fg's i,f,g,o biases
+  const float4 we = (KIND == 1 && tid < MEL_LD * (64 * NW / MEL_LD)) ? Wepi[(size_t)blk * MEL_LD + tid % MEL_LD] : make_float4(0.f, 0.f, 0.f, 0.f);
+  __shared__ __attribute__((aligned(16))) float s_acc[NW * 4 * 64 * 4];  // [K-slice][tile][lane][gate]
+  __shared__ __attribute__((aligned(16))) float s_h[64 * 4];             // [chunk in super-tile][unit]
+  switch (nta) {
+    case 1: lstm_mfma_pass<NCOLS, KIND, 1>(d, n0, cur, step, blk, wsrc, bz, we, s_acc, s_h, t_entry); break;
+    case 2: lstm_mfma_pass<NCOLS, KIND, 2>(d, n0, cur, step, blk, wsrc, bz, we, s_acc, s_h, t_entry); break;
+    case 3: lstm_mfma_pass<NCOLS, KIND, 3>(d, n0, cur, step, blk, wsrc, bz, we, s_acc, s_h, t_entry); break;
+    case 4: lstm_mfma_pass<NCOLS, KIND, 4>(d, n0, cur, step, blk, wsrc, bz, we, s_acc, s_h, t_entry); break;
+    default: break;
   }
 }
 
@@ -530,7 +723,8 @@ __global__ __launch_bounds__(256) void k_qenergy(DecoderBufs d, int i, int cur, 
 // the encoder memory is spread over several CUs; it is issued as 16-byte lane-consecutive loads,
 // prefetched at kernel entry (addresses do not depend on the softmax).  Block 0 also stores the
 // new attention weights.
-__global__ __launch_bounds__(256) void k_softmax_ctx(DecoderBufs d, int i, const float *__restrict__ proj_wc) {
+__global__ __launch_bounds__(256) void k_softmax_ctx(DecoderBufs d, int i, const float *__restrict__ proj_wc,
+                                                     const float *__restrict__ loc_convT, const float *__restrict__ loc_denseT) {
   const int b = blockIdx.x / CTX_BLOCKS, cblk = blockIdx.x % CTX_BLOCKS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int T = d.T;
@@ -552,6 +746,16 @@ __global__ __launch_bounds__(256) void k_softmax_ctx(DecoderBufs d, int i, const
     const int t = tg + TG * u;
     pf[u] = t < T ? mem[(size_t)t * (EMB / 4) + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  // Batched mode: the NEXT step's location features are this kernel's tail (every block holds the whole
+  // softmax, so the 8 blocks of a chunk split the time tiles) instead of a launch of their own; the
+  // cumulative weights ping-pong between two buffers by step parity because the other blocks of the
+  // chunk still read the old ones while block 0 writes the new.
+  const bool batched = d.xf != nullptr;
+  __shared__ float s_awc[T_MAX];
+  LocWeights lw;
+  if (batched) location_weights(lw, loc_convT, loc_denseT);
+  const float *awc_in = batched && (i & 1) ? d.awc2 : d.awc;
+  float *awc_out = batched ? ((i & 1) ? d.awc : d.awc2) : d.awc;
   const int nv = d.n_valid[b];
   for (int t = tid; t < T; t += 256) {
     const float *ep = d.e_part + (size_t)b * (ATT_DIM / 4) * T + t;
@@ -580,12 +784,14 @@ __global__ __launch_bounds__(256) void k_softmax_ctx(DecoderBufs d, int i, const
     for (int t = lane; t < T; t += 64) s_e[t] = s_e[t] / sum;
   }
   __syncthreads();
-  if (act && cblk == 0)
-    for (int t = tid; t < T; t += 256) {
-      const float wv = s_e[t];
+  for (int t = tid; t < T; t += 256) {
+    const float wv = s_e[t], cum = awc_in[b * T + t] + wv;
+    s_awc[t] = cum;
+    if (act && cblk == 0) {
       d.aw[b * T + t] = wv;
-      d.awc[b * T + t] += wv;
+      awc_out[b * T + t] = cum;
     }
+  }
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   int k = 0;
   for (int t0 = tg; t0 < T; t0 += TG * CTX_PF) {
@@ -608,7 +814,13 @@ __global__ __launch_bounds__(256) void k_softmax_ctx(DecoderBufs d, int i, const
 #pragma unroll
     for (int g = 0; g < TG; ++g) v += s_part[g][tid];
     s_ctx[tid] = v;
-    if (act) d.ctx[b * EMB + cblk * CTX_COLS + tid] = v;
+    if (act) {
+      d.ctx[b * EMB + cblk * CTX_COLS + tid] = v;
+      if (d.ctxf) {
+        const int j = cblk * CTX_COLS + tid;
+        d.ctxf[((size_t)(j >> 2) * d.Bpad + b) * 4 + (j & 3)] = v;
+      }
+    }
   }
   __syncthreads();
   // partial mel of these context columns: pmel[cblk][m] = W_p[m][1024 + cols] . ctx[cols]
@@ -619,6 +831,8 @@ __global__ __launch_bounds__(256) void k_softmax_ctx(DecoderBufs d, int i, const
     pv += dpp_move<0xB1, 0xf>(0.f, pv);  // lanes 2j, 2j+1 hold the two halves of row m
     if (act && pm_half == 0 && pm_m <= N_MEL) d.pmel[((size_t)b * PM_ROWS + cblk) * MEL_LD + pm_m] = pv;
   }
+  if (batched && act)
+    for (int tile = cblk; tile * LOC_TT < T; tile += CTX_BLOCKS) location_tile(d, b, tile, s_e, s_awc, lw);
 }
 
 }  // namespace
@@ -646,28 +860,23 @@ void launch_decoder_steps(const DecoderBufs &d, const DeviceWeights &w, int nste
   // letters p,a,q,s,d selecting which kernels a step launches, e.g. "ppppp".
   const char *mix = getenv("XDTTS_DEBUG_MIX");
   const std::string order = mix ? mix : "paqsd";
-  const bool batched = d.B >= BATCH_MFMA_MIN && w.att_wm.p && w.dec_wm.p;  // LSTMs as MFMA GEMMs
+  const bool batched = d.B >= BATCH_MFMA_MIN && w.att_wm.p && w.dec_wm.p && d.xf;  // LSTMs as MFMA GEMMs
   const float4 *att_wm = reinterpret_cast<const float4 *>(w.att_wm.p), *dec_wm = reinterpret_cast<const float4 *>(w.dec_wm.p);
-  const int nt_tiles = std::min(4, (d.B + 15) / 16);  // 16-chunk tiles per pass over the weights
   for (int i = 0; i < nsteps; ++i) {
     const int cur = i & 1;
     for (char k : order) {
       switch (k) {
         case 'p':
-          hipLaunchKernelGGL(k_prenet, dim3(PRENET_BLOCKS * d.B), dim3(256), 0, s, d, i, 0, w.pre0T.p, w.pre1T.p,
-                             w.proj_b.p);
+          if (batched)
+            hipLaunchKernelGGL(k_prenet_b, dim3(PRENET_SPLIT * d.B), dim3(PRENET_BT), 0, s, d, i, 0, w.pre0T.p, w.pre1T.p, w.proj_b.p);
+          else
+            hipLaunchKernelGGL(k_prenet, dim3(PRENET_BLOCKS * d.B), dim3(256), 0, s, d, i, 0, w.pre0T.p, w.pre1T.p,
+                               w.proj_b.p);
           break;
         case 'a':
-          if (batched) {
-            auto launch = [&](auto kern) {
-              hipLaunchKernelGGL(kern, dim3(NBLK), dim3(64 * MFMA_WAVES), 0, s, d, i, cur, att_wm, w.att_b.p, q4, w.loc_conv.p,
-                                 w.loc_denseT.p);
-            };
-            if (nt_tiles == 1) launch(k_lstm_mfma<ATT_COLS, 0, 1>);
-            else if (nt_tiles == 2) launch(k_lstm_mfma<ATT_COLS, 0, 2>);
-            else if (nt_tiles == 3) launch(k_lstm_mfma<ATT_COLS, 0, 3>);
-            else launch(k_lstm_mfma<ATT_COLS, 0, 4>);
-          } else
+          if (batched)
+            hipLaunchKernelGGL((k_lstm_mfma<ATT_COLS, 0>), dim3(NBLK, (d.B + 63) / 64), dim3(64 * MFMA_WAVES), 0, s, d, i, cur, att_wm, w.att_b.p, q4);
+          else
             hipLaunchKernelGGL((k_lstm<ATT_COLS, 0>), dim3(NBLK), dim3(256), 0, s, d, i, cur, att_w, w.att_b.p, q4,
                                w.loc_conv.p, w.loc_denseT.p);
           break;
@@ -676,19 +885,11 @@ void launch_decoder_steps(const DecoderBufs &d, const DeviceWeights &w, int nste
                              reinterpret_cast<const float4 *>(w.q_w.p), w.v_w.p);
           break;
         case 's':
-          hipLaunchKernelGGL(k_softmax_ctx, dim3(CTX_BLOCKS * d.B), dim3(256), 0, s, d, i, w.proj_wc.p);
+          hipLaunchKernelGGL(k_softmax_ctx, dim3(CTX_BLOCKS * d.B), dim3(256), 0, s, d, i, w.proj_wc.p, w.loc_conv.p, w.loc_denseT.p);
           break;
         case 'd':
           if (batched) {
-            auto launch = [&](auto kern) {
-              hipLaunchKernelGGL(kern, dim3(NBLK), dim3(64 * MFMA_WAVES), 0, s, d, i, cur, dec_wm, w.dec_b.p, wh4,
-                                 w.loc_conv.p, w.loc_denseT.p);
-            };
-            hipLaunchKernelGGL(k_location, dim3(loc_tiles * d.B), dim3(256), 0, s, d, w.loc_conv.p, w.loc_denseT.p);
-            if (nt_tiles == 1) launch(k_lstm_mfma<DEC_COLS, 1, 1>);
-            else if (nt_tiles == 2) launch(k_lstm_mfma<DEC_COLS, 1, 2>);
-            else if (nt_tiles == 3) launch(k_lstm_mfma<DEC_COLS, 1, 3>);
-            else launch(k_lstm_mfma<DEC_COLS, 1, 4>);
+            hipLaunchKernelGGL((k_lstm_mfma<DEC_COLS, 1>), dim3(NBLK, (d.B + 63) / 64), dim3(64 * MFMA_WAVES), 0, s, d, i, cur, dec_wm, w.dec_b.p, wh4);
           } else
             hipLaunchKernelGGL((k_lstm<DEC_COLS, 1>), dim3(loc_tiles * d.B + NBLK), dim3(256), 0, s, d, i, cur, dec_w,
                                w.dec_b.p, wh4, w.loc_conv.p, w.loc_denseT.p);
@@ -704,7 +905,10 @@ void launch_decoder_steps(const DecoderBufs &d, const DeviceWeights &w, int nste
 
 // After the last step of a sequence: finishes the projection of the final step (frames, gate).
 void launch_decoder_flush(const DecoderBufs &d, const DeviceWeights &w, hipStream_t s) {
-  hipLaunchKernelGGL(k_prenet, dim3(PRENET_BLOCKS * d.B), dim3(256), 0, s, d, 0, 1, w.pre0T.p, w.pre1T.p, w.proj_b.p);
+  if (d.xf)
+    hipLaunchKernelGGL(k_prenet_b, dim3(PRENET_SPLIT * d.B), dim3(PRENET_BT), 0, s, d, 0, 1, w.pre0T.p, w.pre1T.p, w.proj_b.p);
+  else
+    hipLaunchKernelGGL(k_prenet, dim3(PRENET_BLOCKS * d.B), dim3(256), 0, s, d, 0, 1, w.pre0T.p, w.pre1T.p, w.proj_b.p);
   HIP_CHECK(hipGetLastError());
 }
 

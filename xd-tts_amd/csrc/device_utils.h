@@ -55,5 +55,13 @@ __device__ __forceinline__ float gate_sigmoid(float x) {
   return e / (1.0f + e);
 }
 
+// Hardware exp2/rcp forms for the few transcendental chains that sit on the per-step critical path
+// (cell updates, energies, softmax).  v_exp_f32 / v_rcp_f32 are 1-ulp instructions; against libm's
+// expf/tanhf the results move by a few 1e-7 absolute, far inside the 1e-4 parity bar, and each cell
+// update loses ~120 dependent instructions.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + fast_exp(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(fast_exp(2.0f * x) + 1.0f); }
+
 }  // namespace
 }  // namespace xdtts

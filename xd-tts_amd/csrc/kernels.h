@@ -32,6 +32,14 @@ struct DecoderBufs {
   float gate_threshold;
   int dropout_mode;
   uint32_t dropout_seed, item_base;
+  // Batched mode only (B >= BATCH_MFMA_MIN; null otherwise).  A second copy of the vectors the two
+  // LSTM GEMMs consume, in MFMA B-operand order [K/4][Bpad][4] (Bpad = B rounded up to 16, padding
+  // zero): lane (chunk, k-quad) of a 16-chunk tile loads one 16-byte vector and the 64 lanes of a wave
+  // cover four fully used 256-byte runs.  Written by the producers next to the row-major vectors.
+  float *xf, *ctxf, *att_hf[2], *dec_hf[2];
+  int Bpad;
+  float *awc2;           // [B][T] second cumulative-weights buffer (ping-pong by step parity, batched mode)
+  const int *item_perm;  // [B] dropout-stream index of chunk b (the batch is sorted by length), or null = b
 };
 
 // Enqueues `nsteps` decoder steps on `s` (5 kernels each) and advances the device step base.
