@@ -63,10 +63,17 @@ void xdtts_infer_opts_default(xdtts_infer_opts *opts);
 
 /* ---- Tacotron2 -------------------------------------------------------------------------- */
 
-/* Tacotron2::load(path) -- src/tacotron2/mod.rs:242-267.  `dir` holds the weight container
- * `tacotron2.xdtw` (DESIGN.md "weight container"); the ONNX initialiser importer is the next
- * scope row. */
+/* Tacotron2::load(path) -- src/tacotron2/mod.rs:242-267.  `dir` is the reference's model directory:
+ * encoder.onnx, decoder_iter.onnx and postnet.onnx (mod.rs:246-259) are read directly (a minimal
+ * protobuf reader pulls the weights out of the graphs; nothing of the graphs is executed), or, if
+ * present, the flat container `tacotron2.xdtw` written by xdtts_tacotron2_save.  A git-LFS pointer
+ * file in place of a graph gives XDTTS_ERR_IO with a message naming `git lfs pull`. */
 xdtts_status xdtts_tacotron2_load(const char *dir, int32_t device_id, xdtts_tacotron2 **out);
+
+/* The host half of Tacotron2::load: reads `dir` (ONNX graphs or tacotron2.xdtw, as above) into a
+ * caller-held flat fp32 blob in canonical tensor order (n_floats == xdtts_tensor_total()).  Needs no
+ * device; xdtts_tacotron2_load(dir) == this + xdtts_tacotron2_load_blob. */
+xdtts_status xdtts_model_dir_read(const char *dir, float *blob, size_t n_floats);
 
 /* Seeded synthetic weights with the checkpoint's exact shapes. */
 xdtts_status xdtts_tacotron2_load_synthetic(uint32_t seed, float rec_scale, int32_t device_id,

@@ -235,11 +235,16 @@ def test_onnx_export_converts_and_loads(pkg, model, blob, tmp_path):
     T = {name: blob[off : off + int(np.prod(shape))].reshape(shape) for name, shape, off in pkg.tensor_table()}
     assert [n for n, _ in conv.tensor_table()] == [t[0] for t in pkg.tensor_table()]
     onnx_writer.write_models(str(tmp_path), T, "named")
-    conv.write_container(str(tmp_path), conv.collect(str(tmp_path)))
     ids = synth_ids(40)
     o = pkg.default_opts(fixed_steps=30, dropout_seed=8)
     want = model.infer(ids, opts=o)
-    m = pkg.Tacotron2.load(str(tmp_path))
+    m = pkg.Tacotron2.load(str(tmp_path))                      # straight from the three .onnx files (csrc/onnx_load.cpp)
     got = m.infer(ids, opts=o)
     m.close()
     assert got.shape == want.shape == (80, 30) and np.array_equal(got, want)
+    (tmp_path / "c").mkdir()
+    conv.write_container(str(tmp_path / "c"), conv.collect(str(tmp_path)))   # and through the offline converter
+    m = pkg.Tacotron2.load(str(tmp_path / "c"))
+    got = m.infer(ids, opts=o)
+    m.close()
+    assert np.array_equal(got, want)

@@ -79,3 +79,57 @@ def test_reference_checkout_holds_pointers_only():
     if not os.path.exists(ref):
         pytest.skip("reference checkout not present on this box")
     assert os.path.getsize(ref) < 1024 and open(ref, "rb").read(24).startswith(b"version https://git-lfs")
+
+
+# ---- the same import inside the library: Tacotron2::load(dir) on the reference's model directory ----
+
+@pytest.mark.parametrize("style", ["named", "folded"])
+def test_library_reads_the_onnx_model_dir(pkg, tmp_path, style):
+    """xdtts_model_dir_read (csrc/onnx_load.cpp, the host half of xdtts_tacotron2_load) on the three graphs."""
+    T = random_tensors(5 if style == "named" else 6)
+    onnx_writer.write_models(str(tmp_path), T, style)
+    got = pkg.read_model_dir(str(tmp_path))
+    assert list(got) == [n for n, _ in conv.tensor_table()]
+    for name, _shape in conv.tensor_table():
+        if style == "folded" and ".bn." in name:
+            want = {"weight": 1.0, "bias": 0.0, "running_mean": 0.0, "running_var": np.float32(1.0 - 1e-5)}[name.rsplit(".", 1)[1]]
+            assert np.all(got[name] == np.float32(want)), name
+        else:
+            assert np.array_equal(got[name], T[name]), name
+    # identical to the offline converter's container, and the container wins when both are present
+    conv.write_container(str(tmp_path), conv.collect(str(tmp_path)))
+    again = pkg.read_model_dir(str(tmp_path))
+    assert all(np.array_equal(again[n], got[n]) for n in got)
+
+
+def test_library_reports_lfs_pointers_and_broken_files(pkg, tmp_path):
+    """The reference checkout ships git-LFS pointers (models/tacotron2/*.onnx are 133-byte text files): the
+    load must say so; truncated or garbage files must fail cleanly (XDTTS_ERR_IO), never crash."""
+    with pytest.raises(pkg.XdttsError) as e:
+        pkg.read_model_dir(str(tmp_path))                       # empty directory
+    assert e.value.status == pkg.XDTTS_ERR_IO and "encoder.onnx" in str(e.value)
+    for f in ("encoder", "decoder_iter", "postnet"):
+        (tmp_path / (f + ".onnx")).write_bytes(b"version https://git-lfs.github.com/spec/v1\noid sha256:c16355ad\nsize 22641034\n")
+    with pytest.raises(pkg.XdttsError) as e:
+        pkg.read_model_dir(str(tmp_path))
+    assert e.value.status == pkg.XDTTS_ERR_IO and "git lfs pull" in str(e.value)
+    T = random_tensors(7)
+    onnx_writer.write_models(str(tmp_path), T, "named")
+    good = (tmp_path / "decoder_iter.onnx").read_bytes()
+    rng = np.random.Generator(np.random.PCG64(1))
+    for cut in (10, 1000, len(good) // 2, len(good) - 5):
+        (tmp_path / "decoder_iter.onnx").write_bytes(good[:cut])
+        with pytest.raises(pkg.XdttsError) as e:
+            pkg.read_model_dir(str(tmp_path))
+        assert e.value.status == pkg.XDTTS_ERR_IO
+    (tmp_path / "decoder_iter.onnx").write_bytes(bytes(rng.integers(0, 256, 4096, dtype=np.uint8)))
+    with pytest.raises(pkg.XdttsError) as e:
+        pkg.read_model_dir(str(tmp_path))
+    assert e.value.status == pkg.XDTTS_ERR_IO
+    (tmp_path / "decoder_iter.onnx").write_bytes(good)
+    bad = dict(T)
+    bad["prenet.0.weight"] = np.full_like(T["prenet.0.weight"], np.nan)   # a NaN weight is refused, not loaded
+    onnx_writer.write_models(str(tmp_path), bad, "named")
+    with pytest.raises(pkg.XdttsError) as e:
+        pkg.read_model_dir(str(tmp_path))
+    assert e.value.status == pkg.XDTTS_ERR_IO and "non-finite" in str(e.value)

@@ -57,6 +57,7 @@ _PF = C.POINTER(C.c_float)
 SYMBOLS = {
     "xdtts_infer_opts_default": (None, [C.POINTER(InferOpts)]),
     "xdtts_tacotron2_load": (_I32, [C.c_char_p, _I32, C.POINTER(_VP)]),
+    "xdtts_model_dir_read": (_I32, [C.c_char_p, _VP, _SZ]),
     "xdtts_tacotron2_load_synthetic": (_I32, [_U32, _F, _I32, C.POINTER(_VP)]),
     "xdtts_tacotron2_load_blob": (_I32, [_VP, _SZ, _I32, C.POINTER(_VP)]),
     "xdtts_tacotron2_save": (_I32, [_VP, C.c_char_p]),
@@ -145,6 +146,15 @@ def tensor_table():
         shape = tuple(lib.xdtts_tensor_dim(i, d) for d in range(lib.xdtts_tensor_ndim(i)))
         out.append((lib.xdtts_tensor_name(i).decode(), shape, lib.xdtts_tensor_offset(i)))
     return out
+
+
+def read_model_dir(path):
+    """The host half of Tacotron2::load(path): the reference's model directory (encoder.onnx,
+    decoder_iter.onnx, postnet.onnx -- src/tacotron2/mod.rs:246-259) or a tacotron2.xdtw container as a
+    dict name -> array of the canonical tensors.  Needs no device."""
+    blob = np.empty(lib.xdtts_tensor_total(), dtype=np.float32)
+    _check(lib.xdtts_model_dir_read(os.fsencode(path), _ptr(blob), blob.size))
+    return {n: blob[off : off + int(np.prod(shape))].reshape(shape) for n, shape, off in tensor_table()}
 
 
 def _take(ptr, n, shape):

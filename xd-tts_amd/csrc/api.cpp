@@ -1032,10 +1032,20 @@ xdtts_status xdtts_tacotron2_load(const char *dir, int32_t device_id, xdtts_taco
   xdtts_status st = guard([&] {
     if (!dir) fail(XDTTS_ERR_BAD_ARG, "dir is null");
     select_device(device_id);
-    load_container(dir, blob);
+    load_model_dir(dir, blob);
   });
   if (st != XDTTS_OK) return st;
   return make_handle(std::move(blob), device_id, out);
+}
+
+xdtts_status xdtts_model_dir_read(const char *dir, float *blob, size_t n_floats) {
+  return guard([&] {
+    if (!dir || !blob) fail(XDTTS_ERR_BAD_ARG, "null argument");
+    if (n_floats != tensor_total()) fail(XDTTS_ERR_BAD_ARG, "blob has %zu floats, expected %zu", n_floats, tensor_total());
+    std::vector<float> v;
+    load_model_dir(dir, v);
+    std::memcpy(blob, v.data(), v.size() * sizeof(float));
+  });
 }
 
 xdtts_status xdtts_tacotron2_load_synthetic(uint32_t seed, float rec_scale, int32_t device_id,

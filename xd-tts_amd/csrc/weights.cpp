@@ -199,6 +199,13 @@ void save_container(const std::string &dir, const std::vector<float> &blob) {
   if (!f) fail(XDTTS_ERR_IO, "short write to %s/tacotron2.xdtw", dir.c_str());
 }
 
+void load_model_dir(const std::string &dir, std::vector<float> &blob) {
+  if (std::ifstream(dir + "/tacotron2.xdtw", std::ios::binary)) return load_container(dir, blob);
+  if (onnx_model_dir(dir)) return load_onnx_dir(dir, blob);
+  fail(XDTTS_ERR_IO, "loading tacotron2 weights: %s holds neither tacotron2.xdtw nor encoder.onnx / decoder_iter.onnx / postnet.onnx "
+                     "(the reference's model directory, src/tacotron2/mod.rs:246-259)", dir.c_str());
+}
+
 void load_container(const std::string &dir, std::vector<float> &blob) {
   const std::string path = dir + "/tacotron2.xdtw";
   std::ifstream f(path, std::ios::binary);

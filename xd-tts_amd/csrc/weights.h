@@ -22,6 +22,11 @@ int tensor_index(const char *name);
 // Canonical host blob (flat fp32, tensor_table() order).
 void synthetic_blob(uint32_t seed, float rec_scale, std::vector<float> &blob);
 void load_container(const std::string &dir, std::vector<float> &blob);
+// onnx_load.cpp: the reference's own model directory (encoder.onnx, decoder_iter.onnx, postnet.onnx)
+bool onnx_model_dir(const std::string &dir);
+void load_onnx_dir(const std::string &dir, std::vector<float> &blob);
+// Tacotron2::load(dir): `dir`/tacotron2.xdtw if present, else the three ONNX graphs
+void load_model_dir(const std::string &dir, std::vector<float> &blob);
 void save_container(const std::string &dir, const std::vector<float> &blob);
 
 // One conv1d(+BN eval) layer lowered to an NT GEMM operand: W[co][k*ci] with BN folded in.
