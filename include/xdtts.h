@@ -151,6 +151,26 @@ xdtts_status xdtts_griffinlim_new(const float *mel_basis, size_t n_mels, size_t 
                                   size_t noverlap, float power, size_t iters, float momentum,
                                   int32_t device_id, xdtts_griffinlim **out);
 
+/* The conventions of GriffinLim::infer's first step that the absent `griffin-lim` crate
+ * (Cargo.lock:666-668) leaves open, as switches.  Defaults = the librosa-0.9 reading documented in
+ * DESIGN.md section 2 (what every parity test and bench number uses):
+ *   nnls_iters      0: S = clip(pinv(basis) . m, 0), the least-squares start of the crate's bounded NNLS
+ *                   (lbfgsb 0.1.0, Cargo.lock:888-895); K > 0: K projected-gradient steps of
+ *                   min 1/2 |basis x - m|^2, x >= 0 on the device after that start (fixed step
+ *                   1/lambda_max(basis basis^T); the iteration's limit is the NNLS solution)
+ *   power_mode      0: S = x^(1/power) (librosa mel_to_stft)   1: S = x^power   2: S = x
+ *   mel_decompress  0: m = exp(mel) (Tacotron2's ln compression)   1: m = mel   2: m = 10^mel
+ *   peak_normalise  0: audio as is (src/lib.rs:155 scales by i16::MAX directly)   1: audio / max|audio| */
+typedef struct {
+  int32_t nnls_iters;
+  int32_t power_mode;
+  int32_t mel_decompress;
+  int32_t peak_normalise;
+} xdtts_griffinlim_opts;
+void xdtts_griffinlim_opts_default(xdtts_griffinlim_opts *opts);
+xdtts_status xdtts_griffinlim_set_opts(xdtts_griffinlim *g, const xdtts_griffinlim_opts *opts);
+xdtts_status xdtts_griffinlim_get_opts(const xdtts_griffinlim *g, xdtts_griffinlim_opts *opts);
+
 /* The random initial phase of the crate is un-seeded; here it is a counter-based stream. */
 xdtts_status xdtts_griffinlim_set_seed(xdtts_griffinlim *g, uint32_t seed);
 

@@ -86,6 +86,9 @@ class Oracle:
         L.orc_mel_filter_bank.argtypes = [C.c_double, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p]
         L.orc_mel_to_linear.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, self.ct, C.c_void_p]
         L.orc_griffinlim.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, self.ct, C.c_void_p]
+        L.orc_nnls_lipschitz.restype = C.c_double
+        L.orc_nnls_lipschitz.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orc_mel_to_linear_opts.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, self.ct, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.orc_griffinlim_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, self.ct]
         L.orc_dropout_keep.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int]
 
@@ -195,6 +198,19 @@ class Oracle:
         S = np.empty((pinv.shape[0], mel.shape[1]), dtype=self.dtype)
         self.lib.orc_mel_to_linear(self._p(pinv), mel.shape[0], pinv.shape[0], self._p(mel), mel.shape[1], power, self._p(S))
         return S
+
+    def mel_to_linear_opts(self, pinv, basis, mel, power=1.7, nnls_iters=0, power_mode=0, decompress=0):
+        """Step 1 of GriffinLim::infer with the switches of xdtts_griffinlim_opts."""
+        mel = self._arr(mel)
+        pinv = np.ascontiguousarray(pinv, dtype=np.float32)
+        basis = np.ascontiguousarray(basis, dtype=np.float32)
+        S = np.empty((pinv.shape[0], mel.shape[1]), dtype=self.dtype)
+        self.lib.orc_mel_to_linear_opts(self._p(pinv), self._p(basis), mel.shape[0], pinv.shape[0], self._p(mel), mel.shape[1], power, nnls_iters, power_mode, decompress, self._p(S))
+        return S
+
+    def nnls_lipschitz(self, basis):
+        basis = np.ascontiguousarray(basis, dtype=np.float32)
+        return float(self.lib.orc_nnls_lipschitz(self._p(basis), basis.shape[0], basis.shape[1]))
 
     def phase_init(self, seed, n_bins, F):
         out = np.empty((n_bins, F, 2), dtype=self.dtype)

@@ -624,6 +624,83 @@ void orc_mel_to_linear(const float *pinv, int n_mels, int n_bins, const real *me
   }
 }
 
+/* The general form of step 1 behind the options of xdtts_griffinlim_opts (the crate's conventions
+ * are not in the checkout, so each is a switch; the defaults reproduce orc_mel_to_linear):
+ *   decompress   0: m = exp(mel) (Tacotron2's natural-log compression)   1: m = mel   2: m = 10^mel
+ *   NNLS         x0 = max(pinv m, 0); then nnls_iters projected-gradient steps of
+ *                min 1/2 |A x - m|^2, x >= 0:   x <- max(x - (1/L) A^T (A x - m), 0),  L = lambda_max(A A^T)
+ *                (the fixed point of the iteration is the bounded least-squares solution the crate's
+ *                L-BFGS-B refinement seeks; 0 steps = the clipped least-squares start)
+ *   power_mode   0: S = x^(1/power) (librosa mel_to_stft)   1: S = x^power   2: S = x               */
+double orc_nnls_lipschitz(const float *basis, int n_mels, int n_bins) {
+  /* largest eigenvalue of A A^T by power iteration in double */
+  double *G = (double *)calloc((size_t)n_mels * n_mels, sizeof(double));
+  double *v = (double *)malloc(sizeof(double) * n_mels), *w = (double *)malloc(sizeof(double) * n_mels);
+  for (int i = 0; i < n_mels; ++i)
+    for (int j = 0; j <= i; ++j) {
+      double a = 0;
+      for (int b = 0; b < n_bins; ++b) a += (double)basis[(size_t)i * n_bins + b] * basis[(size_t)j * n_bins + b];
+      G[(size_t)i * n_mels + j] = G[(size_t)j * n_mels + i] = a;
+    }
+  for (int i = 0; i < n_mels; ++i) v[i] = 1.0 / sqrt((double)n_mels);
+  double lam = 0;
+  for (int it = 0; it < 1000; ++it) {
+    double nrm = 0;
+    for (int i = 0; i < n_mels; ++i) {
+      double a = 0;
+      for (int j = 0; j < n_mels; ++j) a += G[(size_t)i * n_mels + j] * v[j];
+      w[i] = a;
+      nrm += a * a;
+    }
+    nrm = sqrt(nrm);
+    for (int i = 0; i < n_mels; ++i) v[i] = w[i] / nrm;
+    if (fabs(nrm - lam) <= 1e-13 * nrm) {
+      lam = nrm;
+      break;
+    }
+    lam = nrm;
+  }
+  free(G);
+  free(v);
+  free(w);
+  return lam;
+}
+
+void orc_mel_to_linear_opts(const float *pinv, const float *basis, int n_mels, int n_bins, const real *mel, int F,
+                            real power, int nnls_iters, int power_mode, int decompress, real *S) {
+  const real step = (real)(1.0 / orc_nnls_lipschitz(basis, n_mels, n_bins));
+  const double ex = power_mode == 0 ? 1.0 / (double)power : (power_mode == 1 ? (double)power : 1.0);
+#pragma omp parallel for schedule(static)
+  for (int t = 0; t < F; ++t) {
+    real m[512], r[512];
+    real *x = (real *)malloc(sizeof(real) * n_bins);
+    for (int k = 0; k < n_mels; ++k) {
+      const real v = mel[(size_t)k * F + t];
+      m[k] = decompress == 0 ? (real)exp((double)v) : (decompress == 2 ? (real)pow(10.0, (double)v) : v);
+    }
+    for (int b = 0; b < n_bins; ++b) {
+      real v = 0;
+      for (int k = 0; k < n_mels; ++k) v += (real)pinv[(size_t)b * n_mels + k] * m[k];
+      x[b] = v > 0 ? v : 0;
+    }
+    for (int it = 0; it < nnls_iters; ++it) {
+      for (int k = 0; k < n_mels; ++k) {
+        real a = 0;
+        for (int b = 0; b < n_bins; ++b) a += (real)basis[(size_t)k * n_bins + b] * x[b];
+        r[k] = a - m[k];
+      }
+      for (int b = 0; b < n_bins; ++b) {
+        real g = 0;
+        for (int k = 0; k < n_mels; ++k) g += r[k] * (real)basis[(size_t)k * n_bins + b];
+        const real v = x[b] - step * g;
+        x[b] = v > 0 ? v : 0;
+      }
+    }
+    for (int b = 0; b < n_bins; ++b) S[(size_t)b * F + t] = power_mode == 2 ? x[b] : (real)pow((double)x[b], ex);
+    free(x);
+  }
+}
+
 void orc_phase_init(uint32_t seed, int n_bins, int F, real *phase0) {
   for (int b = 0; b < n_bins; ++b)
     for (int t = 0; t < F; ++t) {

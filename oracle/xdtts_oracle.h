@@ -126,6 +126,11 @@ int orc_pinv(const float *basis, int n_mels, int n_bins, float *out);
 /* S[n_bins][F] = max(pinv @ exp(mel), 0)^(1/power) */
 void orc_mel_to_linear(const float *pinv, int n_mels, int n_bins, const real *mel, int F,
                        real power, real *S);
+/* Step 1 with the convention switches of xdtts_griffinlim_opts (see the .c file); the defaults
+ * (nnls_iters 0, power_mode 0, decompress 0) give orc_mel_to_linear. */
+double orc_nnls_lipschitz(const float *basis, int n_mels, int n_bins);
+void orc_mel_to_linear_opts(const float *pinv, const float *basis, int n_mels, int n_bins, const real *mel, int F,
+                            real power, int nnls_iters, int power_mode, int decompress, real *S);
 /* phase0[bin][frame][2] = (cos, sin)(2*pi*u), u = rng(seed, 0x47, frame*n_bins+bin) */
 void orc_phase_init(uint32_t seed, int n_bins, int F, real *phase0);
 void orc_stft(const real *y, int n, int n_fft, int hop, real *out /* bins x F x 2 */, int F);

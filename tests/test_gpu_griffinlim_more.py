@@ -117,3 +117,47 @@ def test_config5_full_size_properties(voc, orc):
     assert np.array_equal(voc.infer_linear(S, iters=30), out[30])  # deterministic
     scaled = voc.infer_linear(2.0 * S, iters=30)
     assert rms(scaled, 2.0 * out[30]) <= 1e-5 * max(1.0, float(np.abs(out[30]).max()))
+
+
+def test_mel_to_linear_options_match_the_oracle(pkg, orc):
+    """xdtts_griffinlim_opts: each convention switch of GriffinLim::infer's first step, and the NNLS
+    refinement (projected gradient, two MFMA GEMMs per step), against the oracle's restatement."""
+    v = pkg.create_griffin_lim(iters=8, seed=2)
+    A = orc.mel_filter_bank()
+    P = orc.pinv(A)
+    rng = np.random.default_rng(4)
+    F = 70
+    mel = (rng.uniform(-7.0, -1.0, size=(80, F)) + 1.5 * np.sin(np.arange(F) / 4.0)[None, :]).astype(np.float32)
+    d = v.get_opts()
+    assert (d.nnls_iters, d.power_mode, d.mel_decompress, d.peak_normalise) == (0, 0, 0, 0)
+    base = v.mel_to_linear(mel)
+    scale = float(np.sqrt(np.mean(base.astype(np.float64) ** 2)))
+    for kw in (dict(), dict(power_mode=1), dict(power_mode=2), dict(mel_decompress=1), dict(mel_decompress=2),
+               dict(nnls_iters=1), dict(nnls_iters=7, power_mode=2), dict(nnls_iters=60)):
+        full = dict(nnls_iters=0, power_mode=0, mel_decompress=0, peak_normalise=0)
+        full.update(kw)
+        v.set_opts(**full)
+        S = v.mel_to_linear(mel)
+        ref = orc.mel_to_linear_opts(P, A, mel, power=1.7, nnls_iters=full["nnls_iters"], power_mode=full["power_mode"], decompress=full["mel_decompress"])
+        sc = float(np.sqrt(np.mean(ref.astype(np.float64) ** 2)))
+        assert np.all(np.isfinite(S)) and rms(S, ref) <= 2e-5 * sc, (kw, rms(S, ref), sc)
+    # the refinement really lowers the mel-domain residual
+    v.set_opts(nnls_iters=0, power_mode=2, mel_decompress=0)
+    x0 = v.mel_to_linear(mel)
+    v.set_opts(nnls_iters=40)
+    x1 = v.mel_to_linear(mel)
+    m = np.exp(mel.astype(np.float64))
+    r0, r1 = np.linalg.norm(A.astype(np.float64) @ x0 - m), np.linalg.norm(A.astype(np.float64) @ x1 - m)
+    assert r1 < 0.8 * r0 and x1.min() >= 0
+    # defaults restored -> the documented reading again; peak normalisation scales the same audio to |y| <= 1
+    v.set_opts(nnls_iters=0, power_mode=0, mel_decompress=0, peak_normalise=0)
+    assert np.array_equal(v.mel_to_linear(mel), base) and scale > 0
+    a0 = v.infer(mel)
+    v.set_opts(peak_normalise=1)
+    a1 = v.infer(mel)
+    peak = float(np.abs(a0).max())
+    assert abs(float(np.abs(a1).max()) - 1.0) <= 1e-6 and rms(a1, a0 / peak) <= 1e-6
+    with pytest.raises(pkg.XdttsError) as e:
+        v.set_opts(power_mode=7)
+    assert e.value.status == pkg.XDTTS_ERR_BAD_ARG
+    v.close()

@@ -106,3 +106,47 @@ def test_griffinlim_scale_equivariance(orc64):
     a = orc64.griffinlim(S, seed=1, iters=5)
     b = orc64.griffinlim(3.0 * S, seed=1, iters=5)
     assert np.abs(b - 3.0 * a).max() < 1e-10 * max(1.0, np.abs(a).max())
+
+
+def test_nnls_refinement_descends_to_the_scipy_solution(orc64):
+    """mel -> linear as bounded least squares.  The projected-gradient steps behind
+    xdtts_griffinlim_opts.nnls_iters (restated in the oracle) must lower 1/2 |A x - m|^2 monotonically from the
+    clipped least-squares start and approach scipy's exact NNLS optimum (the fixed point the crate's L-BFGS-B
+    refinement -- lbfgsb 0.1.0, Cargo.lock:888-895 -- looks for)."""
+    from scipy.optimize import nnls
+
+    A = orc64.mel_filter_bank()
+    P = orc64.pinv(A)
+    A64 = A.astype(np.float64)
+    L = orc64.nnls_lipschitz(A)
+    assert abs(L - np.linalg.eigvalsh(A64 @ A64.T).max()) <= 1e-9 * L
+    rng = np.random.default_rng(0)
+    mel = rng.uniform(-7, -1, size=(80, 5)).astype(np.float32)
+    m = np.exp(mel.astype(np.float64))
+    best = np.array([0.5 * nnls(A64, m[:, t])[1] ** 2 for t in range(5)])
+    prev = first = None
+    for it in (0, 1, 10, 100, 2000):
+        X = orc64.mel_to_linear_opts(P, A, mel, nnls_iters=it, power_mode=2)
+        assert X.min() >= 0
+        obj = np.array([0.5 * np.sum((A64 @ X[:, t] - m[:, t]) ** 2) for t in range(5)])
+        assert np.all(obj >= best * (1 - 1e-9))
+        if prev is not None:
+            assert np.all(obj <= prev * (1 + 1e-12))
+        prev = obj
+        first = obj if first is None else first
+    assert np.all((first - prev) >= 0.95 * (first - best))   # 2000 steps close >= 95 % of the gap to the optimum
+
+
+def test_mel_to_linear_switches(orc64):
+    A = orc64.mel_filter_bank()
+    P = orc64.pinv(A)
+    rng = np.random.default_rng(1)
+    mel = rng.uniform(-5, -1, size=(80, 3)).astype(np.float32)
+    base = orc64.mel_to_linear(P, mel, power=1.7)
+    assert np.array_equal(orc64.mel_to_linear_opts(P, A, mel, power=1.7), base)            # defaults = the documented reading
+    x = orc64.mel_to_linear_opts(P, A, mel, power=1.7, power_mode=2)
+    assert np.allclose(base, x ** (1 / 1.7), rtol=1e-12) and np.allclose(orc64.mel_to_linear_opts(P, A, mel, power=1.7, power_mode=1), x ** 1.7, rtol=1e-12)
+    lin = np.exp(mel.astype(np.float64)).astype(np.float32)                                  # already-linear input, decompress = none
+    assert np.allclose(orc64.mel_to_linear_opts(P, A, lin, power_mode=2, decompress=1), x, rtol=1e-5, atol=1e-9)
+    log10 = (mel.astype(np.float64) / np.log(10)).astype(np.float32)                         # 10^x de-compression of the same magnitudes
+    assert np.allclose(orc64.mel_to_linear_opts(P, A, log10, power_mode=2, decompress=2), x, rtol=1e-4, atol=1e-8)

@@ -37,6 +37,12 @@ class XdttsError(RuntimeError):
         self.status = status
 
 
+class GriffinLimOpts(C.Structure):
+    """xdtts_griffinlim_opts: the conventions of GriffinLim::infer's mel->linear step as switches."""
+
+    _fields_ = [("nnls_iters", C.c_int32), ("power_mode", C.c_int32), ("mel_decompress", C.c_int32), ("peak_normalise", C.c_int32)]
+
+
 class InferOpts(C.Structure):
     _fields_ = [
         ("gate_threshold", C.c_float),
@@ -78,6 +84,9 @@ SYMBOLS = {
     "xdtts_tacotron2_sync": (_I32, [_VP]),
     "xdtts_mel_filter_bank": (_I32, [_F, _SZ, _SZ, _F, _F, _VP]),
     "xdtts_griffinlim_new": (_I32, [_VP, _SZ, _SZ, _SZ, _F, _SZ, _F, _I32, C.POINTER(_VP)]),
+    "xdtts_griffinlim_opts_default": (None, [_VP]),
+    "xdtts_griffinlim_set_opts": (_I32, [_VP, _VP]),
+    "xdtts_griffinlim_get_opts": (_I32, [_VP, _VP]),
     "xdtts_griffinlim_set_seed": (_I32, [_VP, _U32]),
     "xdtts_griffinlim_infer": (_I32, [_VP, _VP, _SZ, _SZ, C.POINTER(_PF), C.POINTER(_SZ)]),
     "xdtts_griffinlim_infer_linear": (_I32, [_VP, _VP, _VP, _SZ, _SZ, C.POINTER(_PF), C.POINTER(_SZ)]),
@@ -365,6 +374,19 @@ class GriffinLim:
 
     def set_seed(self, seed):
         _check(lib.xdtts_griffinlim_set_seed(self._h, seed))
+
+    def set_opts(self, **kw):
+        """nnls_iters, power_mode (0 inverse / 1 direct / 2 none), mel_decompress (0 exp / 1 none / 2 10^x),
+        peak_normalise; unspecified fields keep their current value."""
+        o = self.get_opts()
+        for k, v in kw.items():
+            setattr(o, k, v)
+        _check(lib.xdtts_griffinlim_set_opts(self._h, C.byref(o)))
+
+    def get_opts(self):
+        o = GriffinLimOpts()
+        _check(lib.xdtts_griffinlim_get_opts(self._h, C.byref(o)))
+        return o
 
     def close(self):
         if self._h:

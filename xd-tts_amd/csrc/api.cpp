@@ -718,6 +718,11 @@ struct xdtts_griffinlim {
   Events ev;
   float last_ms[3] = {0, 0, 0};
   DevBuf<float> pinv, win, S, melT, mel_in, frames, wss_inv, audio, phase0;
+  // mel->linear options (xdtts_griffinlim_opts) and the NNLS refinement's operands
+  xdtts_griffinlim_opts gopts{0, 0, 0, 0};
+  static constexpr int NBP = 528;  // bins padded to the GEMM's K granule
+  DevBuf<float> basis_p, basisT_p, nnls_x, nnls_r, peak;
+  float nnls_step = 0.f;   // 1 / lambda_max(A A^T)
   hipGraphExec_t graph = nullptr;  // n_iter x (istft, stft) + final ISTFT for the cached (buffers, F, iterations)
   GlBufs graph_key{};
   int graph_iters = -1;
@@ -765,23 +770,70 @@ struct xdtts_griffinlim {
     return g;
   }
 
-  // step 1 of GriffinLim::infer: mel (device, n_mels x F, ln-compressed) -> S [F][nb]
+  // step 1 of GriffinLim::infer: mel (device, n_mels x F) -> S [F][nb], with the convention switches of
+  // xdtts_griffinlim_opts: de-compression, optional projected-gradient NNLS refinement, exponent.
+  //   x0 = max(pinv m, 0);  x <- max(x - (1/L) A^T (A x - m), 0)  nnls_iters times, batched over the
+  //   frames as two MFMA GEMMs per step (residual [F][80], then the update of X [F][NBP]).
   void mel_to_linear(const float *mel_dev_ptr, int F) {
     melT.alloc((size_t)F * n_mels);
-    launch_gl_exp_transpose(mel_dev_ptr, melT.p, n_mels, F, stream);
+    launch_gl_exp_transpose(mel_dev_ptr, melT.p, n_mels, F, gopts.mel_decompress, stream);
+    const float ex = gopts.power_mode == 0 ? 1.0f / power : (gopts.power_mode == 1 ? power : 1.0f);
     GemmArgs a{};
     a.A = melT.p;
     a.lda = n_mels;
     a.W = pinv.p;
-    a.C = S.p;
-    a.ldc = nb;
     a.M = F;
     a.N = nb;
     a.K = n_mels;
     a.batch = 1;
-    a.act = 3;
-    a.p = 1.0f / power;
+    if (gopts.nnls_iters <= 0) {
+      a.C = S.p;
+      a.ldc = nb;
+      a.act = ex == 1.0f ? 1 : 3;
+      a.p = ex;
+      launch_gemm_nt(a, stream);
+      return;
+    }
+    nnls_x.alloc((size_t)F * NBP);
+    nnls_r.alloc((size_t)F * n_mels);
+    HIP_CHECK(hipMemsetAsync(nnls_x.p, 0, (size_t)F * NBP * sizeof(float), stream));  // padding columns stay 0
+    a.C = nnls_x.p;
+    a.ldc = NBP;
+    a.act = 1;
     launch_gemm_nt(a, stream);
+    for (int it = 0; it < gopts.nnls_iters; ++it) {
+      GemmArgs r{};  // R = X A^T - m
+      r.A = nnls_x.p;
+      r.lda = NBP;
+      r.W = basis_p.p;  // [n_mels][NBP]
+      r.C = nnls_r.p;
+      r.ldc = n_mels;
+      r.M = F;
+      r.N = n_mels;
+      r.K = NBP;
+      r.batch = 1;
+      r.R = melT.p;
+      r.ldr = n_mels;
+      r.beta = -1.0f;
+      launch_gemm_nt(r, stream);
+      GemmArgs u{};  // X = max(X - (1/L) R A, 0)
+      u.A = nnls_r.p;
+      u.lda = n_mels;
+      u.W = basisT_p.p;  // [NBP][n_mels]
+      u.C = nnls_x.p;
+      u.ldc = NBP;
+      u.M = F;
+      u.N = NBP;
+      u.K = n_mels;
+      u.batch = 1;
+      u.alpha = -nnls_step;
+      u.R = nnls_x.p;
+      u.ldr = NBP;
+      u.r_before_act = 1;
+      u.act = 1;
+      launch_gemm_nt(u, stream);
+    }
+    launch_gl_pow_rows(nnls_x.p, NBP, S.p, nb, F, ex, stream);
   }
 
   bool persistent_usable() {
@@ -974,6 +1026,34 @@ static void host_pinv(const float *basis, int n, int nbins, std::vector<float> &
     }
     for (int i = 0; i < n; ++i) out[(size_t)b * n + i] = (float)z[i];
   }
+}
+
+// lambda_max(A A^T) by power iteration (double): the Lipschitz constant of the NNLS gradient
+static double host_lipschitz(const float *basis, int n, int nbins) {
+  std::vector<double> G((size_t)n * n, 0.0), v(n, 1.0 / std::sqrt((double)n)), w(n);
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j <= i; ++j) {
+      double s = 0;
+      for (int b = 0; b < nbins; ++b) s += (double)basis[(size_t)i * nbins + b] * basis[(size_t)j * nbins + b];
+      G[(size_t)i * n + j] = G[(size_t)j * n + i] = s;
+    }
+  double lam = 0;
+  for (int it = 0; it < 1000; ++it) {
+    double nrm = 0;
+    for (int i = 0; i < n; ++i) {
+      double a = 0;
+      for (int j = 0; j < n; ++j) a += G[(size_t)i * n + j] * v[j];
+      w[i] = a;
+      nrm += a * a;
+    }
+    nrm = std::sqrt(nrm);
+    if (!(nrm > 0)) fail(XDTTS_ERR_BAD_ARG, "mel basis is all zero");
+    for (int i = 0; i < n; ++i) v[i] = w[i] / nrm;
+    const bool done = std::fabs(nrm - lam) <= 1e-13 * nrm;
+    lam = nrm;
+    if (done) break;
+  }
+  return lam;
 }
 
 // ================================================================================================
@@ -1294,6 +1374,16 @@ xdtts_status xdtts_griffinlim_new(const float *mel_basis, size_t n_mels, size_t 
     std::vector<float> pinv;
     host_pinv(mel_basis, (int)n_mels, (int)n_bins, pinv);
     g->pinv.upload(pinv.data(), pinv.size(), g->stream);
+    {  // NNLS refinement operands: the basis and its transpose, bins zero-padded to NBP, and the step 1/L
+      const int NBP = xdtts_griffinlim::NBP, nm = (int)n_mels, nbi = (int)n_bins;
+      std::vector<float> bp((size_t)nm * NBP, 0.f), bt((size_t)NBP * nm, 0.f);
+      for (int i = 0; i < nm; ++i)
+        for (int b = 0; b < nbi; ++b) bp[(size_t)i * NBP + b] = bt[(size_t)b * nm + i] = mel_basis[(size_t)i * nbi + b];
+      g->basis_p.upload(bp.data(), bp.size(), g->stream);
+      g->basisT_p.upload(bt.data(), bt.size(), g->stream);
+      g->nnls_step = (float)(1.0 / host_lipschitz(mel_basis, nm, nbi));
+      g->peak.alloc(1);
+    }
     std::vector<float2> tw(n_fft);
     std::vector<float> win(n_fft);
     const double PI = 3.14159265358979323846;
@@ -1305,6 +1395,32 @@ xdtts_status xdtts_griffinlim_new(const float *mel_basis, size_t n_mels, size_t 
     g->win.upload(win.data(), win.size(), g->stream);
     HIP_CHECK(hipStreamSynchronize(g->stream));
     *out = g.release();
+  });
+}
+
+void xdtts_griffinlim_opts_default(xdtts_griffinlim_opts *o) {
+  if (!o) return;
+  o->nnls_iters = 0;
+  o->power_mode = 0;
+  o->mel_decompress = 0;
+  o->peak_normalise = 0;
+}
+
+xdtts_status xdtts_griffinlim_set_opts(xdtts_griffinlim *g, const xdtts_griffinlim_opts *o) {
+  return guard([&] {
+    if (!g || !o) fail(XDTTS_ERR_BAD_ARG, "null argument");
+    if (o->nnls_iters < 0 || o->nnls_iters > 100000 || o->power_mode < 0 || o->power_mode > 2 || o->mel_decompress < 0 ||
+        o->mel_decompress > 2 || o->peak_normalise < 0 || o->peak_normalise > 1)
+      fail(XDTTS_ERR_BAD_ARG, "griffin-lim option out of range");
+    std::lock_guard<std::mutex> lk(g->mu);
+    g->gopts = *o;
+  });
+}
+
+xdtts_status xdtts_griffinlim_get_opts(const xdtts_griffinlim *g, xdtts_griffinlim_opts *o) {
+  return guard([&] {
+    if (!g || !o) fail(XDTTS_ERR_BAD_ARG, "null argument");
+    *o = g->gopts;
   });
 }
 
@@ -1325,6 +1441,7 @@ static void gl_iterate_and_fetch(xdtts_griffinlim *g, const GlBufs &b, const flo
   std::lock_guard<std::recursive_mutex> chip(chip_mutex(g->device));
   for (int attempt = 0; attempt < 2; ++attempt) {
     g->iterate(b, phase0_dev, iters);
+    if (g->gopts.peak_normalise) launch_gl_peak_normalise(g->audio.p, (int)N, g->peak.p, g->stream);
     HIP_CHECK(hipEventRecord(g->ev.e[2], g->stream));
     PinnedGuard host(N);
     HIP_CHECK(hipMemcpyAsync(host.p, g->audio.p, N * sizeof(float), hipMemcpyDeviceToHost, g->stream));

@@ -108,11 +108,13 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs g) {
     for (int r = 0; r < 4; ++r) {
       const int m = m0 + wm * 16 + fg * 4 + r;
       if (m >= M) continue;
-      float v = acc[r] + bz;
+      float v = (g.alpha != 0.f ? g.alpha * acc[r] : acc[r]) + bz;
+      const float rv = R ? (g.beta != 0.f ? g.beta : 1.f) * R[(size_t)m * g.ldr + n] : 0.f;
+      if (g.r_before_act) v += rv;
       if (g.act == 1) v = fmaxf(v, 0.f);
       else if (g.act == 2) v = tanhf(v);
       else if (g.act == 3) v = powf(fmaxf(v, 0.f), g.p);
-      if (R) v += R[(size_t)m * g.ldr + n];
+      if (!g.r_before_act) v += rv;
       if (g.transpose_out) C[(size_t)n * g.ldc + m] = v;
       else C[(size_t)m * g.ldc + n] = v;
     }

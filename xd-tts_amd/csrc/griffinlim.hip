@@ -13,6 +13,7 @@
 // iteration touches S, angles and the previous rebuilt spectrum exactly once each.  An iteration is
 // ONE launch (k_gl_fused): the windowed ISTFT frames of a tile (+ halo) live in LDS and the
 // overlap-add is folded into the STFT's gather.
+#include <algorithm>
 #include <utility>
 
 #include "kernels.h"
@@ -813,12 +814,36 @@ __global__ void k_phase_init(GlBufs g, uint32_t seed, const float *phase0) {
   g.tprev[i] = make_float2(0.f, 0.f);
 }
 
-// exp-decompress the natural-log mel and transpose (80 x F) -> (F x 80) for the pinv GEMM
-__global__ void k_exp_transpose(const float *mel, float *out, int n_mels, int F) {
+// de-compress the mel (mode 0: exp of the natural-log mel Tacotron2 emits; 1: none; 2: 10^x) and
+// transpose (80 x F) -> (F x 80) for the pinv GEMM
+__global__ void k_exp_transpose(const float *mel, float *out, int n_mels, int F, int mode) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_mels * F) return;
   const int f = i / n_mels, m = i % n_mels;
-  out[i] = expf(mel[(size_t)m * F + f]);
+  const float v = mel[(size_t)m * F + f];
+  out[i] = mode == 0 ? expf(v) : (mode == 2 ? exp10f(v) : v);
+}
+
+__global__ void k_pow_rows(const float *in, int ld, float *out, int nb, int F, float p) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nb * F) return;
+  const int f = i / nb, k = i % nb;
+  const float v = in[(size_t)f * ld + k];
+  out[i] = p == 1.0f ? v : powf(fmaxf(v, 0.f), p);
+}
+
+// peak normalisation: max |y| through an atomic max on the float's bit pattern (non-negative floats
+// order like unsigned integers), then a scale pass
+__global__ void k_absmax(const float *y, int n, unsigned *out) {
+  float m = 0.f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) m = fmaxf(m, fabsf(y[i]));
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m == m) atomicMax(out, __float_as_uint(m));
+}
+__global__ void k_scale_by_peak(float *y, int n, const unsigned *peak) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const float p = __uint_as_float(*peak);
+  if (i < n && p > 0.f) y[i] = y[i] / p;
 }
 
 // Parity hook (xdtts_griffinlim_step): the iteration state crosses the boundary in the crate's
@@ -845,9 +870,22 @@ __global__ void k_state_export(GlBufs g, const float2 *ang, const float2 *tprev,
 
 }  // namespace
 
-void launch_gl_exp_transpose(const float *mel_80xF, float *out_Fx80, int n_mels, int F, hipStream_t s) {
+void launch_gl_exp_transpose(const float *mel_80xF, float *out_Fx80, int n_mels, int F, int mode, hipStream_t s) {
   const int n = n_mels * F;
-  hipLaunchKernelGGL(k_exp_transpose, dim3((n + 255) / 256), dim3(256), 0, s, mel_80xF, out_Fx80, n_mels, F);
+  hipLaunchKernelGGL(k_exp_transpose, dim3((n + 255) / 256), dim3(256), 0, s, mel_80xF, out_Fx80, n_mels, F, mode);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_gl_pow_rows(const float *in, int ld, float *out, int nb, int F, float p, hipStream_t s) {
+  const int n = nb * F;
+  hipLaunchKernelGGL(k_pow_rows, dim3((n + 255) / 256), dim3(256), 0, s, in, ld, out, nb, F, p);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_gl_peak_normalise(float *y, int n, float *scratch, hipStream_t s) {
+  HIP_CHECK(hipMemsetAsync(scratch, 0, sizeof(float), s));
+  hipLaunchKernelGGL(k_absmax, dim3(std::min(256, (n + 255) / 256)), dim3(256), 0, s, y, n, reinterpret_cast<unsigned *>(scratch));
+  hipLaunchKernelGGL(k_scale_by_peak, dim3((n + 255) / 256), dim3(256), 0, s, y, n, reinterpret_cast<const unsigned *>(scratch));
   HIP_CHECK(hipGetLastError());
 }
 

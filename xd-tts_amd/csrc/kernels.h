@@ -95,6 +95,10 @@ struct GemmArgs {
   int act;            // 0 none, 1 relu, 2 tanh, 3 pow(max(x,0), p)
   int transpose_out;  // store C[n*ldc + m]
   float p;
+  // v = alpha * (A W^T) + bias; R is added scaled by beta, before the activation when r_before_act
+  // (0 in alpha / beta means 1: zero-initialised args keep the plain form)
+  float alpha, beta;
+  int r_before_act;
 };
 constexpr int GEMM_RAGGED_MAX = 16;
 void launch_gemm_nt(const GemmArgs &g, hipStream_t s);
@@ -141,7 +145,12 @@ size_t gl_persistent_xch_words(int nblk);
 bool gl_persistent_supported(int device, int *n_cu);
 void launch_gl_persistent(const GlBufs &g, const GlPersist &p, const float2 *ang_in, const float2 *tprev_in, int n_iter,
                           float alpha, float *audio, hipStream_t s);
-void launch_gl_exp_transpose(const float *mel_80xF, float *out_Fx80, int n_mels, int F, hipStream_t s);
+// mode 0: exp (natural-log mel), 1: copy (already linear), 2: 10^x
+void launch_gl_exp_transpose(const float *mel_80xF, float *out_Fx80, int n_mels, int F, int mode, hipStream_t s);
+// out[F][nb] = in[F][ld]^p (p == 1: copy): the exponent of mel->linear after the NNLS refinement
+void launch_gl_pow_rows(const float *in, int ld, float *out, int nb, int F, float p, hipStream_t s);
+// y *= 1 / max|y| (peak normalisation option); scratch = one float of device memory
+void launch_gl_peak_normalise(float *y, int n, float *scratch, hipStream_t s);
 void launch_gl_phase_init(const GlBufs &g, uint32_t seed, const float *phase0_dev, hipStream_t s);
 void launch_gl_prepare(const GlBufs &g, hipStream_t s);                  // wss_inv for this F
 void launch_gl_iterations(const GlBufs &g, int n_iter, float alpha, float *audio, hipStream_t s);  // + final ISTFT
