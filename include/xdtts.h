@@ -127,6 +127,27 @@ xdtts_status xdtts_tacotron2_decoder(xdtts_tacotron2 *h, const float *memory,
                                      const float *processed_memory, int32_t T, int32_t n_valid,
                                      const xdtts_infer_opts *opts, float *frames, float *gates,
                                      size_t *n_frames);
+/* ONE call of decoder_iter.onnx (mod.rs:304), teacher-forced: the per-step parity hook of SURVEY.md
+ * section 8c(i).  Inputs as the reference feeds them (mod.rs:284-296): memory (T x 512), processed_memory
+ * (T x 128), the mask as n_valid (mod.rs:219-220), decoder_input (80) and the seven state tensors; the
+ * nine outputs (mod.rs:306-307,332-339): decoder_output (80), gate_prediction (1, the logit) and the
+ * seven out_* state tensors, written over the state arguments.  `step` is the frame index (it selects the
+ * prenet-dropout masks of the seeded stream; opts->item_base the chunk). */
+xdtts_status xdtts_tacotron2_decoder_step(xdtts_tacotron2 *h, const float *memory, const float *processed_memory,
+                                          int32_t T, int32_t n_valid, const xdtts_infer_opts *opts, uint32_t step,
+                                          const float *decoder_input, float *attention_hidden,
+                                          float *attention_cell, float *decoder_hidden, float *decoder_cell,
+                                          float *attention_weights, float *attention_weights_cum,
+                                          float *attention_context, float *decoder_output,
+                                          float *gate_prediction);
+
+/* Engine state of a handle: 1 = the persistent decoder / cooperative encoder is in use, 0 = the handle was
+ * demoted to the launch-per-stage / single-workgroup engine after a timed-out exchange (it probes the fast
+ * engine again by itself every 64 calls), -1 = not probed yet.  _reset puts a demoted handle back at once. */
+xdtts_status xdtts_tacotron2_engine_state(const xdtts_tacotron2 *h, int32_t *decoder_persistent,
+                                          int32_t *encoder_cooperative);
+xdtts_status xdtts_tacotron2_engine_reset(xdtts_tacotron2 *h);
+
 /* postnet.onnx (mod.rs:345-355): frames (F x 80) -> mel_outputs_postnet (80 x F). */
 xdtts_status xdtts_tacotron2_postnet(xdtts_tacotron2 *h, const float *frames, int32_t F,
                                      float *mel_out);

@@ -165,3 +165,50 @@ def test_lost_workgroup_drains_and_falls_back(pkg, orc, blob, capfd):
     frames2, _ = m.decoder(mem, pm, 21, pkg.default_opts(fixed_steps=30, dropout_seed=3))
     assert np.array_equal(frames2, frames)
     m.close()
+
+
+def test_teacher_forced_single_step_all_nine_outputs(pkg, model, orc, blob):
+    """ONE decoder_iter call (mod.rs:304) from an identical state -- the oracle's own, taken
+    at several points of a free-running sequence -- must reproduce all nine outputs (mod.rs:306-307,
+    332-339): decoder_output, gate_prediction and the seven out_* state tensors, to 1e-5."""
+    nv = 37
+    mem, pm = encode(orc, blob, nv)     # the encoder window: 100 rows, 37 of them un-padded (mask, mod.rs:219-220)
+    T = mem.shape[0]
+    o = orc.default_opts(dropout_seed=11, item=3)
+    go = pkg.default_opts(dropout_seed=11, item_base=3)
+    st = orc.new_state()
+    names = {"attention_hidden": "att_h", "attention_cell": "att_c", "decoder_hidden": "dec_h", "decoder_cell": "dec_c",
+             "attention_weights": "aw", "attention_weights_cum": "awc", "attention_context": "ctx"}
+    worst = 0.0
+    for step in range(12):
+        snap = {k: np.array(getattr(st, v), dtype=np.float32)[: (T if v in ("aw", "awc") else None)] for k, v in names.items()}
+        dec_in = np.array(st.dec_in, dtype=np.float32)
+        mel, gate = orc.decoder_step(blob, mem, pm, nv, st, o, step)       # advances the oracle's state
+        if step in (0, 1, 5, 11):
+            gmel, ggate, gst = model.decoder_step(mem, pm, nv, snap, dec_in, step, opts=go)
+            errs = [float(np.abs(gmel - mel).max()), abs(ggate - gate)]
+            for k, v in names.items():
+                ref = np.array(getattr(st, v), dtype=np.float32)[: (T if v in ("aw", "awc") else None)]
+                errs.append(float(np.abs(gst[k] - ref).max()))
+            worst = max(worst, max(errs))
+            assert max(errs) <= 1e-5, (step, errs)
+    assert worst > 0  # (the comparison really ran on different implementations)
+
+
+def test_engine_state_and_reset(pkg, orc, blob):
+    mem, pm = encode(orc, blob, 21)
+    m = pkg.Tacotron2.from_blob(blob)
+    assert m.engine_state()["decoder_persistent"] == -1
+    m.decoder(mem, pm, 21, pkg.default_opts(fixed_steps=6, dropout_seed=3))
+    assert m.engine_state() == {"decoder_persistent": 1, "encoder_cooperative": 1}
+    os.environ["XDTTS_PERSIST_FAULT"] = "201"
+    os.environ["XDTTS_PERSIST_SPINS"] = "20000"
+    try:
+        f0, _ = m.decoder(mem, pm, 21, pkg.default_opts(fixed_steps=6, dropout_seed=3))
+    finally:
+        del os.environ["XDTTS_PERSIST_FAULT"], os.environ["XDTTS_PERSIST_SPINS"]
+    assert m.engine_state()["decoder_persistent"] == 0            # demoted after the timed-out exchange
+    m.engine_reset()
+    f1, _ = m.decoder(mem, pm, 21, pkg.default_opts(fixed_steps=6, dropout_seed=3))
+    assert m.engine_state()["decoder_persistent"] == 1 and rms(f0, f1) <= 1e-6
+    m.close()

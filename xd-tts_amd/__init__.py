@@ -78,6 +78,9 @@ SYMBOLS = {
     "xdtts_tacotron2_infer_batch": (_I32, [_VP, _VP, _VP, _I32, _I32, C.POINTER(InferOpts), _VP, C.POINTER(_PF), C.POINTER(_SZ)]),
     "xdtts_tacotron2_encoder": (_I32, [_VP, _VP, _I32, _VP, _VP]),
     "xdtts_tacotron2_decoder": (_I32, [_VP, _VP, _VP, _I32, _I32, C.POINTER(InferOpts), _VP, _VP, C.POINTER(_SZ)]),
+    "xdtts_tacotron2_decoder_step": (_I32, [_VP, _VP, _VP, _I32, _I32, C.POINTER(InferOpts), _U32] + [_VP] * 10),
+    "xdtts_tacotron2_engine_state": (_I32, [_VP, C.POINTER(_I32), C.POINTER(_I32)]),
+    "xdtts_tacotron2_engine_reset": (_I32, [_VP]),
     "xdtts_tacotron2_postnet": (_I32, [_VP, _VP, _I32, _VP]),
     "xdtts_tacotron2_last_timings": (_I32, [_VP, C.POINTER(C.c_float * 4), C.POINTER(_I32)]),
     "xdtts_tacotron2_free": (None, [_VP]),
@@ -339,6 +342,28 @@ class Tacotron2:
         nf = C.c_size_t()
         _check(lib.xdtts_tacotron2_decoder(self._h, _ptr(memory), _ptr(pmem), memory.shape[0], n_valid, C.byref(o), _ptr(frames), _ptr(gates), C.byref(nf)))
         return frames[: nf.value].copy(), gates[: nf.value].copy()
+
+    def decoder_step(self, memory, pmem, n_valid, state, decoder_input, step, opts=None):
+        """ONE decoder_iter call (mod.rs:304).  `state` = dict with the reference's tensor names
+        (attention_hidden, attention_cell, decoder_hidden, decoder_cell, attention_weights,
+        attention_weights_cum, attention_context); returns (decoder_output, gate_prediction, new state)."""
+        memory = np.ascontiguousarray(memory, dtype=np.float32)
+        pmem = np.ascontiguousarray(pmem, dtype=np.float32)
+        names = ("attention_hidden", "attention_cell", "decoder_hidden", "decoder_cell", "attention_weights", "attention_weights_cum", "attention_context")
+        st = {k: np.array(state[k], dtype=np.float32, order="C") for k in names}
+        din = np.ascontiguousarray(decoder_input, dtype=np.float32)
+        out, gate = np.empty(N_MEL, dtype=np.float32), np.empty(1, dtype=np.float32)
+        _check(lib.xdtts_tacotron2_decoder_step(self._h, _ptr(memory), _ptr(pmem), memory.shape[0], n_valid, C.byref(opts) if opts else None, step,
+                                                _ptr(din), *[_ptr(st[k]) for k in names], _ptr(out), _ptr(gate)))
+        return out, float(gate[0]), st
+
+    def engine_state(self):
+        a, b = C.c_int32(), C.c_int32()
+        _check(lib.xdtts_tacotron2_engine_state(self._h, C.byref(a), C.byref(b)))
+        return {"decoder_persistent": a.value, "encoder_cooperative": b.value}
+
+    def engine_reset(self):
+        _check(lib.xdtts_tacotron2_engine_reset(self._h))
 
     def postnet(self, frames):
         frames = np.ascontiguousarray(frames, dtype=np.float32)

@@ -168,12 +168,16 @@ struct xdtts_tacotron2 {
   DevBuf<int> enc_err;
   DevBuf<unsigned long long> dec_exchange;  // granule buffers of the persistent decoder
   DevBuf<int> dec_err;
-  int persist_state = -1;                   // -1 unknown, 0 unavailable on this device, 1 usable
+  int persist_state = -1;                   // -1 unknown, 0 unavailable on this device / demoted, 1 usable
+  bool persist_probe_ok = false;            // the device can host the persistent grid (occupancy probe)
   bool coop_ok = true;                      // cooperative encoder BiLSTM usable (cleared after a timed-out exchange)
   static constexpr int COOP_MAX_B = 16;  // 8*B blocks of 1024 threads must be co-resident
   DevBuf<float> att_h, att_c, dec_h, dec_c, aw, awc, ctx, x, loc, e_part, pmel, frames, gates;
   DevBuf<float> frag;       // batched mode: MFMA-operand copies of x, ctx, att_h[2], dec_h[2]
   DevBuf<int> item_perm;    // batched mode: dropout-stream index of the (length-sorted) chunks
+  DevBuf<float> dec_in_dev; // parity hook: decoder_input of xdtts_tacotron2_decoder_step
+  int demoted_calls = 0;    // decoder calls since a demotion (the fast engines are probed again after PROBE_AFTER)
+  static constexpr int PROBE_AFTER = 64;
   DevBuf<float> ppA, ppB, mel_dev;
   int *host_ctl = nullptr;  // pinned: [0..1] ctl, [2..] nframes
 
@@ -365,7 +369,17 @@ struct xdtts_tacotron2 {
     if (d.B > 2 * PERSIST_B_MAX || d.T > PERSIST_T_MAX) return false;  // 3..4 chunks: two launches of <= 2
     const char *e = getenv("XDTTS_DECODER");
     if (e && std::string(e) == "launch") return false;
-    if (persist_state < 0) persist_state = decoder_persistent_supported(device, PERSIST_B_MAX, PERSIST_T_MAX) ? 1 : 0;
+    if (persist_state < 0) {
+      persist_state = decoder_persistent_supported(device, PERSIST_B_MAX, PERSIST_T_MAX) ? 1 : 0;
+      persist_probe_ok = persist_state == 1;
+    }
+    // a timed-out exchange demotes the handle; the cause (another process holding CUs) may be transient, so
+    // the persistent engine gets another try every PROBE_AFTER calls (xdtts_tacotron2_engine_reset: at once)
+    if (persist_state == 0 && persist_probe_ok && ++demoted_calls >= PROBE_AFTER) {
+      demoted_calls = 0;
+      persist_state = 1;
+      coop_ok = true;
+    }
     return persist_state == 1;
   }
 
@@ -482,8 +496,9 @@ struct xdtts_tacotron2 {
       // engine for good, and decode this request again from the initial state.
       HIP_CHECK(hipMemsetAsync(dec_err.p, 0, sizeof(int), stream));
       persist_state = 0;
+      demoted_calls = 0;
       std::fprintf(stderr, "libxdtts_hip: persistent decoder exchange timed out (grid not co-resident); "
-                           "this handle now uses the launch-per-stage decoder\n");
+                           "this handle now uses the launch-per-stage decoder (probed again after %d calls)\n", PROBE_AFTER);
       launch_decoder_init(d, limits.p, stream);
     }
     if (!d.use_gate) {  // deterministic work: every chunk runs to its cap
@@ -1295,6 +1310,82 @@ xdtts_status xdtts_tacotron2_decoder(xdtts_tacotron2 *h, const float *memory, co
     if (gates) HIP_CHECK(hipMemcpyAsync(gates, d.gates, (size_t)F * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     h->finish_timings();
     *n_frames = (size_t)F;
+  });
+}
+
+// Parity hook: ONE decoder_iter.onnx call (mod.rs:304) from caller-held state, on the launch-per-stage kernels.
+xdtts_status xdtts_tacotron2_decoder_step(xdtts_tacotron2 *h, const float *memory, const float *processed_memory, int32_t T,
+                                          int32_t n_valid, const xdtts_infer_opts *opts, uint32_t step, const float *decoder_input,
+                                          float *attention_hidden, float *attention_cell, float *decoder_hidden, float *decoder_cell,
+                                          float *attention_weights, float *attention_weights_cum, float *attention_context,
+                                          float *decoder_output, float *gate_prediction) {
+  return guard([&] {
+    if (!h || !memory || !processed_memory || !decoder_input || !attention_hidden || !attention_cell || !decoder_hidden || !decoder_cell ||
+        !attention_weights || !attention_weights_cum || !attention_context || !decoder_output || !gate_prediction)
+      fail(XDTTS_ERR_BAD_ARG, "null argument");
+    if (T <= 0 || T > T_MAX || n_valid <= 0 || n_valid > T) fail(XDTTS_ERR_BAD_ARG, "bad T/n_valid");
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIP_CHECK(hipSetDevice(h->device));
+    xdtts_infer_opts o = resolve_opts(opts);
+    if (o.max_steps <= 0 || (uint64_t)step + 2 > (uint64_t)o.max_steps) o.max_steps = (int32_t)std::min<uint64_t>((uint64_t)step + 2, 1u << 30);
+    hipStream_t st = h->stream;
+    h->memory.upload(memory, (size_t)T * EMB, st);
+    h->pmem.upload(processed_memory, (size_t)T * ATT_DIM, st);
+    int nv = n_valid;
+    h->n_valid.upload(&nv, 1, st);
+    DecoderBufs d = h->decoder_bufs(1, T, h->memory.p, h->pmem.p, o);
+    d.use_gate = 0;  // the caller applies the stop rule to gate_prediction (mod.rs:319)
+    const int lim = (int)step + 2;
+    h->limits.upload(&lim, 1, st);
+    launch_decoder_init(d, h->limits.p, st);
+    h->dec_in_dev.upload(decoder_input, N_MEL, st);
+    d.dec_in = h->dec_in_dev.p;
+    auto up = [&](float *dst, const float *src, size_t n) { HIP_CHECK(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyHostToDevice, st)); };
+    up(d.att_h[0], attention_hidden, ATT_RNN);
+    up(d.att_c, attention_cell, ATT_RNN);
+    up(d.dec_h[0], decoder_hidden, DEC_RNN);
+    up(d.dec_c, decoder_cell, DEC_RNN);
+    up(d.aw, attention_weights, (size_t)T);
+    up(d.awc, attention_weights_cum, (size_t)T);
+    up(d.ctx, attention_context, EMB);
+    const int s0 = (int)step;
+    HIP_CHECK(hipMemcpyAsync(d.ctl, &s0, sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipStreamSynchronize(st));  // the sources above are caller memory / locals
+    launch_decoder_single_step(d, h->w, st);
+    d.dec_in = nullptr;
+    launch_decoder_flush(d, h->w, st);  // decoder_output and gate_prediction of this step
+    auto down = [&](float *dst, const float *src, size_t n) { HIP_CHECK(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToHost, st)); };
+    down(attention_hidden, d.att_h[1], ATT_RNN);
+    down(attention_cell, d.att_c, ATT_RNN);
+    down(decoder_hidden, d.dec_h[1], DEC_RNN);
+    down(decoder_cell, d.dec_c, DEC_RNN);
+    down(attention_weights, d.aw, (size_t)T);
+    down(attention_weights_cum, d.awc, (size_t)T);
+    down(attention_context, d.ctx, EMB);
+    down(decoder_output, d.frames + (size_t)step * N_MEL, N_MEL);
+    down(gate_prediction, d.gates + step, 1);
+    HIP_CHECK(hipStreamSynchronize(st));
+  });
+}
+
+// Which engines this handle currently uses (1 = the persistent / cooperative one, 0 = demoted to the
+// launch-per-stage / single-workgroup one after a timed-out exchange, -1 = not probed yet).
+xdtts_status xdtts_tacotron2_engine_state(const xdtts_tacotron2 *h, int32_t *decoder_persistent, int32_t *encoder_cooperative) {
+  return guard([&] {
+    if (!h) fail(XDTTS_ERR_BAD_ARG, "null handle");
+    if (decoder_persistent) *decoder_persistent = h->persist_state;
+    if (encoder_cooperative) *encoder_cooperative = h->coop_ok ? 1 : 0;
+  });
+}
+
+// Puts a demoted handle back on the fast engines (they are probed again on the next call).
+xdtts_status xdtts_tacotron2_engine_reset(xdtts_tacotron2 *h) {
+  return guard([&] {
+    if (!h) fail(XDTTS_ERR_BAD_ARG, "null handle");
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->persist_state = -1;
+    h->coop_ok = true;
+    h->demoted_calls = 0;
   });
 }
 

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -52,6 +53,25 @@ void set_last_error(const char *msg);
       ::xdtts::fail(e_ == hipErrorOutOfMemory ? XDTTS_ERR_OOM : XDTTS_ERR_HIP, "%s: %s (%s:%d)", \
                     #expr, hipGetErrorString(e_), __FILE__, __LINE__);                        \
   } while (0)
+
+// ---- kernels whose workgroups wait for one another -----------------------------------------------
+// The persistent decoder, the cooperative encoder BiLSTM and the persistent Griffin-Lim exchange data
+// between workgroups inside a launch, so their whole grid must be co-resident.  They are launched with
+// hipLaunchCooperativeKernel: the runtime then checks the grid against the device's occupancy AT LAUNCH
+// and refuses it (hipErrorCooperativeLaunchTooLarge) instead of letting resident workgroups spin for
+// ones that were never scheduled.  Costs ~15-20 us of host time per launch (MI355X_MICROARCH.md,
+// coop-launch); XDTTS_COOP=0 switches back to plain launches (residency is identical, only the check
+// is lost).  Every spin stays bounded either way: a grid kept off the chip by ANOTHER process is
+// caught by the timeout path, not by this check.
+template <class... Args>
+inline hipError_t launch_coresident(const void *fn, dim3 grid, dim3 block, size_t lds, hipStream_t s, Args... args) {
+  void *argv[] = {(void *)&args...};
+  static const bool plain = [] {
+    const char *e = getenv("XDTTS_COOP");
+    return e && e[0] == '0';
+  }();
+  return plain ? hipLaunchKernel(fn, grid, block, argv, lds, s) : hipLaunchCooperativeKernel(fn, grid, block, argv, (unsigned)lds, s);
+}
 
 // ---- counter-based RNG (specification shared with oracle/, implemented independently) ----
 __host__ __device__ inline uint32_t mix32(uint32_t x) {

@@ -213,7 +213,8 @@ __global__ __launch_bounds__(256) void k_prenet(DecoderBufs d, int i, int flush,
   const uint32_t item = d.item_base + (uint32_t)(d.item_perm ? d.item_perm[b] : b);
   if (m4 < MEL_LD / 4) *reinterpret_cast<float4 *>(&s_red[part][4 * m4]) = racc;
   __syncthreads();
-  const bool have_prev = step >= 1 && step - 1 < nf;  // the chunk was active at the previous step
+  const bool forced = d.dec_in != nullptr && !flush;  // parity hook: the caller supplies decoder_input
+  const bool have_prev = !forced && step >= 1 && step - 1 < nf;  // the chunk was active at the previous step
   if (tid < MEL_LD) {
     float v = 0.f;
     if (have_prev && tid < N_MEL + 1) {
@@ -221,6 +222,7 @@ __global__ __launch_bounds__(256) void k_prenet(DecoderBufs d, int i, int flush,
 #pragma unroll
       for (int k = 0; k < 8; ++k) v += s_red[k][tid];
     }
+    if (forced && tid < N_MEL) v = d.dec_in[b * N_MEL + tid];
     s_mel[tid] = v;  // step 0: decoder_input = 0 (mod.rs:208)
   }
   __syncthreads();
@@ -900,6 +902,27 @@ void launch_decoder_steps(const DecoderBufs &d, const DeviceWeights &w, int nste
     }
   }
   hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, s, d, nsteps);
+  HIP_CHECK(hipGetLastError());
+}
+
+__global__ __launch_bounds__(256) void k_location_all(DecoderBufs d, const float *__restrict__ loc_convT, const float *__restrict__ loc_denseT) {
+  const int tiles = (d.T + LOC_TT - 1) / LOC_TT;
+  location_role(d, blockIdx.x / tiles, blockIdx.x % tiles, loc_convT, loc_denseT);
+}
+
+void launch_decoder_single_step(const DecoderBufs &d, const DeviceWeights &w, hipStream_t s) {
+  if (d.xf) fail(XDTTS_ERR_BAD_ARG, "single-step hook runs the small-batch kernels");
+  const int loc_tiles = (d.T + LOC_TT - 1) / LOC_TT;
+  const float4 *q4 = reinterpret_cast<const float4 *>(w.q_w4.p), *wh4 = reinterpret_cast<const float4 *>(w.proj_wh4.p);
+  hipLaunchKernelGGL(k_location_all, dim3(loc_tiles * d.B), dim3(256), 0, s, d, w.loc_conv.p, w.loc_denseT.p);
+  hipLaunchKernelGGL(k_prenet, dim3(PRENET_BLOCKS * d.B), dim3(256), 0, s, d, 0, 0, w.pre0T.p, w.pre1T.p, w.proj_b.p);
+  hipLaunchKernelGGL((k_lstm<ATT_COLS, 0>), dim3(NBLK), dim3(256), 0, s, d, 0, 0, reinterpret_cast<const float4 *>(w.att_w.p), w.att_b.p, q4,
+                     w.loc_conv.p, w.loc_denseT.p);
+  hipLaunchKernelGGL(k_qenergy, dim3(ATT_DIM / 4, 1), dim3(256), 0, s, d, 0, 0, reinterpret_cast<const float4 *>(w.q_w.p), w.v_w.p);
+  hipLaunchKernelGGL(k_softmax_ctx, dim3(CTX_BLOCKS * d.B), dim3(256), 0, s, d, 0, w.proj_wc.p, w.loc_conv.p, w.loc_denseT.p);
+  hipLaunchKernelGGL((k_lstm<DEC_COLS, 1>), dim3(loc_tiles * d.B + NBLK), dim3(256), 0, s, d, 0, 0, reinterpret_cast<const float4 *>(w.dec_w.p),
+                     w.dec_b.p, wh4, w.loc_conv.p, w.loc_denseT.p);
+  hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, s, d, 1);
   HIP_CHECK(hipGetLastError());
 }
 

@@ -949,13 +949,9 @@ bool gl_persistent_supported(int device, int *n_cu) {
 // launch-per-iteration path; p.ang_out / p.tprev_out (parity hook) receive the final state.
 void launch_gl_persistent(const GlBufs &g, const GlPersist &p, const float2 *ang_in, const float2 *tprev_in, int n_iter,
                           float alpha, float *audio, hipStream_t s) {
-  if (p.TF <= 4)
-    hipLaunchKernelGGL(k_gl_persistent<4>, dim3(p.nblk), dim3(64 * p.TF), gl_persistent_lds_bytes(p.TF), s, g, p, ang_in, tprev_in,
-                       n_iter, alpha, audio);
-  else
-    hipLaunchKernelGGL(k_gl_persistent<8>, dim3(p.nblk), dim3(64 * p.TF), gl_persistent_lds_bytes(p.TF), s, g, p, ang_in, tprev_in,
-                       n_iter, alpha, audio);
-  HIP_CHECK(hipGetLastError());
+  const void *fn = p.TF <= 4 ? reinterpret_cast<const void *>(k_gl_persistent<4>) : reinterpret_cast<const void *>(k_gl_persistent<8>);
+  HIP_CHECK(launch_coresident(fn, dim3(p.nblk), dim3(64 * p.TF), gl_persistent_lds_bytes(p.TF), s, g, p, ang_in, tprev_in, n_iter, alpha,
+                              audio));
 }
 
 // Enqueues n_iter iterations (no final ISTFT) and returns the buffer that holds the final angles.

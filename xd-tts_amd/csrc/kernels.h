@@ -40,10 +40,14 @@ struct DecoderBufs {
   int Bpad;
   float *awc2;           // [B][T] second cumulative-weights buffer (ping-pong by step parity, batched mode)
   const int *item_perm;  // [B] dropout-stream index of chunk b (the batch is sorted by length), or null = b
+  const float *dec_in;   // parity hook (xdtts_tacotron2_decoder_step): decoder_input [B][80] of this step, or null
 };
 
 // Enqueues `nsteps` decoder steps on `s` (5 kernels each) and advances the device step base.
 void launch_decoder_steps(const DecoderBufs &d, const DeviceWeights &w, int nsteps, hipStream_t s);
+// Parity hook: ONE step (i = 0, state read from the [0] halves, written to [1]) and the location features
+// of the CURRENT attention weights (a sequence normally gets them from its previous step).
+void launch_decoder_single_step(const DecoderBufs &d, const DeviceWeights &w, hipStream_t s);
 // After the last step of a sequence: completes the final frame's projection (frames, gate).
 void launch_decoder_flush(const DecoderBufs &d, const DeviceWeights &w, hipStream_t s);
 size_t decoder_pmel_floats(int B);
