@@ -6,7 +6,7 @@ if len(sys.argv) > 1:
     os.environ["XDTTS_DEBUG_MIX"] = sys.argv[1]
     pkg = importlib.import_module("xd-tts_amd")
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from conftest import synth_ids
+    synth_ids = importlib.import_module("xd-tts_amd.workloads").synth_ids
     ids = synth_ids(95)
     m = pkg.Tacotron2.synthetic()
     o = pkg.default_opts(fixed_steps=400)

@@ -6,7 +6,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle
-from conftest import synth_ids
+synth_ids = importlib.import_module("xd-tts_amd.workloads").synth_ids
 from test_gpu_griffinlim_more import chirps
 pkg = importlib.import_module("xd-tts_amd")
 

@@ -4,7 +4,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 pkg = importlib.import_module("xd-tts_amd")
-from conftest import synth_ids
+synth_ids = importlib.import_module("xd-tts_amd.workloads").synth_ids
 
 def rms(a, b):
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)

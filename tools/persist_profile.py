@@ -5,7 +5,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 pkg = importlib.import_module("xd-tts_amd")
-from conftest import synth_ids
+synth_ids = importlib.import_module("xd-tts_amd.workloads").synth_ids
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 steps = 400
 path = "/tmp/persist_prof.txt"

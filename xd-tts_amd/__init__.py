@@ -115,7 +115,35 @@ SYMBOLS = {
 }
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64
+    and ask for them by file name, so a process that loads libxdtts_hip.so first (system ROCm runtime,
+    soname libamdhip64.so.7) and imports torch later ends up with TWO runtimes driving the same GPU
+    (observed: a device-side error word the host never sees).  If torch is installed but not imported
+    yet, map ITS runtime first -- without importing torch -- so that our DT_NEEDED resolves to that copy
+    and a later `import torch` finds it already loaded.  With torch imported first nothing is needed;
+    without torch installed the system runtime is the only one."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if not spec or not spec.origin:
+        return
+    lib = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(lib):
+        try:
+            C.CDLL(lib, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def _load():
+    _share_torch_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "%s not found: build it with `make -C %s` (or __graft_entry__.build()); there is no CPU fallback" % (LIB_PATH, _HERE)
