@@ -124,6 +124,13 @@ class GriffinLim {
     xdtts_free(audio);
     return out;
   }
+  // The conventions of the crate's mel->linear step as switches (xdtts_griffinlim_opts)
+  void set_opts(const xdtts_griffinlim_opts &o) { check(xdtts_griffinlim_set_opts(g_, &o)); }
+  xdtts_griffinlim_opts opts() const {
+    xdtts_griffinlim_opts o;
+    check(xdtts_griffinlim_get_opts(g_, &o));
+    return o;
+  }
   xdtts_griffinlim *raw() const { return g_; }
 
  private:
