@@ -675,6 +675,9 @@ __global__ __launch_bounds__(64 * MFMA_WAVES) void k_lstm_mfma(DecoderBufs d, in
 // This spreads the 12.8k tanh of a step over 32 CUs instead of one.
 __global__ __launch_bounds__(256) void k_qenergy(DecoderBufs d, int i, int cur, const float4 *__restrict__ Wq,
                                                  const float *__restrict__ v_w) {
+#ifdef XDTTS_LSTM_PROBE
+  const unsigned long long t_in = wall_clock64();
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, blk = blockIdx.x;
   const int row = blk * 4 + wave;
   float4 w[4];
@@ -709,14 +712,26 @@ __global__ __launch_bounds__(256) void k_qenergy(DecoderBufs d, int i, int cur, 
         l4 = *reinterpret_cast<const float4 *>(d.loc + o);
         p4 = *reinterpret_cast<const float4 *>(d.pmem + o);
       }
-      float e = v4.x * tanhf(q4.x + l4.x + p4.x);
-      e = fmaf(v4.y, tanhf(q4.y + l4.y + p4.y), e);
-      e = fmaf(v4.z, tanhf(q4.z + l4.z + p4.z), e);
-      e = fmaf(v4.w, tanhf(q4.w + l4.w + p4.w), e);
+      float e;
+      if (gridDim.y > 1) {  // batched mode: hardware exp2 / rcp tanh, as the persistent engine uses
+        e = v4.x * fast_tanh(q4.x + l4.x + p4.x);
+        e = fmaf(v4.y, fast_tanh(q4.y + l4.y + p4.y), e);
+        e = fmaf(v4.z, fast_tanh(q4.z + l4.z + p4.z), e);
+        e = fmaf(v4.w, fast_tanh(q4.w + l4.w + p4.w), e);
+      } else {
+        e = v4.x * tanhf(q4.x + l4.x + p4.x);
+        e = fmaf(v4.y, tanhf(q4.y + l4.y + p4.y), e);
+        e = fmaf(v4.z, tanhf(q4.z + l4.z + p4.z), e);
+        e = fmaf(v4.w, tanhf(q4.w + l4.w + p4.w), e);
+      }
       if (act) d.e_part[((size_t)b * (ATT_DIM / 4) + blk) * d.T + t] = e;
     }
     __syncthreads();
   }
+#ifdef XDTTS_LSTM_PROBE
+  if (tid == 0 && step == 100 && (blockIdx.y % 17 == 0) && (blk == 0 || blk == 31))
+    printf("probe qenergy blk (%d,%d) in %llu out %llu\n", blk, (int)blockIdx.y, t_in % 1000000ull, wall_clock64() % 1000000ull);
+#endif
 }
 
 // D3b: e_t = sum of the 32 partial energies, -inf where t >= n_valid (mask, mod.rs:219-220);
@@ -727,6 +742,10 @@ __global__ __launch_bounds__(256) void k_qenergy(DecoderBufs d, int i, int cur, 
 // new attention weights.
 __global__ __launch_bounds__(256) void k_softmax_ctx(DecoderBufs d, int i, const float *__restrict__ proj_wc,
                                                      const float *__restrict__ loc_convT, const float *__restrict__ loc_denseT) {
+#ifdef XDTTS_LSTM_PROBE
+  const unsigned long long t_in = wall_clock64();
+  unsigned long long t_sm = 0, t_ctx = 0;
+#endif
   const int b = blockIdx.x / CTX_BLOCKS, cblk = blockIdx.x % CTX_BLOCKS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int T = d.T;
@@ -735,6 +754,28 @@ __global__ __launch_bounds__(256) void k_softmax_ctx(DecoderBufs d, int i, const
   __shared__ __attribute__((aligned(16))) float s_e[T_MAX], s_part[TG][CTX_COLS], s_ctx[CTX_COLS];
   const int c4 = tid % C4, tg = tid / C4;
   const float4 *mem = reinterpret_cast<const float4 *>(d.memory + (size_t)b * T * EMB) + cblk * C4;
+  // Batched mode: the NEXT step's location features are this kernel's tail (every block holds the whole
+  // softmax, so the 8 blocks of a chunk split the time tiles) instead of a launch of their own; the
+  // cumulative weights ping-pong between two buffers by step parity because the other blocks of the
+  // chunk still read the old ones while block 0 writes the new.
+  const bool batched = d.xf != nullptr;
+  __shared__ float s_awc[T_MAX];
+  LocWeights lw;
+  const float *awc_in = batched && (i & 1) ? d.awc2 : d.awc;
+  float *awc_out = batched ? ((i & 1) ? d.awc : d.awc2) : d.awc;
+  const int nv = d.n_valid[b];
+  // Issue order = retire order (vmcnt): the partial energies the softmax waits for go out FIRST; the
+  // context's slice of the encoder memory and the projection / location weights follow and are consumed
+  // after the softmax (batched mode: 416 blocks fetching 10.6 MB of memory made the softmax wait ~3 us).
+  float ev0[ATT_DIM / 4];
+  {
+    const float *ep = d.e_part + (size_t)b * (ATT_DIM / 4) * T + (tid < T ? tid : 0);
+#pragma unroll
+    for (int k = 0; k < ATT_DIM / 4; ++k) ev0[k] = ep[(size_t)k * T];
+  }
+  const int step = d.ctl[0] + i;
+  const bool act = step < d.nframes[b];
+  asm volatile("" ::: "memory");
   // projection weights of this block's 64 context columns: thread (m, half) holds 32 of row m
   const int pm_m = tid >> 1, pm_half = tid & 1;
   float4 wc[8];
@@ -748,29 +789,21 @@ __global__ __launch_bounds__(256) void k_softmax_ctx(DecoderBufs d, int i, const
     const int t = tg + TG * u;
     pf[u] = t < T ? mem[(size_t)t * (EMB / 4) + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  // Batched mode: the NEXT step's location features are this kernel's tail (every block holds the whole
-  // softmax, so the 8 blocks of a chunk split the time tiles) instead of a launch of their own; the
-  // cumulative weights ping-pong between two buffers by step parity because the other blocks of the
-  // chunk still read the old ones while block 0 writes the new.
-  const bool batched = d.xf != nullptr;
-  __shared__ float s_awc[T_MAX];
-  LocWeights lw;
   if (batched) location_weights(lw, loc_convT, loc_denseT);
-  const float *awc_in = batched && (i & 1) ? d.awc2 : d.awc;
-  float *awc_out = batched ? ((i & 1) ? d.awc : d.awc2) : d.awc;
-  const int nv = d.n_valid[b];
-  for (int t = tid; t < T; t += 256) {
-    const float *ep = d.e_part + (size_t)b * (ATT_DIM / 4) * T + t;
-    float ev[ATT_DIM / 4];
-#pragma unroll
-    for (int k = 0; k < ATT_DIM / 4; ++k) ev[k] = ep[(size_t)k * T];
+  asm volatile("" ::: "memory");
+  if (tid < T) {
     float e = 0.f;
 #pragma unroll
-    for (int k = 0; k < ATT_DIM / 4; ++k) e += ev[k];
+    for (int k = 0; k < ATT_DIM / 4; ++k) e += ev0[k];
+    s_e[tid] = tid >= nv ? -INFINITY : e;
+  }
+  for (int t = tid + 256; t < T; t += 256) {  // encoder memories longer than 256 steps
+    const float *ep = d.e_part + (size_t)b * (ATT_DIM / 4) * T + t;
+    float e = 0.f;
+#pragma unroll
+    for (int k = 0; k < ATT_DIM / 4; ++k) e += ep[(size_t)k * T];
     s_e[t] = t >= nv ? -INFINITY : e;
   }
-  const int step = d.ctl[0] + i;
-  const bool act = step < d.nframes[b];
   __syncthreads();
   if (wave == 0) {
     float m = -INFINITY;
@@ -778,7 +811,7 @@ __global__ __launch_bounds__(256) void k_softmax_ctx(DecoderBufs d, int i, const
     m = wave_max(m);
     float sum = 0.f;
     for (int t = lane; t < T; t += 64) {
-      const float ex = expf(s_e[t] - m);
+      const float ex = batched ? fast_exp(s_e[t] - m) : expf(s_e[t] - m);
       s_e[t] = ex;
       sum += ex;
     }
@@ -794,6 +827,9 @@ __global__ __launch_bounds__(256) void k_softmax_ctx(DecoderBufs d, int i, const
       awc_out[b * T + t] = cum;
     }
   }
+#ifdef XDTTS_LSTM_PROBE
+  t_sm = wall_clock64();
+#endif
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   int k = 0;
   for (int t0 = tg; t0 < T; t0 += TG * CTX_PF) {
@@ -833,8 +869,15 @@ __global__ __launch_bounds__(256) void k_softmax_ctx(DecoderBufs d, int i, const
     pv += dpp_move<0xB1, 0xf>(0.f, pv);  // lanes 2j, 2j+1 hold the two halves of row m
     if (act && pm_half == 0 && pm_m <= N_MEL) d.pmel[((size_t)b * PM_ROWS + cblk) * MEL_LD + pm_m] = pv;
   }
+#ifdef XDTTS_LSTM_PROBE
+  t_ctx = wall_clock64();
+#endif
   if (batched && act)
     for (int tile = cblk; tile * LOC_TT < T; tile += CTX_BLOCKS) location_tile(d, b, tile, s_e, s_awc, lw);
+#ifdef XDTTS_LSTM_PROBE
+  if (tid == 0 && step == 100 && (b % 17 == 0) && (cblk == 0 || cblk == 7))
+    printf("probe softmax_ctx blk (%d,%d) in %llu softmax_done %llu ctx_pmel_done %llu out %llu\n", b, cblk, t_in % 1000000ull, t_sm % 1000000ull, t_ctx % 1000000ull, wall_clock64() % 1000000ull);
+#endif
 }
 
 }  // namespace
