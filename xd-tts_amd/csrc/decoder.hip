@@ -673,6 +673,7 @@ __global__ __launch_bounds__(64 * MFMA_WAVES) void k_lstm_mfma(DecoderBufs d, in
 // then the 256 threads each take a time step and emit
 //   e_part[blk][t] = sum_{a in block} v_a tanh(q_a + loc[t][a] + processed_memory[t][a]).
 // This spreads the 12.8k tanh of a step over 32 CUs instead of one.
+constexpr int QE_GROUP = 4;
 __global__ __launch_bounds__(256) void k_qenergy(DecoderBufs d, int i, int cur, const float4 *__restrict__ Wq,
                                                  const float *__restrict__ v_w) {
 #ifdef XDTTS_LSTM_PROBE
@@ -686,8 +687,9 @@ __global__ __launch_bounds__(256) void k_qenergy(DecoderBufs d, int i, int cur, 
   const float4 v4 = *reinterpret_cast<const float4 *>(v_w + blk * 4);
   const int step = d.ctl[0] + i;
   __shared__ __attribute__((aligned(16))) float s_q[4];
-  // small batches: one launch row loops over the chunks; large batches: gridDim.y = B
-  const int b_lo = gridDim.y > 1 ? blockIdx.y : 0, b_hi = gridDim.y > 1 ? b_lo + 1 : d.B;
+  // small batches: one launch row loops over the chunks; large batches: QE_GROUP chunks per block row
+  // (the query rows stay in registers across them)
+  const int b_lo = gridDim.y > 1 ? blockIdx.y * QE_GROUP : 0, b_hi = gridDim.y > 1 ? min(d.B, b_lo + QE_GROUP) : d.B;
   for (int b = b_lo; b < b_hi; ++b) {
     if (b > b_lo && step >= d.nframes[b]) continue;
     const float *h = d.att_h[cur ^ 1] + b * ATT_RNN;
@@ -926,7 +928,7 @@ void launch_decoder_steps(const DecoderBufs &d, const DeviceWeights &w, int nste
                                w.loc_conv.p, w.loc_denseT.p);
           break;
         case 'q':
-          hipLaunchKernelGGL(k_qenergy, dim3(ATT_DIM / 4, batched ? d.B : 1), dim3(256), 0, s, d, i, cur,
+          hipLaunchKernelGGL(k_qenergy, dim3(ATT_DIM / 4, batched ? std::max(2, (d.B + QE_GROUP - 1) / QE_GROUP) : 1), dim3(256), 0, s, d, i, cur,
                              reinterpret_cast<const float4 *>(w.q_w.p), w.v_w.p);
           break;
         case 's':
