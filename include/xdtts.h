@@ -200,6 +200,14 @@ xdtts_status xdtts_griffinlim_set_seed(xdtts_griffinlim *g, uint32_t seed);
 xdtts_status xdtts_griffinlim_infer(xdtts_griffinlim *g, const float *mel, size_t n_mels,
                                     size_t n_frames, float **audio, size_t *n_samples);
 
+/* GriffinLim::infer for n_utt utterances in one call (the vocoder half of a batch; the reference calls
+ * self.vocoder.infer once per utterance, src/lib.rs:141): mels[u] is n_mels x n_frames[u]; audios[u]
+ * receives hop*(n_frames[u]-1) samples, bit-identical to xdtts_griffinlim_infer on that utterance alone.
+ * Utterances share persistent launches (a workgroup never spans two). */
+xdtts_status xdtts_griffinlim_infer_batch(xdtts_griffinlim *g, const float *const *mels, size_t n_mels,
+                                          const size_t *n_frames, int32_t n_utt, float **audios,
+                                          size_t *n_samples);
+
 /* Same, skipping the mel->linear inversion: S is n_bins x F linear magnitude; phase0 is
  * n_bins x F x 2 (cos, sin) or NULL for the seeded stream; iters = 0 uses the handle's count. */
 xdtts_status xdtts_griffinlim_infer_linear(xdtts_griffinlim *g, const float *S,

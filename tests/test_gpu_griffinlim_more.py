@@ -161,3 +161,25 @@ def test_mel_to_linear_options_match_the_oracle(pkg, orc):
         v.set_opts(power_mode=7)
     assert e.value.status == pkg.XDTTS_ERR_BAD_ARG
     v.close()
+
+
+def test_vocoder_batch_equals_one_by_one(pkg):
+    """xdtts_griffinlim_infer_batch: several utterances per persistent launch (workgroups never span two),
+    tiny (< 16 frames) and long (> 1024) ones on their own path -- every audio bit-identical to the
+    single-utterance call, whatever the mix and the order."""
+    v = pkg.create_griffin_lim(iters=12, seed=9)
+    rng = np.random.default_rng(8)
+    Fs = [37, 16, 5, 400, 1100, 19, 2, 257, 64, 1024, 333]
+    mels = [(rng.uniform(-7.0, -1.0, size=(80, F)) + 1.5 * np.sin(np.arange(F) / 6.0)[None, :]).astype(np.float32) for F in Fs]
+    one = [v.infer(m) for m in mels]
+    got = v.infer_batch(mels)
+    assert len(got) == len(Fs)
+    for F, a, b in zip(Fs, got, one):
+        assert a.shape == (256 * (F - 1),) and np.array_equal(a, b), F
+    got2 = v.infer_batch(mels[::-1])[::-1]
+    assert all(np.array_equal(a, b) for a, b in zip(got2, one))
+    # many short utterances: more workgroups than CUs -> several launches
+    many = [mels[0]] * 40 + [mels[3]] * 5
+    outs = v.infer_batch(many)
+    assert all(np.array_equal(o, one[0]) for o in outs[:40]) and all(np.array_equal(o, one[3]) for o in outs[40:])
+    v.close()

@@ -92,6 +92,7 @@ SYMBOLS = {
     "xdtts_griffinlim_get_opts": (_I32, [_VP, _VP]),
     "xdtts_griffinlim_set_seed": (_I32, [_VP, _U32]),
     "xdtts_griffinlim_infer": (_I32, [_VP, _VP, _SZ, _SZ, C.POINTER(_PF), C.POINTER(_SZ)]),
+    "xdtts_griffinlim_infer_batch": (_I32, [_VP, _VP, _SZ, _VP, _I32, _VP, _VP]),
     "xdtts_griffinlim_infer_linear": (_I32, [_VP, _VP, _VP, _SZ, _SZ, C.POINTER(_PF), C.POINTER(_SZ)]),
     "xdtts_griffinlim_mel_to_linear": (_I32, [_VP, _VP, _SZ, _SZ, _VP]),
     "xdtts_griffinlim_step": (_I32, [_VP, _VP, _VP, _VP, _SZ, _SZ]),
@@ -457,6 +458,17 @@ class GriffinLim:
         audio, n = _PF(), C.c_size_t()
         _check(lib.xdtts_griffinlim_infer(self._h, _ptr(mel), mel.shape[0], mel.shape[1], C.byref(audio), C.byref(n)))
         return _take(audio, n.value, (n.value,))
+
+    def infer_batch(self, mels):
+        """GriffinLim::infer for a list of (80, F_u) mels in one call; returns the list of audios."""
+        ms = [np.ascontiguousarray(m, dtype=np.float32) for m in mels]
+        n = len(ms)
+        ptrs = (C.c_void_p * n)(*[m.ctypes.data for m in ms])
+        nf = (C.c_size_t * n)(*[m.shape[1] for m in ms])
+        audios = (_PF * n)()
+        ns = (C.c_size_t * n)()
+        _check(lib.xdtts_griffinlim_infer_batch(self._h, ptrs, ms[0].shape[0], nf, n, audios, ns))
+        return [_take(audios[u], ns[u], (ns[u],)) for u in range(n)]
 
     def infer_linear(self, S, phase0=None, iters=0):
         S = np.ascontiguousarray(S, dtype=np.float32)

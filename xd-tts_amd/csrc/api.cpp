@@ -746,6 +746,8 @@ struct xdtts_griffinlim {
   DevBuf<float2> tw, ang, ang2, tprev, tprev2;  // tprev2: final rebuilt spectrum of the parity hook
   // persistent engine (griffinlim.hip: k_gl_persistent)
   DevBuf<unsigned long long> xch;  // neighbour-overlap granules
+  DevBuf<GlSeg> segs;              // vocoder batch: per-workgroup segment table
+  DevBuf<int> frame_local;         // vocoder batch: row -> frame index inside its utterance
   DevBuf<int> gl_err;
   int *host_err = nullptr;         // pinned
   unsigned epoch = 0;              // tag base; tags are never reused while xch lives
@@ -1569,6 +1571,154 @@ xdtts_status xdtts_griffinlim_infer(xdtts_griffinlim *g, const float *mel, size_
     g->mel_in.upload(mel, n_mels * n_frames, g->stream);
     HIP_CHECK(hipStreamSynchronize(g->stream));
     gl_run_from_device_mel(g, g->mel_in.p, (int)n_frames, audio, n_samples);
+  });
+}
+
+// GriffinLim::infer for several utterances at once (the vocoder half of a batch, BASELINE.json configs[3]):
+// the utterances' frames are concatenated, mel -> linear is one GEMM over all of them, and the persistent
+// kernel takes as many utterances per launch as fit one workgroup per CU (a workgroup never spans two
+// utterances and exchanges overlaps only inside its own).  Every utterance's audio is bit-identical to what
+// xdtts_griffinlim_infer returns for it alone.
+xdtts_status xdtts_griffinlim_infer_batch(xdtts_griffinlim *g, const float *const *mels, size_t n_mels, const size_t *n_frames,
+                                          int32_t n_utt, float **audios, size_t *n_samples) {
+  return guard([&] {
+    if (!g || !mels || !n_frames || !audios || !n_samples || n_utt <= 0) fail(XDTTS_ERR_BAD_ARG, "bad argument");
+    if ((int)n_mels != g->n_mels) fail(XDTTS_ERR_BAD_ARG, "mel has %zu rows, basis has %d", n_mels, g->n_mels);
+    std::vector<int> fbase(n_utt), abase(n_utt), Fu(n_utt);
+    size_t Ftot = 0, Ntot = 0;
+    for (int u = 0; u < n_utt; ++u) {
+      audios[u] = nullptr;
+      n_samples[u] = 0;
+      if (!mels[u] || n_frames[u] < 2) fail(XDTTS_ERR_BAD_ARG, "utterance %d: need at least 2 frames", u);
+      fbase[u] = (int)Ftot;
+      abase[u] = (int)Ntot;
+      Fu[u] = (int)n_frames[u];
+      Ftot += n_frames[u];
+      Ntot += (size_t)g->hop * (n_frames[u] - 1);
+      if (Ftot > (1u << 24)) fail(XDTTS_ERR_BAD_ARG, "batch too large");
+    }
+    std::lock_guard<std::mutex> lk(g->mu);
+    HIP_CHECK(hipSetDevice(g->device));
+    hipStream_t st = g->stream;
+    // mel of all utterances side by side: [n_mels][Ftot], staged in pinned memory (one fast upload)
+    PinnedGuard mel_all((size_t)n_mels * Ftot);
+    std::vector<int> fl(Ftot);
+    for (int u = 0; u < n_utt; ++u) {
+      for (size_t m = 0; m < n_mels; ++m)
+        std::memcpy(mel_all.p + m * Ftot + fbase[u], mels[u] + m * n_frames[u], sizeof(float) * n_frames[u]);
+      for (int f = 0; f < Fu[u]; ++f) fl[(size_t)fbase[u] + f] = f;
+    }
+    g->mel_in.upload(mel_all.p, (size_t)n_mels * Ftot, st);
+    g->frame_local.upload(fl.data(), fl.size(), st);
+    GlBufs all = g->bufs((int)Ftot);
+    g->audio.alloc(std::max<size_t>(Ntot, 1));
+    HIP_CHECK(hipStreamSynchronize(st));  // the two host vectors above
+    const float alpha = g->momentum / (1.0f + g->momentum);
+    std::lock_guard<std::recursive_mutex> chip(chip_mutex(g->device));
+    for (int attempt = 0;; ++attempt) {
+      HIP_CHECK(hipEventRecord(g->ev.e[0], st));
+      g->mel_to_linear(g->mel_in.p, (int)Ftot);
+      HIP_CHECK(hipEventRecord(g->ev.e[1], st));
+      launch_gl_phase_init_batch(all, g->seed, g->frame_local.p, st);
+      // pack consecutive utterances into persistent launches of <= one workgroup per CU (4 frames per workgroup)
+      const bool pers = g->persistent_usable();
+      std::vector<GlSeg> segs;
+      struct Launch { int seg0, nblk; };
+      std::vector<Launch> launches;
+      std::vector<char> batched(n_utt, 0);
+      constexpr int TF = 4;
+      if (pers) {
+        int cur0 = 0, cur_n = 0;
+        auto flush = [&]() {
+          if (cur_n) launches.push_back({cur0, cur_n});
+          cur0 = (int)segs.size();
+          cur_n = 0;
+        };
+        for (int u = 0; u < n_utt; ++u) {
+          const int nb = (Fu[u] + TF - 1) / TF;
+          if (Fu[u] < 16 || nb > g->n_cu || Fu[u] / nb < 3) continue;  // on its own below
+          if (cur_n + nb > g->n_cu) flush();
+          for (int b = 0; b < nb; ++b) {
+            GlSeg sg{};
+            sg.fbase = fbase[u];
+            sg.F = Fu[u];
+            sg.f0 = (int)(((long long)b * Fu[u]) / nb);
+            sg.n_own = (int)(((long long)(b + 1) * Fu[u]) / nb) - sg.f0;
+            sg.first = b == 0;
+            sg.last = b + 1 == nb;
+            sg.abase = abase[u];
+            segs.push_back(sg);
+          }
+          cur_n += nb;
+          batched[u] = 1;
+        }
+        flush();
+      }
+      bool used_persistent = false;
+      if (!segs.empty()) {
+        g->segs.upload(segs.data(), segs.size(), st);
+        HIP_CHECK(hipStreamSynchronize(st));
+        const size_t words = gl_persistent_xch_words(g->n_cu);
+        unsigned need = 0;
+        for (size_t i = 0; i < launches.size(); ++i) need += (unsigned)g->iters + 2u;
+        if (words > g->xch.n || g->epoch > 0x7fff0000u - need) {
+          g->xch.alloc(words);
+          HIP_CHECK(hipMemsetAsync(g->xch.p, 0, g->xch.n * sizeof(unsigned long long), st));
+          g->epoch = 0;
+        }
+        if (!g->gl_err.p) {
+          g->gl_err.alloc(1);
+          HIP_CHECK(hipMemsetAsync(g->gl_err.p, 0, sizeof(int), st));
+          HIP_CHECK(hipHostMalloc((void **)&g->host_err, sizeof(int), hipHostMallocDefault));
+        }
+        for (const Launch &L : launches) {
+          GlPersist p{};
+          p.segs = g->segs.p + L.seg0;
+          p.xch = g->xch.p;
+          p.err = g->gl_err.p;
+          p.epoch = g->epoch;
+          p.nblk = L.nblk;
+          p.TF = TF;
+          g->epoch += (unsigned)g->iters + 2u;
+          launch_gl_persistent(all, p, all.ang, all.tprev, g->iters, alpha, g->audio.p, st);
+        }
+        used_persistent = true;
+      }
+      for (int u = 0; u < n_utt; ++u) {  // the rest one by one (tiny / very long utterances, or a demoted handle)
+        if (batched[u]) continue;
+        GlBufs v = all;
+        v.F = Fu[u];
+        v.S = all.S + (size_t)fbase[u] * g->nb;
+        v.ang = all.ang + (size_t)fbase[u] * g->nb;
+        v.ang2 = all.ang2 + (size_t)fbase[u] * g->nb;
+        v.tprev = all.tprev + (size_t)fbase[u] * g->nb;
+        v.frames = all.frames + (size_t)fbase[u] * g->n_fft;
+        v.wss_inv = all.wss_inv + abase[u];
+        launch_gl_prepare(v, st);
+        g->run_iterations(v, g->iters, alpha, g->audio.p + abase[u]);  // the engine the single-utterance call uses
+        used_persistent = used_persistent || g->last_persistent;
+      }
+      if (g->gopts.peak_normalise)
+        for (int u = 0; u < n_utt; ++u) launch_gl_peak_normalise(g->audio.p + abase[u], g->hop * (Fu[u] - 1), g->peak.p, st);
+      HIP_CHECK(hipEventRecord(g->ev.e[2], st));
+      std::vector<PinnedGuard> out;  // each utterance straight into the buffer the caller receives
+      out.reserve((size_t)n_utt);
+      for (int u = 0; u < n_utt; ++u) {
+        out.emplace_back((size_t)g->hop * (size_t)(Fu[u] - 1));
+        HIP_CHECK(hipMemcpyAsync(out[(size_t)u].p, g->audio.p + abase[u], sizeof(float) * (size_t)g->hop * (size_t)(Fu[u] - 1), hipMemcpyDeviceToHost, st));
+      }
+      g->finish_timings();
+      g->last_persistent = used_persistent;
+      if (g->persistent_failed()) {
+        if (attempt) fail(XDTTS_ERR_HIP, "Griffin-Lim batch: exchange failure on the fallback engine");
+        continue;  // demoted: everything runs one by one on the launch-per-iteration kernels
+      }
+      for (int u = 0; u < n_utt; ++u) {
+        audios[u] = out[(size_t)u].release();
+        n_samples[u] = (size_t)g->hop * (size_t)(Fu[u] - 1);
+      }
+      return;
+    }
   });
 }
 

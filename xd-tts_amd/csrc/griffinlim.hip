@@ -472,8 +472,20 @@ __global__ __launch_bounds__(64 * W) void k_gl_persistent(GlBufs g, GlPersist p,
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int TF = p.TF, nthr = 64 * TF;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
-  const int F = g.F, N = HOP * (F - 1);
-  const int f0 = glp_fstart(b, F, p.nblk), nb_own = glp_fstart(b + 1, F, p.nblk) - f0;
+  // this workgroup's frames: an even split of one utterance, or its row of the segment table (batch)
+  int F = g.F, f0 = glp_fstart(b, g.F, p.nblk), nb_own = glp_fstart(b + 1, g.F, p.nblk) - f0, fbase = 0, abase = 0;
+  bool seg_first = b == 0, seg_last = b + 1 == p.nblk;
+  if (p.segs) {
+    const GlSeg sg = p.segs[b];
+    F = sg.F;
+    f0 = sg.f0;
+    nb_own = sg.n_own;
+    fbase = sg.fbase;
+    abase = sg.abase;
+    seg_first = sg.first != 0;
+    seg_last = sg.last != 0;
+  }
+  const int N = HOP * (F - 1);
   const int range = (nb_own + 3) * HOP, Q0 = f0 * HOP;
   float *sS = smem;                                             // [TF][516]  magnitudes
   float2 *sA = reinterpret_cast<float2 *>(sS + TF * 516);       // [TF][513]  S * (unit-modulus phase estimate): the spectrum the next ISTFT inverts
@@ -497,8 +509,8 @@ __global__ __launch_bounds__(64 * W) void k_gl_persistent(GlBufs g, GlPersist p,
   }
   // ---- state of this block's frames into LDS ----
   if (own) {
-    const float *S = g.S + (size_t)f * g.nb;
-    const float2 *A = ang_in + (size_t)f * g.nb, *P = tprev_in + (size_t)f * g.nb;
+    const float *S = g.S + (size_t)(fbase + f) * g.nb;
+    const float2 *A = ang_in + (size_t)(fbase + f) * g.nb, *P = tprev_in + (size_t)(fbase + f) * g.nb;
     for (int k = lane; k < 513; k += 64) {
       const float sk = S[k];
       const float2 ak = A[k];
@@ -520,8 +532,8 @@ __global__ __launch_bounds__(64 * W) void k_gl_persistent(GlBufs g, GlPersist p,
   }
   __syncthreads();
 
-  u64 *inL = p.xch + (size_t)b * 4 * GLP_HALO, *outL = b > 0 ? p.xch + ((size_t)(b - 1) * 4 + 1) * GLP_HALO : nullptr;
-  u64 *outR = b + 1 < p.nblk ? p.xch + (size_t)(b + 1) * 4 * GLP_HALO : nullptr;
+  u64 *inL = p.xch + (size_t)b * 4 * GLP_HALO, *outL = !seg_first ? p.xch + ((size_t)(b - 1) * 4 + 1) * GLP_HALO : nullptr;
+  u64 *outR = !seg_last ? p.xch + (size_t)(b + 1) * 4 * GLP_HALO : nullptr;
   // slot layout per block: [parity][side: 0 = from the left neighbour, 1 = from the right neighbour][768]
   float2 *buf = reinterpret_cast<float2 *>(fb + wave * FBS);
 
@@ -562,7 +574,7 @@ __global__ __launch_bounds__(64 * W) void k_gl_persistent(GlBufs g, GlPersist p,
     // granules travel while the own range is summed: the first 768 samples of the range get own frames
     // 0..2, the last 768 own frames n-3..n-1 (ascending; bitwise the same sums as B1 forms below) ----
     {
-      const bool has_l = b > 0, has_r = outR != nullptr;
+      const bool has_l = !seg_first, has_r = outR != nullptr;
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
         const int k = tid + u * nthr;
@@ -615,7 +627,7 @@ __global__ __launch_bounds__(64 * W) void k_gl_persistent(GlBufs g, GlPersist p,
       constexpr int U = 3;  // ceil(768 / threads) for 256..512 threads
       float pl[U], pr[U], hl[U], hr[U];
       bool dl[U], dr[U];
-      const bool has_l = b > 0, has_r = outR != nullptr;
+      const bool has_l = !seg_first, has_r = outR != nullptr;
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int k = tid + u * nthr;
@@ -678,10 +690,10 @@ __global__ __launch_bounds__(64 * W) void k_gl_persistent(GlBufs g, GlPersist p,
     if (it == n_iter) {
       // ---- final ISTFT: the block's share of the centre-trimmed signal ----
       if (audio) {
-        const int lo = b == 0 ? 0 : 384, hi = b + 1 == p.nblk ? range : 384 + HOP * nb_own;
+        const int lo = seg_first ? 0 : 384, hi = seg_last ? range : 384 + HOP * nb_own;
         for (int j = lo + tid; j < hi; j += nthr) {
           const int n = Q0 + j - NFFT / 2;
-          if (n >= 0 && n < N) audio[n] = yb[j];
+          if (n >= 0 && n < N) audio[abase + n] = yb[j];
         }
       }
       break;
@@ -724,7 +736,7 @@ __global__ __launch_bounds__(64 * W) void k_gl_persistent(GlBufs g, GlPersist p,
       // round trips per iteration.
       float2 *X = sA + wave * 513, *P = sP + wave * 513;
       const float *S = sS + wave * 516;
-      float2 *ang_g = (p.ang_out && it == n_iter - 1) ? p.ang_out + (size_t)f * g.nb : nullptr;  // parity hook
+      float2 *ang_g = (p.ang_out && it == n_iter - 1) ? p.ang_out + (size_t)(fbase + f) * g.nb : nullptr;  // parity hook
       float2 zk[4], zc[4], pv[9];
       float sk[9];
 #pragma unroll
@@ -783,7 +795,7 @@ __global__ __launch_bounds__(64 * W) void k_gl_persistent(GlBufs g, GlPersist p,
 #endif
   // ---- state write-back (parity hook only; the angles were stored by the last update) ----
   if (p.tprev_out && own) {
-    float2 *P = p.tprev_out + (size_t)f * g.nb;
+    float2 *P = p.tprev_out + (size_t)(fbase + f) * g.nb;
     for (int k = lane; k < 513; k += 64) P[k] = sP[wave * 513 + k];
   }
 }
@@ -811,6 +823,18 @@ __global__ void k_phase_init(GlBufs g, uint32_t seed, const float *phase0) {
     a = make_float2(cs, sn);
   }
   g.ang[i] = a;
+  g.tprev[i] = make_float2(0.f, 0.f);
+}
+
+// batch form of k_phase_init: rows of several utterances; the seeded stream is indexed inside each utterance
+__global__ void k_phase_init_batch(GlBufs g, uint32_t seed, const int *__restrict__ frame_local) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= g.F * g.nb) return;
+  const int f = i / g.nb, k = i % g.nb;
+  const float u = rng_uniform(seed, 0x47u, (uint32_t)(frame_local[f] * g.nb + k));
+  float sn, cs;
+  sincospif(2.0f * u, &sn, &cs);
+  g.ang[i] = make_float2(cs, sn);
   g.tprev[i] = make_float2(0.f, 0.f);
 }
 
@@ -892,6 +916,12 @@ void launch_gl_peak_normalise(float *y, int n, float *scratch, hipStream_t s) {
 void launch_gl_phase_init(const GlBufs &g, uint32_t seed, const float *phase0_dev, hipStream_t s) {
   const int n = g.F * g.nb;
   hipLaunchKernelGGL(k_phase_init, dim3((n + 255) / 256), dim3(256), 0, s, g, seed, phase0_dev);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_gl_phase_init_batch(const GlBufs &g, uint32_t seed, const int *frame_local, hipStream_t s) {
+  const int n = g.F * g.nb;
+  hipLaunchKernelGGL(k_phase_init_batch, dim3((n + 255) / 256), dim3(256), 0, s, g, seed, frame_local);
   HIP_CHECK(hipGetLastError());
 }
 

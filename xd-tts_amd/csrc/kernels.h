@@ -135,7 +135,21 @@ struct GlBufs {
 // launch, one workgroup per CU owning 3..TF consecutive frames, state in LDS, 768-sample overlaps
 // exchanged with the two neighbours as tagged 8-byte granules.
 constexpr int GLP_TF_MAX = 8;  // frames per workgroup (LDS: 10.3 KB of state + 4 KB of frame each; 8 waves = 2 per SIMD)
+// One workgroup's share when a launch covers SEVERAL utterances (vocoder batch): the utterances' frames
+// are concatenated in S / angles / previous spectrum, workgroups never span two utterances and exchange
+// overlaps only inside their own.
+struct GlSeg {
+  int fbase;   // row of the utterance's first frame in the concatenated arrays
+  int F;       // frames of the utterance
+  int f0;      // first own frame, within the utterance
+  int n_own;   // own frames (3..TF)
+  int first;   // no left neighbour
+  int last;    // no right neighbour
+  int abase;   // offset of the utterance's samples in the audio output
+  int pad;
+};
 struct GlPersist {
+  const GlSeg *segs;        // [nblk] or null = one utterance of g.F frames split evenly over the workgroups
   unsigned long long *xch;  // [nblk][2 parities][2 sides][768] granules
   int *err;                 // set when a bounded spin ran out
   unsigned epoch;           // tag base of this call (tags = epoch + iteration + 1; never reused within the buffer's life)
@@ -156,6 +170,8 @@ void launch_gl_pow_rows(const float *in, int ld, float *out, int nb, int F, floa
 // y *= 1 / max|y| (peak normalisation option); scratch = one float of device memory
 void launch_gl_peak_normalise(float *y, int n, float *scratch, hipStream_t s);
 void launch_gl_phase_init(const GlBufs &g, uint32_t seed, const float *phase0_dev, hipStream_t s);
+// batch form: g.F = total frames of the concatenated utterances; frame_local[f] = index of row f inside its utterance
+void launch_gl_phase_init_batch(const GlBufs &g, uint32_t seed, const int *frame_local, hipStream_t s);
 void launch_gl_prepare(const GlBufs &g, hipStream_t s);                  // wss_inv for this F
 void launch_gl_iterations(const GlBufs &g, int n_iter, float alpha, float *audio, hipStream_t s);  // + final ISTFT
 const float2 *launch_gl_iterate(const GlBufs &g, int n_iter, float alpha, hipStream_t s);         // iterations only

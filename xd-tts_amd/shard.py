@@ -64,10 +64,14 @@ def run_share(model, vocoder, share, chunks, steps, owner, opts):
     timings = model.last_timings()
     t1 = time.perf_counter()
     samples, audio = 0, {}
-    for u in share:
-        m = np.concatenate([mels[i] for i in range(len(chunks)) if owner[i] == u], axis=1)
-        audio[u] = vocoder.infer(m)
-        samples += audio[u].size
+    umels = [np.concatenate([mels[i] for i in range(len(chunks)) if owner[i] == u], axis=1) for u in share]
+    if hasattr(vocoder, "infer_batch"):   # utterances share the vocoder's persistent launches
+        outs = vocoder.infer_batch(umels)
+    else:
+        outs = [vocoder.infer(m) for m in umels]
+    for u, a in zip(share, outs):
+        audio[u] = a
+        samples += a.size
     t2 = time.perf_counter()
     return {"frames": int(sum(m.shape[1] for m in mels)), "samples": int(samples), "seconds": t2 - t0, "mel_gen_seconds": t1 - t0,
             "vocoder_seconds": t2 - t1, "timings": timings, "mels": mels, "audio": audio}
