@@ -126,12 +126,22 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    # developer aids for exercising the N > 1 control flow on a 1-GPU box: XDTTS_BENCH_DEVICE pins every rank to
+    # one device, XDTTS_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one GPU)
+    dev_override = os.environ.get("XDTTS_BENCH_DEVICE")
+    if dev_override is not None:
+        local_rank = int(dev_override)
+    backend = os.environ.get("XDTTS_BENCH_BACKEND", "nccl")
+    red_dev = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(local_rank)
 
@@ -153,7 +163,7 @@ def main():
     def max_over_ranks(x):
         if dist is None:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        t = torch.tensor([x], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -262,7 +272,7 @@ def main():
         barrier()
         log("config3/4 share done")
         fr, t_mel, tm, voc_ms = res["frames"], res["mel_gen_seconds"], res["timings"], res["vocoder_seconds"] * 1e3
-        totals, max_s, per_rank = shard.gather_counters(res, dist, device="cuda" if dist else "cpu")
+        totals, max_s, per_rank = shard.gather_counters(res, dist, device=red_dev if dist else "cpu")
         it = tm["steps"]
         act = float(sum(steps))                                                    # active chunk-steps of this rank
         dsec = tm["decoder_ms"] * 1e-3
