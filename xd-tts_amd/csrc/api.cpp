@@ -870,7 +870,7 @@ struct xdtts_griffinlim {
   // launch; the caller holds the chip lock until the stream has drained and then asks
   // persistent_failed().
   const float2 *run_iterations(const GlBufs &g, int n_iter, float alpha, float *audio_out, bool want_state = false,
-                               const float2 **tprev_fin = nullptr) {
+                               const float2 **tprev_fin = nullptr, bool gen_phase = false) {
     int TF = 0, nblk = 0;
     last_persistent = false;
     if (tprev_fin) *tprev_fin = g.tprev;
@@ -893,6 +893,8 @@ struct xdtts_griffinlim {
       p.nblk = nblk;
       p.TF = TF;
       if (const char *sp = getenv("XDTTS_GL_SPINS")) p.spins = atoi(sp);  // test hook
+      p.gen_phase = gen_phase ? 1 : 0;
+      p.seed = seed;
       epoch += (unsigned)n_iter + 2u;
       if (want_state) {
         p.ang_out = g.ang2;
@@ -949,14 +951,17 @@ struct xdtts_griffinlim {
 
   // phase init + iterations + final ISTFT; S already in place.  Result in audio (device).
   void iterate(const GlBufs &g, const float *phase0_dev, int n_iter) {
-    launch_gl_phase_init(g, seed, phase0_dev, stream);
-    launch_gl_prepare(g, stream);
     const float alpha = momentum / (1.0f + momentum);
     int TF = 0, nblk = 0;
     if (persistent_usable() && gl_persistent_plan(g.F, n_cu, &TF, &nblk)) {
-      run_iterations(g, n_iter, alpha, audio.p);  // one launch: nothing to capture
+      // one launch: nothing to capture; with the seeded stream the kernel draws the phase itself (no
+      // phase-init launch, no window-sum table: the kernel keeps its own)
+      if (phase0_dev) launch_gl_phase_init(g, seed, phase0_dev, stream);
+      run_iterations(g, n_iter, alpha, audio.p, false, nullptr, phase0_dev == nullptr);
       return;
     }
+    launch_gl_phase_init(g, seed, phase0_dev, stream);
+    launch_gl_prepare(g, stream);
     last_persistent = false;
     // the launch-per-iteration loop is launch-bound: replay it as one hipGraph
     if (!graph || std::memcmp(&graph_key, &g, sizeof g) != 0 || graph_iters != n_iter || graph_alpha != alpha ||

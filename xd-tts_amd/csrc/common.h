@@ -63,14 +63,20 @@ void set_last_error(const char *msg);
 // coop-launch); XDTTS_COOP=0 switches back to plain launches (residency is identical, only the check
 // is lost).  Every spin stays bounded either way: a grid kept off the chip by ANOTHER process is
 // caught by the timeout path, not by this check.
+// `coop_default` = what the call site does when XDTTS_COOP is unset: the decoder and the encoder BiLSTM
+// launch cooperatively (their launches last milliseconds); the persistent Griffin-Lim does not -- the
+// cooperative launch measured +17 us on a 200-350 us vocoder call (5 %), its grid is checked against the
+// occupancy query when the handle is created, and a grid that still is not resident is caught by the
+// bounded spins like everywhere else.  XDTTS_COOP=1 / 0 forces either form for all three.
 template <class... Args>
-inline hipError_t launch_coresident(const void *fn, dim3 grid, dim3 block, size_t lds, hipStream_t s, Args... args) {
+inline hipError_t launch_coresident(bool coop_default, const void *fn, dim3 grid, dim3 block, size_t lds, hipStream_t s, Args... args) {
   void *argv[] = {(void *)&args...};
-  static const bool plain = [] {
+  static const int forced = [] {
     const char *e = getenv("XDTTS_COOP");
-    return e && e[0] == '0';
+    return !e ? -1 : (e[0] == '0' ? 0 : 1);
   }();
-  return plain ? hipLaunchKernel(fn, grid, block, argv, lds, s) : hipLaunchCooperativeKernel(fn, grid, block, argv, (unsigned)lds, s);
+  const bool coop = forced < 0 ? coop_default : forced == 1;
+  return coop ? hipLaunchCooperativeKernel(fn, grid, block, argv, (unsigned)lds, s) : hipLaunchKernel(fn, grid, block, argv, lds, s);
 }
 
 // ---- counter-based RNG (specification shared with oracle/, implemented independently) ----

@@ -723,7 +723,7 @@ __global__ void k_persist_seed(PersistBufs g, const int *limits, int B) {
 
 template <int PB>
 void launch_pb(const DecoderBufs &d, const PersistBufs &g, const PersistWeights &pw, int nsteps, hipStream_t s) {
-  HIP_CHECK(launch_coresident(reinterpret_cast<const void *>(k_decoder_persistent<PB>), dim3(P_NCU), dim3(PT), 0, s, d, g, pw, nsteps));
+  HIP_CHECK(launch_coresident(true, reinterpret_cast<const void *>(k_decoder_persistent<PB>), dim3(P_NCU), dim3(PT), 0, s, d, g, pw, nsteps));
 }
 
 }  // namespace

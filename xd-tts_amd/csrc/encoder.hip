@@ -103,7 +103,7 @@ void launch_bilstm_coop(const float *xproj, const float *whhT_fwd, const float *
                         unsigned long long *exchange, int *err, int B, int T, hipStream_t s) {
   // tags must start at 0 for every call
   HIP_CHECK(hipMemsetAsync(exchange, 0, bilstm_coop_exchange_words(B) * sizeof(unsigned long long), s));
-  HIP_CHECK(launch_coresident(reinterpret_cast<const void *>(k_bilstm_coop), dim3(CO_BLOCKS, 2, B), dim3(1024), 0, s, xproj, whhT_fwd,
+  HIP_CHECK(launch_coresident(true, reinterpret_cast<const void *>(k_bilstm_coop), dim3(CO_BLOCKS, 2, B), dim3(1024), 0, s, xproj, whhT_fwd,
                               whhT_bwd, memory, exchange, err, B, T));
 }
 

@@ -507,16 +507,46 @@ __global__ __launch_bounds__(64 * W) void k_gl_persistent(GlBufs g, GlPersist p,
     twk[r] = g.tw[lane + 64 * r];
     wn[r] = reinterpret_cast<const float2 *>(g.win)[lane + 64 * r];
   }
+  // W == 4 (one wave per SIMD, the whole register file): the previous spectrum and the magnitudes of the
+  // nine bins a lane updates (pairs k / 512-k for k = lane + 64 r, and k = 256 on lane 0) stay in REGISTERS
+  // for the whole call -- 27 LDS accesses less per iteration in the phase-update chain.
+  constexpr bool REGSTATE = W == 4;
+  float2 rP[9];
+  float rS[9];
+  if (REGSTATE && own) {
+    const float *S = g.S + (size_t)(fbase + f) * g.nb;
+    const float2 *P = tprev_in + (size_t)(fbase + f) * g.nb;
+    const float2 zero2 = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = lane + 64 * r;
+      rP[2 * r] = p.gen_phase ? zero2 : P[k];
+      rP[2 * r + 1] = p.gen_phase ? zero2 : P[512 - k];
+      rS[2 * r] = S[k];
+      rS[2 * r + 1] = S[512 - k];
+    }
+    rP[8] = p.gen_phase ? zero2 : P[256];
+    rS[8] = S[256];
+  }
   // ---- state of this block's frames into LDS ----
   if (own) {
     const float *S = g.S + (size_t)(fbase + f) * g.nb;
     const float2 *A = ang_in + (size_t)(fbase + f) * g.nb, *P = tprev_in + (size_t)(fbase + f) * g.nb;
     for (int k = lane; k < 513; k += 64) {
       const float sk = S[k];
-      const float2 ak = A[k];
+      float2 ak, pk = make_float2(0.f, 0.f);
+      if (p.gen_phase) {  // the seeded stream of k_phase_init: u keyed (seed, frame * 513 + bin), frame inside the utterance
+        const float u = rng_uniform(p.seed, 0x47u, (uint32_t)(f * g.nb + k));
+        float sn, cs;
+        sincospif(2.0f * u, &sn, &cs);
+        ak = make_float2(cs, sn);
+      } else {
+        ak = A[k];
+        pk = P[k];
+      }
       sS[wave * 516 + k] = sk;
       sA[wave * 513 + k] = make_float2(ak.x * sk, ak.y * sk);
-      sP[wave * 513 + k] = P[k];
+      sP[wave * 513 + k] = pk;
     }
   }
   for (int j = tid; j < range; j += nthr) {
@@ -581,16 +611,16 @@ __global__ __launch_bounds__(64 * W) void k_gl_persistent(GlBufs g, GlPersist p,
         if (k < GLP_HALO) {
           if (has_l) {
             float v = fb[k];
-            if (k >= HOP) v += fb[FBS + k - HOP];
-            if (k >= 2 * HOP) v += fb[2 * FBS + k - 2 * HOP];
+            if (W == 4 ? u >= 1 : k >= HOP) v += fb[FBS + k - HOP];           // W == 4: 256 threads, u = the 256-sample third
+            if (W == 4 ? u >= 2 : k >= 2 * HOP) v += fb[2 * FBS + k - 2 * HOP];
             __hip_atomic_store(outL + (size_t)par * 2 * GLP_HALO + k, ((u64)want << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
           }
           if (has_r) {
             const float l1 = fb[(nb_own - 1) * FBS + HOP + k];
             float v = l1;
-            if (k < HOP) v = (fb[(nb_own - 3) * FBS + 3 * HOP + k] + fb[(nb_own - 2) * FBS + 2 * HOP + k]) + l1;
-            else if (k < 2 * HOP) v = fb[(nb_own - 2) * FBS + 2 * HOP + k] + l1;
+            if (W == 4 ? u == 0 : k < HOP) v = (fb[(nb_own - 3) * FBS + 3 * HOP + k] + fb[(nb_own - 2) * FBS + 2 * HOP + k]) + l1;
+            else if (W == 4 ? u == 1 : k < 2 * HOP) v = fb[(nb_own - 2) * FBS + 2 * HOP + k] + l1;
             __hip_atomic_store(outR + (size_t)par * 2 * GLP_HALO + k, ((u64)want << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
           }
@@ -744,14 +774,14 @@ __global__ __launch_bounds__(64 * W) void k_gl_persistent(GlBufs g, GlPersist p,
         const int k = lane + 64 * r;
         zk[r] = buf[k];
         zc[r] = buf[(512 - k) & 511];
-        pv[2 * r] = P[k];
-        pv[2 * r + 1] = P[512 - k];
-        sk[2 * r] = S[k];
-        sk[2 * r + 1] = S[512 - k];
+        pv[2 * r] = REGSTATE ? rP[2 * r] : P[k];
+        pv[2 * r + 1] = REGSTATE ? rP[2 * r + 1] : P[512 - k];
+        sk[2 * r] = REGSTATE ? rS[2 * r] : S[k];
+        sk[2 * r + 1] = REGSTATE ? rS[2 * r + 1] : S[512 - k];
       }
       const float2 z256 = buf[256];
-      pv[8] = P[256];
-      sk[8] = S[256];
+      pv[8] = REGSTATE ? rP[8] : P[256];
+      sk[8] = REGSTATE ? rS[8] : S[256];
       float2 xs[9], xo[9];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -775,14 +805,20 @@ __global__ __launch_bounds__(64 * W) void k_gl_persistent(GlBufs g, GlPersist p,
           ang_g[k] = xo[2 * r];
           ang_g[512 - k] = xo[2 * r + 1];
         }
-        P[k] = xs[2 * r];
-        P[512 - k] = xs[2 * r + 1];
+        if (REGSTATE) {
+          rP[2 * r] = xs[2 * r];
+          rP[2 * r + 1] = xs[2 * r + 1];
+        } else {
+          P[k] = xs[2 * r];
+          P[512 - k] = xs[2 * r + 1];
+        }
         X[k] = make_float2(xo[2 * r].x * sk[2 * r], xo[2 * r].y * sk[2 * r]);
         X[512 - k] = make_float2(xo[2 * r + 1].x * sk[2 * r + 1], xo[2 * r + 1].y * sk[2 * r + 1]);
       }
+      if (REGSTATE) rP[8] = xs[8];
       if (lane == 0) {
         if (ang_g) ang_g[256] = xo[8];
-        P[256] = xs[8];
+        if (!REGSTATE) P[256] = xs[8];
         X[256] = make_float2(xo[8].x * sk[8], xo[8].y * sk[8]);
       }
       wave_lds_sync();
@@ -796,7 +832,16 @@ __global__ __launch_bounds__(64 * W) void k_gl_persistent(GlBufs g, GlPersist p,
   // ---- state write-back (parity hook only; the angles were stored by the last update) ----
   if (p.tprev_out && own) {
     float2 *P = p.tprev_out + (size_t)(fbase + f) * g.nb;
-    for (int k = lane; k < 513; k += 64) P[k] = sP[wave * 513 + k];
+    if (REGSTATE) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        P[lane + 64 * r] = rP[2 * r];
+        P[512 - (lane + 64 * r)] = rP[2 * r + 1];
+      }
+      if (lane == 0) P[256] = rP[8];
+    } else {
+      for (int k = lane; k < 513; k += 64) P[k] = sP[wave * 513 + k];
+    }
   }
 }
 
@@ -980,7 +1025,7 @@ bool gl_persistent_supported(int device, int *n_cu) {
 void launch_gl_persistent(const GlBufs &g, const GlPersist &p, const float2 *ang_in, const float2 *tprev_in, int n_iter,
                           float alpha, float *audio, hipStream_t s) {
   const void *fn = p.TF <= 4 ? reinterpret_cast<const void *>(k_gl_persistent<4>) : reinterpret_cast<const void *>(k_gl_persistent<8>);
-  HIP_CHECK(launch_coresident(fn, dim3(p.nblk), dim3(64 * p.TF), gl_persistent_lds_bytes(p.TF), s, g, p, ang_in, tprev_in, n_iter, alpha,
+  HIP_CHECK(launch_coresident(false, fn, dim3(p.nblk), dim3(64 * p.TF), gl_persistent_lds_bytes(p.TF), s, g, p, ang_in, tprev_in, n_iter, alpha,
                               audio));
 }
 

@@ -155,6 +155,8 @@ struct GlPersist {
   unsigned epoch;           // tag base of this call (tags = epoch + iteration + 1; never reused within the buffer's life)
   int nblk, TF;
   int spins;                // test hook: poll limit (0 = default)
+  int gen_phase;            // 1: the kernel draws the seeded initial phase itself (angles = exp(2 pi i u), previous spectrum 0)
+  unsigned seed;            //    instead of reading ang_in / tprev_in (saves the phase-init launch and a round trip through HBM)
   float2 *ang_out, *tprev_out;  // parity hook: final state, or null
   unsigned long long *prof;     // developer profile build only: [nblk][12] phase clocks, else null
 };
