@@ -6,6 +6,7 @@
 R=${1:-02}; HEAD=${2:-unknown}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/r$R; mkdir -p $OUT
+make -C xd-tts_amd prof -j16 > $OUT/make_prof.log 2>&1
 CMD="python bench.py --steps 3 --warmup 1 --no-cpu-baseline"
 rm -rf /tmp/prof_k /tmp/prof_f /tmp/prof_w
 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_k -o k -- $CMD > $OUT/prof_kernel.log 2>&1
