@@ -182,4 +182,9 @@ def test_vocoder_batch_equals_one_by_one(pkg):
     many = [mels[0]] * 40 + [mels[3]] * 5
     outs = v.infer_batch(many)
     assert all(np.array_equal(o, one[0]) for o in outs[:40]) and all(np.array_equal(o, one[3]) for o in outs[40:])
+    # options apply per utterance in a batch too
+    v.set_opts(peak_normalise=1, nnls_iters=3)
+    single = [v.infer(m) for m in mels[:4]]
+    for a, b in zip(v.infer_batch(mels[:4]), single):
+        assert np.array_equal(a, b) and abs(float(np.abs(a).max()) - 1.0) <= 1e-6
     v.close()

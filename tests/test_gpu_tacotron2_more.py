@@ -248,3 +248,16 @@ def test_onnx_export_converts_and_loads(pkg, model, blob, tmp_path):
     got = m.infer(ids, opts=o)
     m.close()
     assert np.array_equal(got, want)
+
+
+def test_batched_path_with_a_smaller_window(pkg, model, orc, blob):
+    """The batched MFMA path (>= 5 chunks) with max_chunk = 50: encoder window, mask, location tiles and the
+    operand-order activation copies all follow T; every chunk still equals its own oracle run."""
+    lens = [50, 7, 33, 48, 21, 50, 12]
+    ids_list = [synth_ids(n, seed=90 + i) for i, n in enumerate(lens)]
+    steps = [18, 5, 11, 20, 9, 14, 16]
+    o = pkg.default_opts(dropout_seed=23, item_base=2, max_chunk=50)
+    mels = model.infer_batch(ids_list, opts=o, fixed_steps=steps)
+    for b, (ids, st) in enumerate(zip(ids_list, steps)):
+        ref = orc.infer_chunk(blob, ids, orc.default_opts(fixed_steps=st, dropout_seed=23, item=2 + b), window=50)
+        assert mels[b].shape == (80, st) and rms(mels[b], ref) <= 1e-5, b
