@@ -171,7 +171,8 @@ struct xdtts_tacotron2 {
   int persist_state = -1;                   // -1 unknown, 0 unavailable on this device / demoted, 1 usable
   bool persist_probe_ok = false;            // the device can host the persistent grid (occupancy probe)
   bool coop_ok = true;                      // cooperative encoder BiLSTM usable (cleared after a timed-out exchange)
-  static constexpr int COOP_MAX_B = 16;  // 8*B blocks of 1024 threads must be co-resident
+  int coop_group = 16;                      // chunks per cooperative BiLSTM launch: 8 workgroups of 1024 threads per
+                                            // chunk must be co-resident, one per CU (set from the CU count in init)
   DevBuf<float> att_h, att_c, dec_h, dec_c, aw, awc, ctx, x, loc, e_part, pmel, frames, gates;
   DevBuf<float> frag;       // batched mode: MFMA-operand copies of x, ctx, att_h[2], dec_h[2]
   DevBuf<int> item_perm;    // batched mode: dropout-stream index of the (length-sorted) chunks
@@ -198,6 +199,9 @@ struct xdtts_tacotron2 {
     HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     ev.create();
     HIP_CHECK(hipHostMalloc((void **)&host_ctl, sizeof(int) * (2 + 4096), hipHostMallocDefault));
+    int cus = 0;
+    HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    coop_group = cus / 8 < 1 ? 1 : cus / 8;
     enc_err.alloc(1);
     HIP_CHECK(hipMemsetAsync(enc_err.p, 0, sizeof(int), stream));
     dec_err.alloc(1);
@@ -252,9 +256,12 @@ struct xdtts_tacotron2 {
       g.batch = B;
       launch_gemm_nt(g, stream);
     }
-    if (B <= COOP_MAX_B && coop_ok) {
-      enc_exchange.alloc(bilstm_coop_exchange_words(B));
-      launch_bilstm_coop(xproj.p, w.enc_whhT[0].p, w.enc_whhT[1].p, memory.p, enc_exchange.p, enc_err.p, B, T, stream);
+    if (coop_ok) {
+      // equal groups of at most coop_group chunks (52 chunks on 256 CUs: 26 + 26)
+      const int launches = (B + coop_group - 1) / coop_group, group = (B + launches - 1) / launches;
+      enc_exchange.alloc(bilstm_coop_exchange_words(group));
+      launch_bilstm_coop(xproj.p, w.enc_whhT[0].p, w.enc_whhT[1].p, memory.p, enc_exchange.p, enc_err.p, B, T, group,
+                         stream);
     } else {
       launch_bilstm(xproj.p, w.enc_whhT[0].p, w.enc_whhT[1].p, memory.p, B, T, stream);
     }

@@ -29,7 +29,8 @@ constexpr unsigned SPIN_LIMIT = 1u << 22;
 __global__ __launch_bounds__(1024) void k_bilstm_coop(const float *__restrict__ xproj,
                                                       const float *__restrict__ whhT_f,
                                                       const float *__restrict__ whhT_b, float *memory, u64 *exchange,
-                                                      int *err, int B, int T) {
+                                                      int *err, int B, int T, int b0, int Btot) {
+  // this launch runs chunks b0 .. b0+B-1 of a batch of Btot (xproj is [2][Btot][T][4H], memory [Btot][T][EMB])
   const int k = blockIdx.x, dir = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
   const int rl = tid & 255, q = tid >> 8;     // local gate row, column quarter
   const int g = rl >> 6, ul = rl & 63;
@@ -40,7 +41,7 @@ __global__ __launch_bounds__(1024) void k_bilstm_coop(const float *__restrict__ 
   for (int j = 0; j < 64; ++j) w[j] = whhT[(size_t)(64 * q + j) * (4 * ENC_H) + row];
   __shared__ float h[ENC_H], part[4][256], gl[256];
   __shared__ int dead;
-  const float *xp = xproj + ((size_t)dir * B + b) * T * (4 * ENC_H);
+  const float *xp = xproj + ((size_t)dir * Btot + b0 + b) * T * (4 * ENC_H);
   gu64 *ex = (gu64 *)(exchange + ((size_t)dir * B + b) * 2 * ENC_H);
   float c = 0.f;
   if (tid < ENC_H) h[tid] = 0.f;
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(1024) void k_bilstm_coop(const float *__restrict__ 
       const float hn = og * tanhf(c);
       const int u = CO_UNITS * k + tid;
       h[u] = hn;
-      memory[((size_t)b * T + t) * EMB + dir * ENC_H + u] = hn;
+      memory[((size_t)(b0 + b) * T + t) * EMB + dir * ENC_H + u] = hn;
       if (s + 1 < T)  // publish: tag = step + 1 (never 0), one naturally aligned 8-byte store
         __hip_atomic_store(ex + (s & 1) * ENC_H + u, ((u64)(unsigned)(s + 1) << 32) | (u64)__float_as_uint(hn),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -100,11 +101,16 @@ __global__ __launch_bounds__(1024) void k_bilstm_coop(const float *__restrict__ 
 size_t bilstm_coop_exchange_words(int B) { return (size_t)2 * B * 2 * ENC_H; }
 
 void launch_bilstm_coop(const float *xproj, const float *whhT_fwd, const float *whhT_bwd, float *memory,
-                        unsigned long long *exchange, int *err, int B, int T, hipStream_t s) {
-  // tags must start at 0 for every call
-  HIP_CHECK(hipMemsetAsync(exchange, 0, bilstm_coop_exchange_words(B) * sizeof(unsigned long long), s));
-  HIP_CHECK(launch_coresident(true, reinterpret_cast<const void *>(k_bilstm_coop), dim3(CO_BLOCKS, 2, B), dim3(1024), 0, s, xproj, whhT_fwd,
-                              whhT_bwd, memory, exchange, err, B, T));
+                        unsigned long long *exchange, int *err, int B, int T, int group, hipStream_t s) {
+  // 8 workgroups per chunk must be co-resident, so a large batch runs as launches of at most
+  // `group` chunks each (sized to the CU count by the caller); the exchange buffer is reused
+  for (int b0 = 0; b0 < B; b0 += group) {
+    const int n = B - b0 < group ? B - b0 : group;
+    // tags must start at 0 for every launch
+    HIP_CHECK(hipMemsetAsync(exchange, 0, bilstm_coop_exchange_words(n) * sizeof(unsigned long long), s));
+    HIP_CHECK(launch_coresident(true, reinterpret_cast<const void *>(k_bilstm_coop), dim3(CO_BLOCKS, 2, n), dim3(1024), 0, s, xproj,
+                                whhT_fwd, whhT_bwd, memory, exchange, err, n, T, b0, B));
+  }
 }
 
 }  // namespace xdtts

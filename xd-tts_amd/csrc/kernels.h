@@ -118,7 +118,7 @@ void launch_bilstm(const float *xproj, const float *whhT_fwd, const float *whhT_
 // tagged-granule exchange of the hidden state (encoder.hip).  Needs all 8*B blocks co-resident.
 size_t bilstm_coop_exchange_words(int B);
 void launch_bilstm_coop(const float *xproj, const float *whhT_fwd, const float *whhT_bwd, float *memory,
-                        unsigned long long *exchange, int *err, int B, int T, hipStream_t s);
+                        unsigned long long *exchange, int *err, int B, int T, int group, hipStream_t s);
 
 // ---- Griffin-Lim -------------------------------------------------------------------------------
 struct GlBufs {
