@@ -775,6 +775,9 @@ __global__ __launch_bounds__(256) void k_softmax_ctx(DecoderBufs d, int i, const
 #pragma unroll
     for (int k = 0; k < ATT_DIM / 4; ++k) ev0[k] = ep[(size_t)k * T];
   }
+  // (the previous cumulative weights too: loaded where they are used, after the softmax's barriers, their
+  // latency is exposed)
+  const float awc_pre = tid < T ? awc_in[b * T + tid] : 0.f;
   const int step = d.ctl[0] + i;
   const bool act = step < d.nframes[b];
   asm volatile("" ::: "memory");
@@ -822,7 +825,7 @@ __global__ __launch_bounds__(256) void k_softmax_ctx(DecoderBufs d, int i, const
   }
   __syncthreads();
   for (int t = tid; t < T; t += 256) {
-    const float wv = s_e[t], cum = awc_in[b * T + t] + wv;
+    const float wv = s_e[t], cum = (t == tid ? awc_pre : awc_in[b * T + t]) + wv;
     s_awc[t] = cum;
     if (act && cblk == 0) {
       d.aw[b * T + t] = wv;
