@@ -552,9 +552,7 @@ struct xdtts_tacotron2 {
     HIP_CHECK(hipMemsetAsync(ppA.p, 0, slot * n * sizeof(float), stream));
     HIP_CHECK(hipMemsetAsync(ppB.p, 0, slot * n * sizeof(float), stream));
     // layer 0 input: the frames themselves, viewed as zero-padded [FP][80] buffers
-    for (int i = 0; i < n; ++i)
-      HIP_CHECK(hipMemcpyAsync(ppB.p + slot * i + (size_t)pad * N_MEL, frames_dev + frame_stride * i,
-                               (size_t)F[i] * N_MEL * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    launch_copy_rows(frames_dev, frame_stride, ppB.p + (size_t)pad * N_MEL, slot, F, n, N_MEL, stream);
     float *src = ppB.p, *dst = ppA.p;
     for (int i = 0; i < POST_CONVS; ++i) {
       const ConvGemm &c = w.post_conv[i];

@@ -8,10 +8,13 @@
 //     (lda = C instead of k*C) -- implicit GEMM with no im2col buffer;
 //   * BiLSTM input projections, the attention memory layer, and the Griffin-Lim mel->linear
 //     product (pinv(mel_basis) . exp(mel)).
-// Tile: 32x32 per 256-thread block (one 16x16 MFMA tile per wave), K-slab 32 through double-buffered
-// LDS, global loads four slabs ahead.  Within a slab the contraction
+// Tile: 32x32 or 64x64 per 256-thread block (one or 2x2 16x16 MFMA tiles per wave), K-slab 32 through
+// double-buffered LDS, global loads four slabs ahead.  Within a slab the contraction
 // index is permuted (k = 4*(lane>>4) + kk) so each lane fetches its four K values of a tile row
 // with one ds_read_b128.
+#include <algorithm>
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace xdtts {
@@ -20,17 +23,21 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// 32x32 output tile per 256-thread block: 2 x 2 waves, one 16x16 MFMA tile each -- measured the
-// fastest shape on this path (larger tiles: post-net 0.49 / 0.79 ms against 0.38 ms; 52-chunk
-// encoder 2.41 against 1.83 ms).  K-slab 32 through double-buffered LDS, one barrier per slab.
-// These GEMMs put only 1-2 blocks on a CU (M = 100..800 rows), a slab's eight MFMAs take ~0.1 us
-// and an L2 round trip ~0.7 us, so the global loads run FOUR slabs ahead in named registers (an
-// indexed ring was demoted to scratch by the compiler), unconditional and clamped into the operand
-// so nothing depends on their data until the slab is staged (the zero fill happens there).  Every
-// output element accumulates its K products in ascending order.
-constexpr int BM = 32, BN = 32, BK = 32, LDS_LD = 36;  // 144-byte rows: 16-B aligned float4 reads
+// Output tile per 256-thread block: 2 x 2 waves, each MT x NT MFMA tiles of 16x16.
+//   32x32 (MT = NT = 1): the single-utterance shapes (M = 100..800 rows put only 1-2 blocks on a CU) -- measured
+//     the fastest there (64x64: post-net 0.49 / 0.79 ms against 0.38 ms);
+//   64x64 (MT = NT = 2): batches whose grid fills the chip several times over (the 52-chunk post-net: M = 25 171
+//     rows in all): four times the MFMA work per staged slab and per barrier.
+// K-slab 32 through double-buffered LDS, one barrier per slab.  A slab's MFMAs take 0.1-0.4 us and an L2 round
+// trip ~0.7 us, so the global loads run FOUR slabs ahead in named registers (an indexed ring was demoted to
+// scratch by the compiler), unconditional and clamped into the operand so nothing depends on their data until
+// the slab is staged (the zero fill happens there).  Every output element accumulates its K products in
+// ascending order in both shapes, so they give identical results.
+constexpr int BK = 32, LDS_LD = 36;  // 144-byte rows: 16-B aligned float4 reads
 
+template <int BM, int BN>
 __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs g) {
+  constexpr int MT = BM / 32, NT = BN / 32;  // MFMA tiles per wave; also: float4 loads per thread and slab
   __shared__ __attribute__((aligned(16))) float As[2][BM * LDS_LD];
   __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDS_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -42,81 +49,114 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs g) {
   float *C = g.C + (size_t)z * g.strideC + (g.ragged ? g.Cz[z] : 0);
   const float *R = g.R ? g.R + (size_t)z * g.strideR : nullptr;
 
-  // global -> LDS assignment: thread loads one float4 of A and one of W per slab
+  // global -> LDS assignment: thread loads MT float4 of A and NT of W per slab (rows lr + 32 r)
   const int lr = tid >> 3, lc = (tid & 7) * 4;
-  const bool a_ok = m0 + lr < M, b_ok = n0 + lr < g.N;
-  const float *a_src = A + (size_t)(a_ok ? m0 + lr : M - 1) * g.lda + lc;
-  const float *b_src = g.W + (size_t)(b_ok ? n0 + lr : g.N - 1) * g.K + lc;
+  bool a_ok[MT], b_ok[NT];
+  const float *a_src[MT], *b_src[NT];
+#pragma unroll
+  for (int r = 0; r < MT; ++r) {
+    a_ok[r] = m0 + lr + 32 * r < M;
+    a_src[r] = A + (size_t)(a_ok[r] ? m0 + lr + 32 * r : M - 1) * g.lda + lc;
+  }
+#pragma unroll
+  for (int r = 0; r < NT; ++r) {
+    b_ok[r] = n0 + lr + 32 * r < g.N;
+    b_src[r] = g.W + (size_t)(b_ok[r] ? n0 + lr + 32 * r : g.N - 1) * g.K + lc;
+  }
   const int nslab = (g.K + BK - 1) / BK;
   const int fi = lane & 15, fg = lane >> 4;
-  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  struct Slab {
+    float4 a[MT], b[NT];
+  };
 
-#define GEMM_FETCH(SLAB, QA, QB)                                                            \
+#define GEMM_FETCH(SLAB, Q)                                                                 \
   do {                                                                                      \
     const int k0_ = ((SLAB) < nslab && (SLAB) * BK + lc < g.K) ? (SLAB) * BK : 0;           \
-    QA = *reinterpret_cast<const float4 *>(a_src + k0_);                                    \
-    QB = *reinterpret_cast<const float4 *>(b_src + k0_);                                    \
+    _Pragma("unroll") for (int r_ = 0; r_ < MT; ++r_) Q.a[r_] = *reinterpret_cast<const float4 *>(a_src[r_] + k0_); \
+    _Pragma("unroll") for (int r_ = 0; r_ < NT; ++r_) Q.b[r_] = *reinterpret_cast<const float4 *>(b_src[r_] + k0_); \
   } while (0)
-#define GEMM_STAGE(SLAB, QA, QB)                                                            \
+#define GEMM_STAGE(SLAB, Q)                                                                 \
   do {                                                                                      \
     const bool kok_ = (SLAB) * BK + lc < g.K; /* K is a multiple of 16, not always of 32 */ \
-    /* no `cond ? QA : zero4` on the vector class: it selects between ADDRESSES and sends the  \
+    /* no `cond ? Q : zero4` on the vector class: it selects between ADDRESSES and sends the  \
        prefetch registers to scratch */                                                      \
-    const float ma_ = (kok_ && a_ok) ? 1.f : 0.f, mb_ = (kok_ && b_ok) ? 1.f : 0.f;         \
-    *reinterpret_cast<float4 *>(&As[(SLAB) & 1][lr * LDS_LD + lc]) =                        \
-        make_float4(ma_ != 0.f ? QA.x : 0.f, ma_ != 0.f ? QA.y : 0.f, ma_ != 0.f ? QA.z : 0.f, ma_ != 0.f ? QA.w : 0.f); \
-    *reinterpret_cast<float4 *>(&Bs[(SLAB) & 1][lr * LDS_LD + lc]) =                        \
-        make_float4(mb_ != 0.f ? QB.x : 0.f, mb_ != 0.f ? QB.y : 0.f, mb_ != 0.f ? QB.z : 0.f, mb_ != 0.f ? QB.w : 0.f); \
+    _Pragma("unroll") for (int r_ = 0; r_ < MT; ++r_) {                                     \
+      const float ma_ = (kok_ && a_ok[r_]) ? 1.f : 0.f;                                     \
+      *reinterpret_cast<float4 *>(&As[(SLAB) & 1][(lr + 32 * r_) * LDS_LD + lc]) =         \
+          make_float4(ma_ != 0.f ? Q.a[r_].x : 0.f, ma_ != 0.f ? Q.a[r_].y : 0.f, ma_ != 0.f ? Q.a[r_].z : 0.f, ma_ != 0.f ? Q.a[r_].w : 0.f); \
+    }                                                                                       \
+    _Pragma("unroll") for (int r_ = 0; r_ < NT; ++r_) {                                     \
+      const float mb_ = (kok_ && b_ok[r_]) ? 1.f : 0.f;                                     \
+      *reinterpret_cast<float4 *>(&Bs[(SLAB) & 1][(lr + 32 * r_) * LDS_LD + lc]) =         \
+          make_float4(mb_ != 0.f ? Q.b[r_].x : 0.f, mb_ != 0.f ? Q.b[r_].y : 0.f, mb_ != 0.f ? Q.b[r_].z : 0.f, mb_ != 0.f ? Q.b[r_].w : 0.f); \
+    }                                                                                       \
   } while (0)
-#define GEMM_STEP(J, QA, QB, NA, NB)                                                        \
+#define GEMM_STEP(J, Q, NQ)                                                                 \
   if (s0 + (J) < nslab) {                                                                   \
-    GEMM_FETCH(s0 + (J) + 4, QA, QB); /* slot J was staged for this slab already: refill */ \
+    GEMM_FETCH(s0 + (J) + 4, Q); /* slot J was staged for this slab already: refill */      \
     __builtin_amdgcn_sched_barrier(0); /* or the scheduler sinks the loads to their use */  \
     _Pragma("unroll") for (int kg = 0; kg < BK / 16; ++kg) {                                \
-      const float4 af = *reinterpret_cast<const float4 *>(&As[(J) & 1][(wm * 16 + fi) * LDS_LD + kg * 16 + fg * 4]); \
-      const float4 bf = *reinterpret_cast<const float4 *>(&Bs[(J) & 1][(wn * 16 + fi) * LDS_LD + kg * 16 + fg * 4]); \
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bf.x, acc, 0, 0, 0);                 \
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bf.y, acc, 0, 0, 0);                 \
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bf.z, acc, 0, 0, 0);                 \
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bf.w, acc, 0, 0, 0);                 \
+      float4 af[MT], bf[NT];                                                                \
+      _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_)                                     \
+        af[i_] = *reinterpret_cast<const float4 *>(&As[(J) & 1][(wm * 16 * MT + 16 * i_ + fi) * LDS_LD + kg * 16 + fg * 4]); \
+      _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_)                                     \
+        bf[j_] = *reinterpret_cast<const float4 *>(&Bs[(J) & 1][(wn * 16 * NT + 16 * j_ + fi) * LDS_LD + kg * 16 + fg * 4]); \
+      _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_)                                     \
+        _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i_].x, bf[j_].x, acc[i_][j_], 0, 0, 0); \
+      _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_)                                     \
+        _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i_].y, bf[j_].y, acc[i_][j_], 0, 0, 0); \
+      _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_)                                     \
+        _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i_].z, bf[j_].z, acc[i_][j_], 0, 0, 0); \
+      _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_)                                     \
+        _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i_].w, bf[j_].w, acc[i_][j_], 0, 0, 0); \
     }                                                                                       \
-    if (s0 + (J) + 1 < nslab) GEMM_STAGE(s0 + (J) + 1, NA, NB); /* buffer last read before the previous barrier */ \
+    if (s0 + (J) + 1 < nslab) GEMM_STAGE(s0 + (J) + 1, NQ); /* buffer last read before the previous barrier */ \
     __syncthreads();                                                                        \
   }
 
-  float4 a0, b0, a1, b1, a2, b2, a3, b3;
-  GEMM_FETCH(0, a0, b0);
-  GEMM_FETCH(1, a1, b1);
-  GEMM_FETCH(2, a2, b2);
-  GEMM_FETCH(3, a3, b3);
-  GEMM_STAGE(0, a0, b0);
+  Slab q0, q1, q2, q3;
+  GEMM_FETCH(0, q0);
+  GEMM_FETCH(1, q1);
+  GEMM_FETCH(2, q2);
+  GEMM_FETCH(3, q3);
+  GEMM_STAGE(0, q0);
   __syncthreads();
   for (int s0 = 0; s0 < nslab; s0 += 4) {  // slab parity == J parity
-    GEMM_STEP(0, a0, b0, a1, b1)
-    GEMM_STEP(1, a1, b1, a2, b2)
-    GEMM_STEP(2, a2, b2, a3, b3)
-    GEMM_STEP(3, a3, b3, a0, b0)
+    GEMM_STEP(0, q0, q1)
+    GEMM_STEP(1, q1, q2)
+    GEMM_STEP(2, q2, q3)
+    GEMM_STEP(3, q3, q0)
   }
 #undef GEMM_STEP
 #undef GEMM_STAGE
 #undef GEMM_FETCH
   // epilogue: D register r of lane l holds row (l>>4)*4 + r, column l&15 of its 16x16 tile
-  const int n = n0 + wn * 16 + fi;
-  if (n < g.N) {
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = n0 + wn * 16 * NT + 16 * j + fi;
+    if (n >= g.N) continue;
     const float bz = g.bias ? g.bias[n] : 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = m0 + wm * 16 + fg * 4 + r;
-      if (m >= M) continue;
-      float v = (g.alpha != 0.f ? g.alpha * acc[r] : acc[r]) + bz;
-      const float rv = R ? (g.beta != 0.f ? g.beta : 1.f) * R[(size_t)m * g.ldr + n] : 0.f;
-      if (g.r_before_act) v += rv;
-      if (g.act == 1) v = fmaxf(v, 0.f);
-      else if (g.act == 2) v = tanhf(v);
-      else if (g.act == 3) v = powf(fmaxf(v, 0.f), g.p);
-      if (!g.r_before_act) v += rv;
-      if (g.transpose_out) C[(size_t)n * g.ldc + m] = v;
-      else C[(size_t)m * g.ldc + n] = v;
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * 16 * MT + 16 * i + fg * 4 + r;
+        if (m >= M) continue;
+        float v = (g.alpha != 0.f ? g.alpha * acc[i][j][r] : acc[i][j][r]) + bz;
+        const float rv = R ? (g.beta != 0.f ? g.beta : 1.f) * R[(size_t)m * g.ldr + n] : 0.f;
+        if (g.r_before_act) v += rv;
+        if (g.act == 1) v = fmaxf(v, 0.f);
+        else if (g.act == 2) v = tanhf(v);
+        else if (g.act == 3) v = powf(fmaxf(v, 0.f), g.p);
+        if (!g.r_before_act) v += rv;
+        if (g.transpose_out) C[(size_t)n * g.ldc + m] = v;
+        else C[(size_t)m * g.ldc + n] = v;
+      }
     }
   }
 }
@@ -227,12 +267,45 @@ __global__ void k_transpose(const float *in, float *out, int rows, int cols) {
     if (ox < rows && oy0 + j < cols) out[(size_t)(oy0 + j) * rows + ox] = tile[threadIdx.x][j];
 }
 
+struct RowCounts {
+  int n[GEMM_RAGGED_MAX];
+};
+__global__ void k_copy_rows(const float *__restrict__ src, size_t src_stride, float *dst, size_t dst_stride, RowCounts rows, int cols4) {
+  const int z = blockIdx.y;
+  const size_t total = (size_t)rows.n[z] * cols4;
+  const float4 *s4 = reinterpret_cast<const float4 *>(src + z * src_stride);
+  float4 *d4 = reinterpret_cast<float4 *>(dst + z * dst_stride);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) d4[i] = s4[i];
+}
+
 }  // namespace
+
+void launch_copy_rows(const float *src, size_t src_stride, float *dst, size_t dst_stride, const int *rows, int n, int cols,
+                      hipStream_t s) {
+  if (n > GEMM_RAGGED_MAX || cols % 4 != 0 || src_stride % 4 != 0 || dst_stride % 4 != 0) fail(XDTTS_ERR_BAD_ARG, "copy_rows: n=%d cols=%d", n, cols);
+  RowCounts rc{};
+  int most = 0;
+  for (int z = 0; z < n; ++z) {
+    rc.n[z] = rows[z];
+    most = std::max(most, rows[z]);
+  }
+  if (most == 0) return;
+  const int blocks = std::min(64, (most * (cols / 4) + 255) / 256);
+  hipLaunchKernelGGL(k_copy_rows, dim3(blocks, n), dim3(256), 0, s, src, src_stride, dst, dst_stride, rc, cols / 4);
+  HIP_CHECK(hipGetLastError());
+}
 
 void launch_gemm_nt(const GemmArgs &g, hipStream_t s) {
   if (g.ragged && g.batch > GEMM_RAGGED_MAX) fail(XDTTS_ERR_BAD_ARG, "gemm: ragged batch of %d", g.batch);
   if (g.K % 16 != 0 || g.lda % 4 != 0) fail(XDTTS_ERR_BAD_ARG, "gemm: K=%d lda=%ld not supported", g.K, g.lda);
-  hipLaunchKernelGGL(k_gemm_nt, dim3((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.batch), dim3(256), 0, s, g);
+  // 64x64 tiles once they fill the chip at least twice over (XDTTS_GEMM_TILE=32|64: developer comparison aid)
+  static const int forced = getenv("XDTTS_GEMM_TILE") ? atoi(getenv("XDTTS_GEMM_TILE")) : 0;
+  const long tiles64 = (long)((g.N + 63) / 64) * ((g.M + 63) / 64) * g.batch;
+  const bool big = forced ? forced == 64 : (g.N >= 64 && tiles64 >= 512);
+  if (big)
+    hipLaunchKernelGGL((k_gemm_nt<64, 64>), dim3((g.N + 63) / 64, (g.M + 63) / 64, g.batch), dim3(256), 0, s, g);
+  else
+    hipLaunchKernelGGL((k_gemm_nt<32, 32>), dim3((g.N + 31) / 32, (g.M + 31) / 32, g.batch), dim3(256), 0, s, g);
   HIP_CHECK(hipGetLastError());
 }
 

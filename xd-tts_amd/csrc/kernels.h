@@ -94,8 +94,8 @@ struct GemmArgs {
   // ragged batches (post-net over chunks of different length): per-item row count and extra element
   // offset of C, used when ragged != 0 (batch <= GEMM_RAGGED_MAX); blocks past an item's rows exit
   int ragged;
-  int Mz[16];
-  long Cz[16];
+  int Mz[64];
+  long Cz[64];
   int act;            // 0 none, 1 relu, 2 tanh, 3 pow(max(x,0), p)
   int transpose_out;  // store C[n*ldc + m]
   float p;
@@ -104,7 +104,7 @@ struct GemmArgs {
   float alpha, beta;
   int r_before_act;
 };
-constexpr int GEMM_RAGGED_MAX = 16;
+constexpr int GEMM_RAGGED_MAX = 64;  // (the argument block stays under 1 KB)
 void launch_gemm_nt(const GemmArgs &g, hipStream_t s);
 
 // ---- encoder (encoder.onnx, mod.rs:379) ---------------------------------------------------------
@@ -183,5 +183,9 @@ void launch_gl_state_import(const GlBufs &g, const float *ang_in, const float *r
 void launch_gl_state_export(const GlBufs &g, const float2 *ang, const float2 *tprev, float *ang_out, float *reb_out,
                             hipStream_t s);
 void launch_transpose(const float *in, float *out, int rows, int cols, hipStream_t s);
+// Ragged row copy: item z (< n <= GEMM_RAGGED_MAX) has rows[z] rows of `cols` floats at src + z * src_stride; they go
+// to dst + z * dst_stride (one launch instead of a memcpy per chunk: the post-net's padded layer-0 input)
+void launch_copy_rows(const float *src, size_t src_stride, float *dst, size_t dst_stride, const int *rows, int n, int cols,
+                      hipStream_t s);
 
 }  // namespace xdtts
