@@ -181,12 +181,19 @@ xdtts_status xdtts_griffinlim_new(const float *mel_basis, size_t n_mels, size_t 
  *                   1/lambda_max(basis basis^T); the iteration's limit is the NNLS solution)
  *   power_mode      0: S = x^(1/power) (librosa mel_to_stft)   1: S = x^power   2: S = x
  *   mel_decompress  0: m = exp(mel) (Tacotron2's ln compression)   1: m = mel   2: m = 10^mel
- *   peak_normalise  0: audio as is (src/lib.rs:155 scales by i16::MAX directly)   1: audio / max|audio| */
+ *   peak_normalise  0: audio as is (src/lib.rs:155 scales by i16::MAX directly)   1: audio / max|audio|
+ * and one switch of xdtts_griffinlim_infer_batch only:
+ *   batch_shape     0: a workgroup owns up to 4 or up to 8 frames of an utterance, whichever shape needs less time
+ *                   for the batch at hand (the overlap-add then sums in a different order than the single call:
+ *                   same audio within the fp32 drift of DESIGN.md section 2, not bit for bit)
+ *                   4: always the shape of the single-utterance call: every audio of a batch is bit-identical to
+ *                   xdtts_griffinlim_infer on that utterance alone (about 1.5x the time on a large batch) */
 typedef struct {
   int32_t nnls_iters;
   int32_t power_mode;
   int32_t mel_decompress;
   int32_t peak_normalise;
+  int32_t batch_shape;
 } xdtts_griffinlim_opts;
 void xdtts_griffinlim_opts_default(xdtts_griffinlim_opts *opts);
 xdtts_status xdtts_griffinlim_set_opts(xdtts_griffinlim *g, const xdtts_griffinlim_opts *opts);
@@ -202,8 +209,9 @@ xdtts_status xdtts_griffinlim_infer(xdtts_griffinlim *g, const float *mel, size_
 
 /* GriffinLim::infer for n_utt utterances in one call (the vocoder half of a batch; the reference calls
  * self.vocoder.infer once per utterance, src/lib.rs:141): mels[u] is n_mels x n_frames[u]; audios[u]
- * receives hop*(n_frames[u]-1) samples, bit-identical to xdtts_griffinlim_infer on that utterance alone.
- * Utterances share persistent launches (a workgroup never spans two). */
+ * receives hop*(n_frames[u]-1) samples: the audio of xdtts_griffinlim_infer on that utterance alone (bit for bit
+ * with opts.batch_shape = 4; within fp32 drift with the default, see xdtts_griffinlim_opts), whatever the mix
+ * and the order.  Utterances share persistent launches (a workgroup never spans two). */
 xdtts_status xdtts_griffinlim_infer_batch(xdtts_griffinlim *g, const float *const *mels, size_t n_mels,
                                           const size_t *n_frames, int32_t n_utt, float **audios,
                                           size_t *n_samples);

@@ -165,9 +165,11 @@ def test_mel_to_linear_options_match_the_oracle(pkg, orc):
 
 def test_vocoder_batch_equals_one_by_one(pkg):
     """xdtts_griffinlim_infer_batch: several utterances per persistent launch (workgroups never span two),
-    tiny (< 16 frames) and long (> 1024) ones on their own path -- every audio bit-identical to the
-    single-utterance call, whatever the mix and the order."""
+    tiny (< 16 frames) and long (> 1024) ones on their own path.  With batch_shape = 4 every audio is
+    bit-identical to the single-utterance call, whatever the mix and the order; the default picks 8-frame
+    workgroups when they save launches, and the audio then agrees within the fp32 drift of 12 iterations."""
     v = pkg.create_griffin_lim(iters=12, seed=9)
+    v.set_opts(batch_shape=4)
     rng = np.random.default_rng(8)
     Fs = [37, 16, 5, 400, 1100, 19, 2, 257, 64, 1024, 333]
     mels = [(rng.uniform(-7.0, -1.0, size=(80, F)) + 1.5 * np.sin(np.arange(F) / 6.0)[None, :]).astype(np.float32) for F in Fs]
@@ -182,6 +184,16 @@ def test_vocoder_batch_equals_one_by_one(pkg):
     many = [mels[0]] * 40 + [mels[3]] * 5
     outs = v.infer_batch(many)
     assert all(np.array_equal(o, one[0]) for o in outs[:40]) and all(np.array_equal(o, one[3]) for o in outs[40:])
+    # default shape: 8 frames per workgroup here (2 launches instead of 4), same audio within drift, and the
+    # result does not depend on the call (deterministic)
+    v.set_opts(batch_shape=0)
+    auto = v.infer_batch(many)
+    ref = [one[0]] * 40 + [one[3]] * 5
+    rel = [float(np.sqrt(np.mean((a.astype(np.float64) - b) ** 2)) / np.sqrt(np.mean(b.astype(np.float64) ** 2))) for a, b in zip(auto, ref)]
+    assert max(rel) <= 5e-5, max(rel)  # measured 5e-6
+    assert not all(np.array_equal(a, b) for a, b in zip(auto, ref))  # (the 8-frame shape really ran)
+    assert all(np.array_equal(a, b) for a, b in zip(v.infer_batch(many), auto))
+    v.set_opts(batch_shape=4)
     # options apply per utterance in a batch too
     v.set_opts(peak_normalise=1, nnls_iters=3)
     single = [v.infer(m) for m in mels[:4]]

@@ -40,7 +40,7 @@ class XdttsError(RuntimeError):
 class GriffinLimOpts(C.Structure):
     """xdtts_griffinlim_opts: the conventions of GriffinLim::infer's mel->linear step as switches."""
 
-    _fields_ = [("nnls_iters", C.c_int32), ("power_mode", C.c_int32), ("mel_decompress", C.c_int32), ("peak_normalise", C.c_int32)]
+    _fields_ = [("nnls_iters", C.c_int32), ("power_mode", C.c_int32), ("mel_decompress", C.c_int32), ("peak_normalise", C.c_int32), ("batch_shape", C.c_int32)]
 
 
 class InferOpts(C.Structure):
@@ -198,12 +198,29 @@ def read_model_dir(path):
     return {n: blob[off : off + int(np.prod(shape))].reshape(shape) for n, shape, off in tensor_table()}
 
 
+class _Pinned:
+    """Owner of one library buffer (pinned host memory): xdtts_free when the last view of it goes."""
+
+    def __init__(self, addr):
+        self.addr = addr
+
+    def __del__(self):
+        if self.addr and lib is not None:
+            lib.xdtts_free(C.cast(self.addr, _PF))
+            self.addr = None
+
+
 def _take(ptr, n, shape):
-    """Copy a library-owned pinned buffer into numpy and release it."""
-    try:
-        return np.ctypeslib.as_array(ptr, shape=(max(n, 1),))[:n].reshape(shape).copy()
-    finally:
-        lib.xdtts_free(ptr)
+    """A numpy view of a library-owned pinned buffer (no copy: a batch of audio is tens of MB); the buffer
+    goes back to the library's pool when the array and every view of it are gone."""
+    addr = C.cast(ptr, C.c_void_p).value
+    if not n or not addr:
+        if addr:
+            lib.xdtts_free(ptr)
+        return np.zeros(shape, dtype=np.float32)
+    buf = (C.c_float * int(n)).from_address(addr)
+    buf._owner = _Pinned(addr)  # numpy keeps `buf` as the array's base, `buf` keeps the owner
+    return np.frombuffer(buf, dtype=np.float32).reshape(shape)
 
 
 def generate_id_list():
@@ -431,7 +448,8 @@ class GriffinLim:
 
     def set_opts(self, **kw):
         """nnls_iters, power_mode (0 inverse / 1 direct / 2 none), mel_decompress (0 exp / 1 none / 2 10^x),
-        peak_normalise; unspecified fields keep their current value."""
+        peak_normalise, batch_shape (0 auto / 4 the single-utterance shape: bit-identical batches); unspecified
+        fields keep their current value."""
         o = self.get_opts()
         for k, v in kw.items():
             setattr(o, k, v)

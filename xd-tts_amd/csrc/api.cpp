@@ -1257,8 +1257,8 @@ xdtts_status xdtts_tacotron2_infer_batch(xdtts_tacotron2 *h, const int64_t *ids,
     }
     int total = 0;
     std::vector<int> F = h->infer_batch_device(padded.data(), lens, B, T, o, fixed_steps_per_item, &total);
-    std::vector<float> all((size_t)N_MEL * total);
-    HIP_CHECK(hipMemcpyAsync(all.data(), h->mel_dev.p, all.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    PinnedGuard all((size_t)N_MEL * total);  // pinned staging: a pageable destination halves the copy rate
+    HIP_CHECK(hipMemcpyAsync(all.p, h->mel_dev.p, (size_t)N_MEL * total * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     h->finish_timings();
     std::vector<PinnedGuard> out;  // all B buffers exist before the first one is handed over
     out.reserve((size_t)B);
@@ -1267,7 +1267,7 @@ xdtts_status xdtts_tacotron2_infer_batch(xdtts_tacotron2 *h, const int64_t *ids,
     for (int b = 0; b < B; ++b) {
       float *m = out[(size_t)b].p;
       for (int r = 0; r < N_MEL; ++r)
-        std::memcpy(m + (size_t)r * F[b], all.data() + (size_t)r * total + off, sizeof(float) * F[b]);
+        std::memcpy(m + (size_t)r * F[b], all.p + (size_t)r * total + off, sizeof(float) * F[b]);
       off += F[b];
     }
     for (int b = 0; b < B; ++b) {
@@ -1507,13 +1507,14 @@ void xdtts_griffinlim_opts_default(xdtts_griffinlim_opts *o) {
   o->power_mode = 0;
   o->mel_decompress = 0;
   o->peak_normalise = 0;
+  o->batch_shape = 0;
 }
 
 xdtts_status xdtts_griffinlim_set_opts(xdtts_griffinlim *g, const xdtts_griffinlim_opts *o) {
   return guard([&] {
     if (!g || !o) fail(XDTTS_ERR_BAD_ARG, "null argument");
     if (o->nnls_iters < 0 || o->nnls_iters > 100000 || o->power_mode < 0 || o->power_mode > 2 || o->mel_decompress < 0 ||
-        o->mel_decompress > 2 || o->peak_normalise < 0 || o->peak_normalise > 1)
+        o->mel_decompress > 2 || o->peak_normalise < 0 || o->peak_normalise > 1 || (o->batch_shape != 0 && o->batch_shape != 4))
       fail(XDTTS_ERR_BAD_ARG, "griffin-lim option out of range");
     std::lock_guard<std::mutex> lk(g->mu);
     g->gopts = *o;
@@ -1630,39 +1631,52 @@ xdtts_status xdtts_griffinlim_infer_batch(xdtts_griffinlim *g, const float *cons
       g->mel_to_linear(g->mel_in.p, (int)Ftot);
       HIP_CHECK(hipEventRecord(g->ev.e[1], st));
       launch_gl_phase_init_batch(all, g->seed, g->frame_local.p, st);
-      // pack consecutive utterances into persistent launches of <= one workgroup per CU (4 frames per workgroup)
+      // pack consecutive utterances into persistent launches of <= one workgroup per CU.  A workgroup owns up to
+      // 4 frames (one wave each) or up to 8 (two waves per SIMD): an iteration of the 8-frame shape takes 6.8 us
+      // against 5.35 us (tools/gl_tf_sweep.py), so it wins as soon as it saves launches.
       const bool pers = g->persistent_usable();
       std::vector<GlSeg> segs;
       struct Launch { int seg0, nblk; };
       std::vector<Launch> launches;
       std::vector<char> batched(n_utt, 0);
-      constexpr int TF = 4;
-      if (pers) {
-        int cur0 = 0, cur_n = 0;
+      auto pack = [&](int tf, bool build) {  // returns the number of launches
+        int cur0 = 0, cur_n = 0, n_launch = 0;
         auto flush = [&]() {
-          if (cur_n) launches.push_back({cur0, cur_n});
+          if (cur_n) {
+            ++n_launch;
+            if (build) launches.push_back({cur0, cur_n});
+          }
           cur0 = (int)segs.size();
           cur_n = 0;
         };
         for (int u = 0; u < n_utt; ++u) {
-          const int nb = (Fu[u] + TF - 1) / TF;
+          const int nb = (Fu[u] + tf - 1) / tf;
           if (Fu[u] < 16 || nb > g->n_cu || Fu[u] / nb < 3) continue;  // on its own below
           if (cur_n + nb > g->n_cu) flush();
-          for (int b = 0; b < nb; ++b) {
-            GlSeg sg{};
-            sg.fbase = fbase[u];
-            sg.F = Fu[u];
-            sg.f0 = (int)(((long long)b * Fu[u]) / nb);
-            sg.n_own = (int)(((long long)(b + 1) * Fu[u]) / nb) - sg.f0;
-            sg.first = b == 0;
-            sg.last = b + 1 == nb;
-            sg.abase = abase[u];
-            segs.push_back(sg);
+          if (build) {
+            for (int b = 0; b < nb; ++b) {
+              GlSeg sg{};
+              sg.fbase = fbase[u];
+              sg.F = Fu[u];
+              sg.f0 = (int)(((long long)b * Fu[u]) / nb);
+              sg.n_own = (int)(((long long)(b + 1) * Fu[u]) / nb) - sg.f0;
+              sg.first = b == 0;
+              sg.last = b + 1 == nb;
+              sg.abase = abase[u];
+              segs.push_back(sg);
+            }
+            batched[u] = 1;
           }
           cur_n += nb;
-          batched[u] = 1;
         }
         flush();
+        return n_launch;
+      };
+      int TF = 4;
+      if (pers) {
+        const int l4 = pack(4, false), l8 = pack(GLP_TF_MAX, false);
+        if (g->gopts.batch_shape == 0 && l8 > 0 && 6.8 * l8 < 5.35 * l4) TF = GLP_TF_MAX;
+        pack(TF, true);
       }
       bool used_persistent = false;
       if (!segs.empty()) {
