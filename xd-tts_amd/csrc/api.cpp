@@ -344,6 +344,11 @@ struct xdtts_tacotron2 {
   // Replays (building on first use) a hipGraph holding GRAPH_STEPS decoder steps.  The kernels
   // read the step index from device memory, so one graph serves every position of the loop.
   void replay_steps(const DecoderBufs &d) {
+    static const bool no_graph = getenv("XDTTS_NO_GRAPH") != nullptr;  // developer comparison aid
+    if (no_graph) {
+      launch_decoder_steps(d, w, GRAPH_STEPS, stream);
+      return;
+    }
     if (!graph || std::memcmp(&graph_key, &d, sizeof d) != 0) {
       if (graph) {
         (void)hipGraphExecDestroy(graph);
