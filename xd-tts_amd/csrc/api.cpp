@@ -1644,43 +1644,57 @@ xdtts_status xdtts_griffinlim_infer_batch(xdtts_griffinlim *g, const float *cons
       struct Launch { int seg0, nblk; };
       std::vector<Launch> launches;
       std::vector<char> batched(n_utt, 0);
-      auto pack = [&](int tf, bool build) {  // returns the number of launches
-        int cur0 = 0, cur_n = 0, n_launch = 0;
-        auto flush = [&]() {
-          if (cur_n) {
-            ++n_launch;
-            if (build) launches.push_back({cur0, cur_n});
-          }
-          cur0 = (int)segs.size();
-          cur_n = 0;
-        };
+      auto pack = [&](int tf, bool build) {  // returns the relative cost: launches x time per iteration of the shape
+        // first-fit decreasing over launches of n_cu workgroups (which launch an utterance rides in does not
+        // change its audio: its own split into workgroups depends on its frame count alone)
+        std::vector<std::pair<int, int>> items;  // (workgroups, utterance)
+        int n_alone = 0;
         for (int u = 0; u < n_utt; ++u) {
           const int nb = (Fu[u] + tf - 1) / tf;
-          if (Fu[u] < 16 || nb > g->n_cu || Fu[u] / nb < 3) continue;  // on its own below
-          if (cur_n + nb > g->n_cu) flush();
-          if (build) {
-            for (int b = 0; b < nb; ++b) {
-              GlSeg sg{};
-              sg.fbase = fbase[u];
-              sg.F = Fu[u];
-              sg.f0 = (int)(((long long)b * Fu[u]) / nb);
-              sg.n_own = (int)(((long long)(b + 1) * Fu[u]) / nb) - sg.f0;
-              sg.first = b == 0;
-              sg.last = b + 1 == nb;
-              sg.abase = abase[u];
-              segs.push_back(sg);
-            }
-            batched[u] = 1;
+          if (Fu[u] < 16 || nb > g->n_cu || Fu[u] / nb < 3) {  // on its own below
+            n_alone += Fu[u] >= 16;  // (a launch of the 5..8-frame shape; the tiny ones cost next to nothing)
+            continue;
           }
-          cur_n += nb;
+          items.emplace_back(nb, u);
         }
-        flush();
-        return n_launch;
+        std::stable_sort(items.begin(), items.end(), [](const std::pair<int, int> &a, const std::pair<int, int> &b) { return a.first > b.first; });
+        std::vector<int> room;                 // free workgroups of each launch
+        std::vector<std::vector<int>> riders;  // its utterances
+        for (const auto &it : items) {
+          size_t k = 0;
+          while (k < room.size() && room[k] < it.first) ++k;
+          if (k == room.size()) {
+            room.push_back(g->n_cu);
+            riders.emplace_back();
+          }
+          room[k] -= it.first;
+          riders[k].push_back(it.second);
+        }
+        if (build)
+          for (size_t k = 0; k < riders.size(); ++k) {
+            const int seg0 = (int)segs.size();
+            for (int u : riders[k]) {
+              const int nb = (Fu[u] + tf - 1) / tf;
+              for (int b = 0; b < nb; ++b) {
+                GlSeg sg{};
+                sg.fbase = fbase[u];
+                sg.F = Fu[u];
+                sg.f0 = (int)(((long long)b * Fu[u]) / nb);
+                sg.n_own = (int)(((long long)(b + 1) * Fu[u]) / nb) - sg.f0;
+                sg.first = b == 0;
+                sg.last = b + 1 == nb;
+                sg.abase = abase[u];
+                segs.push_back(sg);
+              }
+              batched[u] = 1;
+            }
+            launches.push_back({seg0, (int)segs.size() - seg0});
+          }
+        return (tf <= 4 ? 5.35 : 6.8) * (double)riders.size() + 6.8 * n_alone;
       };
       int TF = 4;
       if (pers) {
-        const int l4 = pack(4, false), l8 = pack(GLP_TF_MAX, false);
-        if (g->gopts.batch_shape == 0 && l8 > 0 && 6.8 * l8 < 5.35 * l4) TF = GLP_TF_MAX;
+        if (g->gopts.batch_shape == 0 && pack(GLP_TF_MAX, false) < pack(4, false)) TF = GLP_TF_MAX;
         pack(TF, true);
       }
       bool used_persistent = false;
