@@ -766,8 +766,22 @@ struct xdtts_griffinlim {
   bool last_persistent = false;    // the last run_iterations used the persistent engine
   int demoted_calls = 0;           // calls since a demotion (the engine is probed again after PROBE_AFTER)
   static constexpr int PROBE_AFTER = 64;
+  // vocoder batch: the audio of a finished launch goes to the host while the next launches run
+  hipStream_t copy_stream = nullptr;
+  std::vector<hipEvent_t> copy_ev;
+  hipEvent_t launch_done(size_t k) {
+    if (!copy_stream) HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+    while (copy_ev.size() <= k) {
+      hipEvent_t e = nullptr;
+      HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      copy_ev.push_back(e);
+    }
+    return copy_ev[k];
+  }
 
   ~xdtts_griffinlim() {
+    for (hipEvent_t e : copy_ev) (void)hipEventDestroy(e);
+    if (copy_stream) (void)hipStreamDestroy(copy_stream);
     if (host_err) (void)hipHostFree(host_err);
     if (graph) (void)hipGraphExecDestroy(graph);
     if (stream) (void)hipStreamDestroy(stream);
@@ -1641,7 +1655,7 @@ xdtts_status xdtts_griffinlim_infer_batch(xdtts_griffinlim *g, const float *cons
       // against 5.35 us (tools/gl_tf_sweep.py), so it wins as soon as it saves launches.
       const bool pers = g->persistent_usable();
       std::vector<GlSeg> segs;
-      struct Launch { int seg0, nblk; };
+      struct Launch { int seg0, nblk; std::vector<int> utts; };
       std::vector<Launch> launches;
       std::vector<char> batched(n_utt, 0);
       auto pack = [&](int tf, bool build) {  // returns the relative cost: launches x time per iteration of the shape
@@ -1688,7 +1702,7 @@ xdtts_status xdtts_griffinlim_infer_batch(xdtts_griffinlim *g, const float *cons
               }
               batched[u] = 1;
             }
-            launches.push_back({seg0, (int)segs.size() - seg0});
+            launches.push_back({seg0, (int)segs.size() - seg0, riders[k]});
           }
         return (tf <= 4 ? 5.35 : 6.8) * (double)riders.size() + 6.8 * n_alone;
       };
@@ -1698,6 +1712,26 @@ xdtts_status xdtts_griffinlim_infer_batch(xdtts_griffinlim *g, const float *cons
         pack(TF, true);
       }
       bool used_persistent = false;
+      std::vector<PinnedGuard> out;  // each utterance straight into the buffer the caller receives
+      out.reserve((size_t)n_utt);
+      for (int u = 0; u < n_utt; ++u) out.emplace_back((size_t)g->hop * (size_t)(Fu[u] - 1));
+      struct Drain {  // no buffer of `out` goes back to the pool while a copy into it may be in flight
+        hipStream_t &s;
+        ~Drain() {
+          if (s) (void)hipStreamSynchronize(s);
+        }
+      } drain{g->copy_stream};
+      // (peak normalisation rewrites the audio after the launches: then the copies follow everything)
+      const bool early = !g->gopts.peak_normalise;
+      size_t n_ev = 0;
+      auto fetch_audio = [&](const std::vector<int> &utts) {  // after the work just enqueued on `st`
+        hipEvent_t e = g->launch_done(n_ev++);
+        HIP_CHECK(hipEventRecord(e, st));
+        HIP_CHECK(hipStreamWaitEvent(g->copy_stream, e, 0));
+        for (int u : utts)
+          HIP_CHECK(hipMemcpyAsync(out[(size_t)u].p, g->audio.p + abase[u], sizeof(float) * (size_t)g->hop * (size_t)(Fu[u] - 1),
+                                   hipMemcpyDeviceToHost, g->copy_stream));
+      };
       if (!segs.empty()) {
         g->segs.upload(segs.data(), segs.size(), st);
         HIP_CHECK(hipStreamSynchronize(st));
@@ -1724,6 +1758,7 @@ xdtts_status xdtts_griffinlim_infer_batch(xdtts_griffinlim *g, const float *cons
           p.TF = TF;
           g->epoch += (unsigned)g->iters + 2u;
           launch_gl_persistent(all, p, all.ang, all.tprev, g->iters, alpha, g->audio.p, st);
+          if (early) fetch_audio(L.utts);
         }
         used_persistent = true;
       }
@@ -1740,17 +1775,19 @@ xdtts_status xdtts_griffinlim_infer_batch(xdtts_griffinlim *g, const float *cons
         launch_gl_prepare(v, st);
         g->run_iterations(v, g->iters, alpha, g->audio.p + abase[u]);  // the engine the single-utterance call uses
         used_persistent = used_persistent || g->last_persistent;
+        if (early) fetch_audio(std::vector<int>(1, u));
       }
-      if (g->gopts.peak_normalise)
-        for (int u = 0; u < n_utt; ++u) launch_gl_peak_normalise(g->audio.p + abase[u], g->hop * (Fu[u] - 1), g->peak.p, st);
+      if (!early) {
+        std::vector<int> every((size_t)n_utt);
+        for (int u = 0; u < n_utt; ++u) {
+          launch_gl_peak_normalise(g->audio.p + abase[u], g->hop * (Fu[u] - 1), g->peak.p, st);
+          every[(size_t)u] = u;
+        }
+        fetch_audio(every);
+      }
       HIP_CHECK(hipEventRecord(g->ev.e[2], st));
-      std::vector<PinnedGuard> out;  // each utterance straight into the buffer the caller receives
-      out.reserve((size_t)n_utt);
-      for (int u = 0; u < n_utt; ++u) {
-        out.emplace_back((size_t)g->hop * (size_t)(Fu[u] - 1));
-        HIP_CHECK(hipMemcpyAsync(out[(size_t)u].p, g->audio.p + abase[u], sizeof(float) * (size_t)g->hop * (size_t)(Fu[u] - 1), hipMemcpyDeviceToHost, st));
-      }
       g->finish_timings();
+      HIP_CHECK(hipStreamSynchronize(g->copy_stream));
       g->last_persistent = used_persistent;
       if (g->persistent_failed()) {
         if (attempt) fail(XDTTS_ERR_HIP, "Griffin-Lim batch: exchange failure on the fallback engine");
