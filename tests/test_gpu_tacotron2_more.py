@@ -261,3 +261,34 @@ def test_batched_path_with_a_smaller_window(pkg, model, orc, blob):
     for b, (ids, st) in enumerate(zip(ids_list, steps)):
         ref = orc.infer_chunk(blob, ids, orc.default_opts(fixed_steps=st, dropout_seed=23, item=2 + b), window=50)
         assert mels[b].shape == (80, st) and rms(mels[b], ref) <= 1e-5, b
+
+
+def test_gemm_tile_shapes_give_identical_results(tmp_path):
+    """k_gemm_nt picks 32x32 tiles for the single-utterance shapes and 64x64 once a grid fills the chip twice;
+    both accumulate every output element's K products in ascending order, so a batch decoded with either
+    shape forced (XDTTS_GEMM_TILE is read once per process: two child processes) is bit-identical."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = (
+        "import importlib, sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import torch\n"
+        "from conftest import synth_ids\n"
+        "pkg = importlib.import_module('xd-tts_amd')\n"
+        "m = pkg.Tacotron2.synthetic()\n"
+        "ids = [synth_ids(20 + 3 * i, seed=300 + i) for i in range(24)]\n"
+        "mels = m.infer_batch(ids, opts=pkg.default_opts(dropout_seed=5), fixed_steps=[6 + i %% 5 for i in range(24)])\n"
+        "np.savez(sys.argv[1], *mels)\n"
+    ) % (root, os.path.join(root, "tests"))
+    out = {}
+    for tile in ("32", "64"):
+        path = str(tmp_path / ("mels_%s.npz" % tile))
+        env = dict(os.environ, XDTTS_GEMM_TILE=tile)
+        r = subprocess.run([sys.executable, "-c", script, path], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        with np.load(path) as z:
+            out[tile] = [z[k] for k in z.files]
+    assert len(out["32"]) == 24
+    assert all(np.array_equal(a, b) for a, b in zip(out["32"], out["64"]))
