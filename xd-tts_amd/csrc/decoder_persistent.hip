@@ -8,7 +8,11 @@
 // whole utterance (8 waves x 64 lanes x 136 VGPRs = 272 KB per CU), wave w owning gate rows w and
 // w + 8 of each (16 waves x 68 VGPRs leaves too few working registers under the 128-VGPR cap).  What crosses CUs per step is only the state: six all-gather edges
 //     x (256 values) -> all      h_att (1024) -> all      partial energies (8 x T) -> 8
-//     context (512) -> all       h_dec (1024) -> all      mel + gate (81) -> 16
+//     attention weights (T) -> all    h_dec (1024) -> all      mel + gate (81) -> 16
+// (the attention CONTEXT never crosses: every consumer of it is linear in it, so each workgroup folds its own
+// context columns into the encoder memory once per launch -- P[row][t] = W[row][ctx cols] . memory[t] -- and
+// takes  sum_t w_t P[row][t]  instead of  W[row][ctx cols] . (sum_t w_t memory[t]);  the T weights leave the
+// attention role right after the softmax, the context sum itself is off the step's critical path altogether)
 // carried by data-tagged 8-byte granules {tag = step + 1, value} (one relaxed agent-scope store per
 // value; readers re-read until the tag matches -- MI355X_MICROARCH.md hand-off recipe R2, the
 // scheme the encoder BiLSTM already uses): no flags, no fences, placement-independent.  Two slots
@@ -130,8 +134,8 @@ __device__ __forceinline__ unsigned opaque(unsigned v) {
 }
 
 constexpr int persist_lds_floats(int pb) {
-  const int common = pb * (PRENET + EMB + ATT_RNN + DEC_RNN + 16) + 8 + 32 + 16 * pb;
-  const int attn = TP * 64 + 2 * TP * 16 + 2 * TP + 16 + NW * 64 + 2 * WPAD + 62 * 16 + 64 + TP + 16 + 8 * PT * 4;
+  const int common = pb * (PRENET + TP + ATT_RNN + DEC_RNN + 16) + 8 + 32 + 16 * pb;
+  const int attn = 2 * TP * 16 + 2 * TP + 16 + NW * 64 + 2 * WPAD + 62 * 16 + 64 + TP + 16 + 8 * PT * 4;
   const int pre = N_MEL * PRENET + MEL_GL + 2 * PRENET + 8 + 6 * PT * 4;
   return common + (attn > pre ? attn : pre);
 }
@@ -168,8 +172,8 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
   const unsigned L4 = opaque(4u * (unsigned)lane);
   // ---- LDS: state vectors of all chunks, then the role's working set -------------------------
   float *s_x = smem;                     // [PB][256]
-  float *s_ctx = s_x + PB * PRENET;      // [PB][512]
-  float *s_hatt = s_ctx + PB * EMB;      // [PB][1024]
+  float *s_w = s_x + PB * PRENET;        // [PB][TP]  attention weights of the current step (zero from T on)
+  float *s_hatt = s_w + PB * TP;         // [PB][1024]
   float *s_hdec = s_hatt + PB * ATT_RNN; // [PB][1024]
   float *s_g = s_hdec + PB * DEC_RNN;    // [PB][16] gate pre-activations of this workgroup's rows
   int *s_act = reinterpret_cast<int *>(s_g + PB * 16);  // [0..1] active at this step, [2..3] alive: not yet seen inactive, [4] error word
@@ -177,8 +181,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
   float *s_cell = s_bias + 32;           // [4][4 PB] att_c, dec_c, h_att, h_dec of the (chunk, unit) cell threads
   float *role = s_cell + 16 * PB;
   // attention role
-  float *s_mem = role;                   // [TP][64]  this workgroup's columns of the encoder memory
-  float *s_pm = s_mem + TP * 64;         // [TP][16]  processed_memory, own dims
+  float *s_pm = role;                    // [TP][16]  processed_memory, own dims
   float *s_loc = s_pm + TP * 16;         // [TP][16]  location features, own dims
   float *s_aw = s_loc + TP * 16;         // [TP]
   float *s_awc = s_aw + TP;              // [TP]
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
   float *s_part = s_q + 16;              // [NW][64]
   float *s_wpad = s_part + NW * 64;      // [2][WPAD]
   float *s_G = s_wpad + 2 * WPAD;        // [62][16]  fused location filter, own dims
-  float *s_cown = s_G + 62 * 16;         // [64]      own context columns
+  float *s_cown = s_G + 62 * 16;         // [64]      own context columns (write-back only)
   float *s_e = s_cown + 64;              // [TP]      masked energies
   float *s_vv = s_e + TP;                // [16]      v, own dims
   float *s_qw = s_vv + 16;               // [8][PT] float4: query rows 16 rk + wave (+8), 4 x 16 B per lane each
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       s_hatt[b * ATT_RNN + tid + PT * h] = d.att_h[0][b * ATT_RNN + tid + PT * h];
       s_hdec[b * DEC_RNN + tid + PT * h] = d.dec_h[0][b * DEC_RNN + tid + PT * h];
     }
-    s_ctx[b * EMB + tid] = d.ctx[b * EMB + tid];
+    if (tid < TP) s_w[b * TP + tid] = tid < T ? d.aw[b * T + tid] : 0.f;  // weights of step s-1 stand for ctx(s-1)
   }
   const int cb = tid >> 2, cu = tid & 3;  // cell-update threads: tid < 4 PB -> (chunk, unit)
   const bool cell = tid < 4 * PB;
@@ -246,10 +249,6 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
   }
   int nvalid = 0, nf_r = 0;
   if (attn) {
-    for (int i = tid; i < TP * 64; i += PT) {
-      const int t = i >> 6, cc = i & 63;
-      s_mem[i] = t < T ? d.memory[((size_t)rb * T + t) * EMB + 64 * rk + cc] : 0.f;
-    }
     for (int i = tid; i < TP * 16; i += PT) {
       const int t = i >> 4, dd = i & 15;
       s_pm[i] = t < T ? d.pmem[((size_t)rb * T + t) * ATT_DIM + 16 * rk + dd] : 0.f;
@@ -259,7 +258,6 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       s_awc[tid] = tid < T ? d.awc[rb * T + tid] : 0.f;
     }
     for (int i = tid; i < 62 * 16; i += PT) s_G[i] = w.loc_fused[(size_t)(i >> 4) * ATT_DIM + 16 * rk + (i & 15)];
-    if (tid < 64) s_cown[tid] = d.ctx[rb * EMB + 64 * rk + tid];
     if (tid < 16) s_vv[tid] = w.v_w[16 * rk + tid];
 #pragma unroll
     for (int r = 0; r < 2; ++r)
@@ -281,16 +279,61 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
   const uint32_t item = d.item_base + (uint32_t)rb;
   __syncthreads();
 
+  // ---- context columns folded into the encoder memory (once per launch) -------------------------
+  // pma / pmd [b][r][h]: lane l holds  W_att / W_dec [row r of this wave][ctx cols] . memory_b[t = l + 64 h];
+  // pmp [h]: the same for this wave's projection row (projection role, chunk rb).  The ctx column blocks of wa /
+  // wd (k = 1, 2 and k = 4, 5) are dead after this loop: 32 weight registers make room for 8 PB + 2 of these.
+  float pma[PB][2][2], pmd[PB][2][2], pmp[2] = {0.f, 0.f};
+  {
+    float4 pw4 = make_float4(0.f, 0.f, 0.f, 0.f), pw5 = pw4;
+    if (prow_ok) {
+      pw4 = lds4(s_pw + 4 * (4 * PT + tid));
+      pw5 = lds4(s_pw + 4 * (5 * PT + tid));
+    }
+#pragma unroll
+    for (int b = 0; b < PB; ++b) {
+      const float4 *m4 = reinterpret_cast<const float4 *>(d.memory + (size_t)b * T * EMB);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float ra[2] = {0.f, 0.f}, rd[2] = {0.f, 0.f}, rp = 0.f;
+        for (int tt = 0; tt < 64 && tt + 64 * h < T; ++tt) {
+          const int t = tt + 64 * h;
+          const float4 m0 = m4[(size_t)t * (EMB / 4) + lane], m1 = m4[(size_t)t * (EMB / 4) + 64 + lane];
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const float va = wave_sum(dot4(wa[r][2], m1, dot4(wa[r][1], m0, 0.f)));
+            const float vd = wave_sum(dot4(wd[r][5], m1, dot4(wd[r][4], m0, 0.f)));
+            if (lane == tt) {
+              ra[r] = va;
+              rd[r] = vd;
+            }
+          }
+          if (pre && b == rb) {  // (workgroup-uniform)
+            const float vp = wave_sum(dot4(pw5, m1, dot4(pw4, m0, 0.f)));
+            if (lane == tt) rp = vp;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          pma[b][r][h] = ra[r];
+          pmd[b][r][h] = rd[r];
+        }
+        if (pre && b == rb) pmp[h] = rp;
+      }
+    }
+  }
+
   // ---- deferred pieces: everything that does not depend on the newest vector -----------------
   float aacc[PB][2], dacc[PB][2];
   auto att_bulk = [&](unsigned L4, bool all) {  // attention LSTM, columns [ctx(s-1) ; h_att(s-1)]
 #pragma unroll
     for (int b = 0; b < PB; ++b) {
       if (!all && !s_act[b]) continue;  // a stopped chunk's state is frozen
-      float a0 = 0.f, a1 = 0.f;
+      const float w0 = s_w[b * TP + (L4 >> 2)], w1 = s_w[b * TP + 64 + (L4 >> 2)];  // weights of steps lane, lane + 64
+      float a0 = fmaf(pma[b][0][1], w1, pma[b][0][0] * w0), a1 = fmaf(pma[b][1][1], w1, pma[b][1][0] * w0);
 #pragma unroll
-      for (int k = 1; k < 7; ++k) {
-        const float4 v = k < 3 ? lds4(s_ctx + b * EMB + 256 * (k - 1) + L4) : lds4(s_hatt + b * ATT_RNN + 256 * (k - 3) + L4);
+      for (int k = 3; k < 7; ++k) {
+        const float4 v = lds4(s_hatt + b * ATT_RNN + 256 * (k - 3) + L4);
         a0 = dot4(wa[0][k], v, a0);
         a1 = dot4(wa[1][k], v, a1);
       }
@@ -495,7 +538,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       }
     PROF_MARK(4);  // q + energies (attention) + dec bulk
     __builtin_amdgcn_sched_barrier(0);
-    // ---- P3 (attention role): energies of all 8 slices -> softmax -> own context columns ----------
+    // ---- P3 (attention role): energies of all 8 slices -> softmax -> the attention weights leave ----------
     if (attn && act_r) {
       {
         // all threads poll: thread -> time step tid/4, slices 2j and 2j+1 (j = tid%4); quad sum
@@ -511,62 +554,49 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       }
       __syncthreads();
       {
-        // every wave recomputes the softmax in registers (lane <-> steps lane, lane + 64), so the
-        // context partials need no second LDS round trip: weights come by readlane
+        // (every wave computes the softmax in registers, lane <-> steps lane, lane + 64; wave 0 uses it)
         const float e0 = s_e[lane], e1 = s_e[lane + 64];
         const float m = wave_max(fmaxf(e0, e1));
         const float x0 = fast_exp(e0 - m), x1 = fast_exp(e1 - m);
         const float rs = __builtin_amdgcn_rcpf(wave_sum(x0 + x1));
         const float a0 = x0 * rs, a1 = x1 * rs;
         if (wave == 0) {
+          // The chunk's eight attention workgroups hold the same weights: workgroup rk publishes steps
+          // 16 rk .. 16 rk + 15 -- sixteen consecutive lanes, ONE 128-byte store (see the x edge below)
+          const int t = lane + (rk < 4 ? 0 : 64);
+          if ((lane >> 4) == (rk & 3) && t < T) publish(g.w + (unsigned)((p * GS + rb) * TP + t), want, rk < 4 ? a0 : a1);
           s_aw[lane] = a0;
           s_awc[lane] += a0;
           s_aw[lane + 64] = a1;
           s_awc[lane + 64] += a1;
         }
-        const int ws = __builtin_amdgcn_readfirstlane(wave);
-        float acc = 0.f;  // column lane, time steps wave + 8 u (rows t >= T of s_mem are zero)
-#pragma unroll
-        for (int u = 0; u < TP / NW; ++u) {
-          const int src = __float_as_int(u < 8 ? a0 : a1);
-          const float wv = __int_as_float(__builtin_amdgcn_readlane(src, ws + NW * (u & 7)));
-          acc = fmaf(wv, s_mem[TID + NW * 64 * u], acc);
-        }
-        s_part[TID] = acc;
-      }
-      __syncthreads();
-      if (tid < 64) {
-        float v = 0.f;
-#pragma unroll
-        for (int q = 0; q < NW; ++q) v += s_part[q * 64 + TID];
-        s_cown[tid] = v;
-        publish(g.ctx + (unsigned)((p * GS + rb) * EMB + 64 * rk + tid), want, v);
       }
     }
     PROF_MARK(5);  // attention: wait e_part + softmax + ctx
     __builtin_amdgcn_sched_barrier(0);
-    // ---- P4: ctx(s) -> decoder LSTM ------------------------------------------------------------
+    // ---- P4: attention weights w(s) -> decoder LSTM (its context columns are folded into pmd) -------
     {
+      bool need[PB];
+#pragma unroll
+      for (int b = 0; b < PB; ++b) need[b] = act[b] && tid < T;
       float v[PB];
       unsigned tg[PB];
-      lazy_wait(attn ? g.first : g.clazy);  // ctx(s) cannot arrive before the attention chain has run
-      gather<PB>(g.ctx, (unsigned)(p * GS * EMB + tid), EMB, want, act, v, tg, pc);
+      lazy_wait(attn ? g.first : g.clazy);  // w(s) cannot arrive before the attention chain has run
+      if (tid < TP) {
+        gather<PB>(g.w, (unsigned)(p * GS * TP + tid), TP, want, need, v, tg, pc);
 #pragma unroll
-      for (int b = 0; b < PB; ++b)
-        if (act[b]) s_ctx[b * EMB + tid] = v[b];
+        for (int b = 0; b < PB; ++b)
+          if (need[b]) s_w[b * TP + tid] = v[b];
+      }
     }
     __syncthreads();
-    PROF_MARK(6);  // wait ctx
+    PROF_MARK(6);  // wait w
 #pragma unroll
     for (int b = 0; b < PB; ++b)
       if (act[b]) {
-        float a0 = dacc[b][0], a1 = dacc[b][1];
-#pragma unroll
-        for (int k = 4; k < 6; ++k) {
-          const float4 v = lds4(s_ctx + b * EMB + 256 * (k - 4) + L4);
-          a0 = dot4(wd[0][k], v, a0);
-          a1 = dot4(wd[1][k], v, a1);
-        }
+        const float w0 = s_w[b * TP + lane], w1 = s_w[b * TP + 64 + lane];
+        float a0 = fmaf(pmd[b][0][1], w1, fmaf(pmd[b][0][0], w0, dacc[b][0]));
+        float a1 = fmaf(pmd[b][1][1], w1, fmaf(pmd[b][1][0], w0, dacc[b][1]));
         a0 = wave_sum(a0);
         a1 = wave_sum(a1);
         if (lane == 0) {
@@ -606,8 +636,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       float a = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) a = dot4(lds4(s_pw + 4 * (j * PT + TID)), lds4(s_hdec + rb * DEC_RNN + 256 * j + L4), a);
-#pragma unroll
-      for (int j = 4; j < 6; ++j) a = dot4(lds4(s_pw + 4 * (j * PT + TID)), lds4(s_ctx + rb * EMB + 256 * (j - 4) + L4), a);
+      a = fmaf(pmp[1], s_w[rb * TP + 64 + lane], fmaf(pmp[0], s_w[rb * TP + lane], a));  // the context columns
       a = wave_sum(a);
       if (lane == 0) publish(g.mel + (unsigned)((p * GS + rb) * MEL_GL + prow), want, a + s_pb[wave]);
     }
@@ -706,7 +735,21 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
     d.dec_h[0][cb * DEC_RNN + 4 * c + cu] = s_cell[12 * PB + tid];
   }
   if (attn) {
-    if (tid < 64) d.ctx[rb * EMB + 64 * rk + tid] = s_cown[tid];
+    // the context of the last step, for the state only: own 64 columns = sum_t w_t memory[t]
+    {
+      const int col = tid & 63, q = tid >> 6;
+      float acc = 0.f;
+      for (int t = q; t < T; t += NW) acc = fmaf(s_aw[t], d.memory[((size_t)rb * T + t) * EMB + 64 * rk + col], acc);
+      __syncthreads();
+      s_part[tid] = acc;
+      __syncthreads();
+      if (tid < 64) {
+        float v = 0.f;
+#pragma unroll
+        for (int u = 0; u < NW; ++u) v += s_part[u * 64 + tid];
+        d.ctx[rb * EMB + 64 * rk + tid] = v;
+      }
+    }
     if (rk == 0 && tid < T) {
       d.aw[rb * T + tid] = s_aw[tid];
       d.awc[rb * T + tid] = s_awc[tid];
@@ -730,7 +773,7 @@ void launch_pb(const DecoderBufs &d, const PersistBufs &g, const PersistWeights 
 
 size_t persist_granule_words(int B) {
   (void)B;
-  return (size_t)2 * GS * (PRENET + ATT_RNN + ATTN_CU * EP_LD + EMB + DEC_RNN + MEL_GL);
+  return (size_t)2 * GS * (PRENET + ATT_RNN + ATTN_CU * EP_LD + TP + DEC_RNN + MEL_GL);
 }
 
 PersistBufs persist_bufs(unsigned long long *base, int *err, int B) {
@@ -739,8 +782,8 @@ PersistBufs persist_bufs(unsigned long long *base, int *err, int B) {
   (void)B;
   g.hatt = g.x + (size_t)2 * GS * PRENET;
   g.ep = g.hatt + (size_t)2 * GS * ATT_RNN;
-  g.ctx = g.ep + (size_t)2 * GS * ATTN_CU * EP_LD;
-  g.hdec = g.ctx + (size_t)2 * GS * EMB;
+  g.w = g.ep + (size_t)2 * GS * ATTN_CU * EP_LD;
+  g.hdec = g.w + (size_t)2 * GS * TP;
   g.mel = g.hdec + (size_t)2 * GS * DEC_RNN;
   g.err = err;
   g.lazy = PERSIST_LAZY_DEFAULT;
@@ -757,7 +800,7 @@ PersistBufs persist_view(const PersistBufs &g, int b0) {
   v.x += (size_t)b0 * PRENET;
   v.hatt += (size_t)b0 * ATT_RNN;
   v.ep += (size_t)b0 * ATTN_CU * EP_LD;
-  v.ctx += (size_t)b0 * EMB;
+  v.w += (size_t)b0 * TP;
   v.hdec += (size_t)b0 * DEC_RNN;
   v.mel += (size_t)b0 * MEL_GL;
   return v;
