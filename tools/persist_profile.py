@@ -22,7 +22,7 @@ for _ in range(2):
 t = m.last_timings()
 print("B=%d: %.2f us/step" % (B, t["decoder_ms"] * 1e3 / steps))
 a = np.loadtxt(path)[:, :11] / 100.0 / steps  # 100 MHz clock -> us per step
-names = ["loop", "wait x", "att tail", "wait h_att", "q+energies/bulk", "softmax+ctx", "wait ctx", "dec tail+bulk", "wait h_dec", "proj/bulk/loc", "prenet"]
+names = ["loop", "wait x", "att tail", "wait h_att", "q+energies/bulk", "wait energies", "softmax", "dec tail+bulk", "wait h_dec", "proj/bulk/loc", "prenet"]
 roles = {"attn c0": slice(0, 8), "pre c0": slice(8 * B, 8 * B + 16), "plain": slice(24 * B, 256)}
 if B > 1:
     roles["attn c1"] = slice(8, 16)

@@ -7,12 +7,14 @@
 // attention-LSTM units 4c..4c+3 and of decoder-LSTM units 4c..4c+3 in its register file for the
 // whole utterance (8 waves x 64 lanes x 136 VGPRs = 272 KB per CU), wave w owning gate rows w and
 // w + 8 of each (16 waves x 68 VGPRs leaves too few working registers under the 128-VGPR cap).  What crosses CUs per step is only the state: six all-gather edges
-//     x (256 values) -> all      h_att (1024) -> all      partial energies (8 x T) -> 8
-//     attention weights (T) -> all    h_dec (1024) -> all      mel + gate (81) -> 16
-// (the attention CONTEXT never crosses: every consumer of it is linear in it, so each workgroup folds its own
-// context columns into the encoder memory once per launch -- P[row][t] = W[row][ctx cols] . memory[t] -- and
-// takes  sum_t w_t P[row][t]  instead of  W[row][ctx cols] . (sum_t w_t memory[t]);  the T weights leave the
-// attention role right after the softmax, the context sum itself is off the step's critical path altogether)
+//     x (256 values) -> all      h_att (1024) -> all      partial energies (8 x T) -> all
+//     h_dec (1024) -> all        mel + gate (81) -> 16
+// -- five all-gather edges.  Neither the attention CONTEXT nor the attention WEIGHTS cross: every consumer of the
+// context is linear in it, so each workgroup folds its own context columns into the encoder memory once per launch
+// -- P[row][t] = W[row][ctx cols] . memory[t] -- and takes  sum_t w_t P[row][t]  instead of
+// W[row][ctx cols] . (sum_t w_t memory[t]);  and the weights w are a 100-element softmax that EVERY workgroup
+// computes for itself from the partial energies it gathers anyway (lane <-> steps lane, lane + 64: exactly the
+// registers the folded products need), which is cheaper than a sixth edge to broadcast them.
 // carried by data-tagged 8-byte granules {tag = step + 1, value} (one relaxed agent-scope store per
 // value; readers re-read until the tag matches -- MI355X_MICROARCH.md hand-off recipe R2, the
 // scheme the encoder BiLSTM already uses): no flags, no fences, placement-independent.  Two slots
@@ -135,7 +137,7 @@ __device__ __forceinline__ unsigned opaque(unsigned v) {
 
 constexpr int persist_lds_floats(int pb) {
   const int common = pb * (PRENET + TP + ATT_RNN + DEC_RNN + 16) + 8 + 32 + 16 * pb;
-  const int attn = 2 * TP * 16 + 2 * TP + 16 + NW * 64 + 2 * WPAD + 62 * 16 + 64 + TP + 16 + 8 * PT * 4;
+  const int attn = 2 * TP * 16 + 2 * TP + 16 + NW * 64 + 2 * WPAD + 62 * 16 + 64 + 16 + 8 * PT * 4;
   const int pre = N_MEL * PRENET + MEL_GL + 2 * PRENET + 8 + 6 * PT * 4;
   return common + (attn > pre ? attn : pre);
 }
@@ -172,8 +174,8 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
   const unsigned L4 = opaque(4u * (unsigned)lane);
   // ---- LDS: state vectors of all chunks, then the role's working set -------------------------
   float *s_x = smem;                     // [PB][256]
-  float *s_w = s_x + PB * PRENET;        // [PB][TP]  attention weights of the current step (zero from T on)
-  float *s_hatt = s_w + PB * TP;         // [PB][1024]
+  float *s_e = s_x + PB * PRENET;        // [PB][TP]  masked energies of the current step (-inf from T / n_valid on)
+  float *s_hatt = s_e + PB * TP;         // [PB][1024]
   float *s_hdec = s_hatt + PB * ATT_RNN; // [PB][1024]
   float *s_g = s_hdec + PB * DEC_RNN;    // [PB][16] gate pre-activations of this workgroup's rows
   int *s_act = reinterpret_cast<int *>(s_g + PB * 16);  // [0..1] active at this step, [2..3] alive: not yet seen inactive, [4] error word
@@ -190,8 +192,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
   float *s_wpad = s_part + NW * 64;      // [2][WPAD]
   float *s_G = s_wpad + 2 * WPAD;        // [62][16]  fused location filter, own dims
   float *s_cown = s_G + 62 * 16;         // [64]      own context columns (write-back only)
-  float *s_e = s_cown + 64;              // [TP]      masked energies
-  float *s_vv = s_e + TP;                // [16]      v, own dims
+  float *s_vv = s_cown + 64;             // [16]      v, own dims
   float *s_qw = s_vv + 16;               // [8][PT] float4: query rows 16 rk + wave (+8), 4 x 16 B per lane each
   // projection + prenet role
   float *s_W0 = role;                    // [80][256]
@@ -237,7 +238,16 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       s_hatt[b * ATT_RNN + tid + PT * h] = d.att_h[0][b * ATT_RNN + tid + PT * h];
       s_hdec[b * DEC_RNN + tid + PT * h] = d.dec_h[0][b * DEC_RNN + tid + PT * h];
     }
-    if (tid < TP) s_w[b * TP + tid] = tid < T ? d.aw[b * T + tid] : 0.f;  // weights of step s-1 stand for ctx(s-1)
+  }
+  // attention weights of the chunks, lane <-> steps lane and lane + 64 (zero from T on): the weights of step s-1
+  // stand for ctx(s-1) at the start, every step's softmax replaces them
+  float wreg[PB][2];
+  int nv[PB];
+#pragma unroll
+  for (int b = 0; b < PB; ++b) {
+    wreg[b][0] = lane < T ? d.aw[b * T + lane] : 0.f;
+    wreg[b][1] = lane + 64 < T ? d.aw[b * T + lane + 64] : 0.f;
+    nv[b] = d.n_valid[b];
   }
   const int cb = tid >> 2, cu = tid & 3;  // cell-update threads: tid < 4 PB -> (chunk, unit)
   const bool cell = tid < 4 * PB;
@@ -247,7 +257,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
     s_cell[8 * PB + tid] = d.att_h[0][cb * ATT_RNN + 4 * c + cu];
     s_cell[12 * PB + tid] = d.dec_h[0][cb * DEC_RNN + 4 * c + cu];
   }
-  int nvalid = 0, nf_r = 0;
+  int nf_r = 0;
   if (attn) {
     for (int i = tid; i < TP * 16; i += PT) {
       const int t = i >> 4, dd = i & 15;
@@ -264,7 +274,6 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         *reinterpret_cast<float4 *>(s_qw + 4 * ((4 * r + j) * PT + tid)) = w.q_w[(unsigned)((16 * rk + wave + NW * r) * (ATT_RNN / 4) + lane + 64 * j)];
-    nvalid = d.n_valid[rb];
   }
   if (pre) {
     for (int i = tid; i < N_MEL * PRENET; i += PT) s_W0[i] = w.pre0T[i];
@@ -329,7 +338,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
 #pragma unroll
     for (int b = 0; b < PB; ++b) {
       if (!all && !s_act[b]) continue;  // a stopped chunk's state is frozen
-      const float w0 = s_w[b * TP + (L4 >> 2)], w1 = s_w[b * TP + 64 + (L4 >> 2)];  // weights of steps lane, lane + 64
+      const float w0 = wreg[b][0], w1 = wreg[b][1];
       float a0 = fmaf(pma[b][0][1], w1, pma[b][0][0] * w0), a1 = fmaf(pma[b][1][1], w1, pma[b][1][0] * w0);
 #pragma unroll
       for (int k = 3; k < 7; ++k) {
@@ -538,63 +547,50 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       }
     PROF_MARK(4);  // q + energies (attention) + dec bulk
     __builtin_amdgcn_sched_barrier(0);
-    // ---- P3 (attention role): energies of all 8 slices -> softmax -> the attention weights leave ----------
-    if (attn && act_r) {
-      {
-        // all threads poll: thread -> time step tid/4, slices 2j and 2j+1 (j = tid%4); quad sum
-        const int t = tid >> 2, j = tid & 3;
-        const bool need[2] = {t < T, t < T};
-        float v[2];
-        unsigned tg[2];
-        gather<2>(g.ep, (unsigned)(((p * GS + rb) * ATTN_CU + 2 * j) * EP_LD + t), EP_LD, want, need, v, tg, pc);
-        float e = v[0] + v[1];
+    // ---- P3 (every workgroup): partial energies of the 8 slices of every chunk -> softmax -> weights in registers ----
+    {
+      // all threads poll: thread -> time step tid / 4, slices j and j + 4 (j = tid % 4) of every active chunk; quad sum
+      const int t = tid >> 2, j = tid & 3;
+      bool need[2 * PB];
+#pragma unroll
+      for (int i = 0; i < 2 * PB; ++i) need[i] = act[i >> 1] && t < T;
+      float v[2 * PB];
+      unsigned tg[2 * PB];
+      lazy_wait(attn ? g.first : g.clazy);  // the energies cannot arrive before the attention role has run
+      gather<2 * PB>(g.ep, (unsigned)((p * GS * ATTN_CU + j) * EP_LD + t), 4u * EP_LD, want, need, v, tg, pc);
+#pragma unroll
+      for (int b = 0; b < PB; ++b) {
+        float e = v[2 * b] + v[2 * b + 1];
         e += dpp_move<0xB1, 0xf>(0.f, e);  // quad_perm:[1,0,3,2]
         e += dpp_move<0x4E, 0xf>(0.f, e);  // quad_perm:[2,3,0,1]
-        if (j == 0) s_e[t] = (t < T && t < nvalid) ? e : -INFINITY;  // mask, mod.rs:219-220
-      }
-      __syncthreads();
-      {
-        // (every wave computes the softmax in registers, lane <-> steps lane, lane + 64; wave 0 uses it)
-        const float e0 = s_e[lane], e1 = s_e[lane + 64];
-        const float m = wave_max(fmaxf(e0, e1));
-        const float x0 = fast_exp(e0 - m), x1 = fast_exp(e1 - m);
-        const float rs = __builtin_amdgcn_rcpf(wave_sum(x0 + x1));
-        const float a0 = x0 * rs, a1 = x1 * rs;
-        if (wave == 0) {
-          // The chunk's eight attention workgroups hold the same weights: workgroup rk publishes steps
-          // 16 rk .. 16 rk + 15 -- sixteen consecutive lanes, ONE 128-byte store (see the x edge below)
-          const int t = lane + (rk < 4 ? 0 : 64);
-          if ((lane >> 4) == (rk & 3) && t < T) publish(g.w + (unsigned)((p * GS + rb) * TP + t), want, rk < 4 ? a0 : a1);
-          s_aw[lane] = a0;
-          s_awc[lane] += a0;
-          s_aw[lane + 64] = a1;
-          s_awc[lane + 64] += a1;
-        }
-      }
-    }
-    PROF_MARK(5);  // attention: wait e_part + softmax + ctx
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- P4: attention weights w(s) -> decoder LSTM (its context columns are folded into pmd) -------
-    {
-      bool need[PB];
-#pragma unroll
-      for (int b = 0; b < PB; ++b) need[b] = act[b] && tid < T;
-      float v[PB];
-      unsigned tg[PB];
-      lazy_wait(attn ? g.first : g.clazy);  // w(s) cannot arrive before the attention chain has run
-      if (tid < TP) {
-        gather<PB>(g.w, (unsigned)(p * GS * TP + tid), TP, want, need, v, tg, pc);
-#pragma unroll
-        for (int b = 0; b < PB; ++b)
-          if (need[b]) s_w[b * TP + tid] = v[b];
+        if (j == 0 && act[b]) s_e[b * TP + t] = (t < T && t < nv[b]) ? e : -INFINITY;  // mask, mod.rs:219-220
       }
     }
     __syncthreads();
-    PROF_MARK(6);  // wait w
+    PROF_MARK(5);  // wait e_part
+#pragma unroll
+    for (int b = 0; b < PB; ++b)
+      if (act[b]) {  // every wave: the softmax in registers, lane <-> steps lane, lane + 64
+        const float e0 = s_e[b * TP + lane], e1 = s_e[b * TP + lane + 64];
+        const float m = wave_max(fmaxf(e0, e1));
+        const float x0 = fast_exp(e0 - m), x1 = fast_exp(e1 - m);
+        const float rs = __builtin_amdgcn_rcpf(wave_sum(x0 + x1));
+        wreg[b][0] = x0 * rs;
+        wreg[b][1] = x1 * rs;
+      }
+    if (attn && act_r && wave == 0) {  // the attention role keeps them for the next step's location features
+      s_aw[lane] = wreg[rb][0];
+      s_awc[lane] += wreg[rb][0];
+      s_aw[lane + 64] = wreg[rb][1];
+      s_awc[lane + 64] += wreg[rb][1];
+    }
+    PROF_MARK(6);  // softmax
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- P4: decoder LSTM (its context columns are folded into pmd) -----------------------------------
 #pragma unroll
     for (int b = 0; b < PB; ++b)
       if (act[b]) {
-        const float w0 = s_w[b * TP + lane], w1 = s_w[b * TP + 64 + lane];
+        const float w0 = wreg[b][0], w1 = wreg[b][1];
         float a0 = fmaf(pmd[b][0][1], w1, fmaf(pmd[b][0][0], w0, dacc[b][0]));
         float a1 = fmaf(pmd[b][1][1], w1, fmaf(pmd[b][1][0], w0, dacc[b][1]));
         a0 = wave_sum(a0);
@@ -636,7 +632,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       float a = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) a = dot4(lds4(s_pw + 4 * (j * PT + TID)), lds4(s_hdec + rb * DEC_RNN + 256 * j + L4), a);
-      a = fmaf(pmp[1], s_w[rb * TP + 64 + lane], fmaf(pmp[0], s_w[rb * TP + lane], a));  // the context columns
+      a = fmaf(pmp[1], wreg[rb][1], fmaf(pmp[0], wreg[rb][0], a));  // the context columns
       a = wave_sum(a);
       if (lane == 0) publish(g.mel + (unsigned)((p * GS + rb) * MEL_GL + prow), want, a + s_pb[wave]);
     }
@@ -773,7 +769,7 @@ void launch_pb(const DecoderBufs &d, const PersistBufs &g, const PersistWeights 
 
 size_t persist_granule_words(int B) {
   (void)B;
-  return (size_t)2 * GS * (PRENET + ATT_RNN + ATTN_CU * EP_LD + TP + DEC_RNN + MEL_GL);
+  return (size_t)2 * GS * (PRENET + ATT_RNN + ATTN_CU * EP_LD + DEC_RNN + MEL_GL);
 }
 
 PersistBufs persist_bufs(unsigned long long *base, int *err, int B) {
@@ -782,8 +778,7 @@ PersistBufs persist_bufs(unsigned long long *base, int *err, int B) {
   (void)B;
   g.hatt = g.x + (size_t)2 * GS * PRENET;
   g.ep = g.hatt + (size_t)2 * GS * ATT_RNN;
-  g.w = g.ep + (size_t)2 * GS * ATTN_CU * EP_LD;
-  g.hdec = g.w + (size_t)2 * GS * TP;
+  g.hdec = g.ep + (size_t)2 * GS * ATTN_CU * EP_LD;
   g.mel = g.hdec + (size_t)2 * GS * DEC_RNN;
   g.err = err;
   g.lazy = PERSIST_LAZY_DEFAULT;
@@ -800,7 +795,6 @@ PersistBufs persist_view(const PersistBufs &g, int b0) {
   v.x += (size_t)b0 * PRENET;
   v.hatt += (size_t)b0 * ATT_RNN;
   v.ep += (size_t)b0 * ATTN_CU * EP_LD;
-  v.w += (size_t)b0 * TP;
   v.hdec += (size_t)b0 * DEC_RNN;
   v.mel += (size_t)b0 * MEL_GL;
   return v;

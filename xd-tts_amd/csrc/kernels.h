@@ -59,7 +59,7 @@ constexpr int PERSIST_B_MAX = 2;    // chunks in lock-step (register file + LDS 
 constexpr int PERSIST_T_MAX = 128;  // encoder steps (the reference's window is 100, mod.rs:363)
 // Granule exchange buffers: 8-byte {tag, value} records, [2 step parities][B][n] each.
 struct PersistBufs {
-  unsigned long long *x, *hatt, *ep, *w, *hdec, *mel;  // (w: the attention weights; the context itself never crosses)
+  unsigned long long *x, *hatt, *ep, *hdec, *mel;  // (neither the context nor the attention weights cross)
   int *err;  // set by a workgroup whose bounded spin ran out
   int spins, fault;  // developer/test knobs: poll limit (0 = default) and a workgroup (index + 1) that never runs
   int shrink;  // 2-chunk launch: end as soon as one chunk stops (the host continues with a 1-chunk launch)
