@@ -247,8 +247,8 @@ def main():
             "traffic_source": traffic_src,
             # the weights stay in registers, so `achieved` is ALGORITHMIC bytes per second (every parameter
             # counted once per step as SURVEY 8(d) defines), not bytes moved: what limits the kernel in
-            # practice is the latency of the 6 state-exchange edges per step
-            "limiter": "inter-CU exchange latency (6 all-gather edges per step), not HBM bandwidth",
+            # practice is the latency of the 5 state-exchange edges per step
+            "limiter": "inter-CU exchange latency (5 all-gather edges per step), not HBM bandwidth",
             "hbm_traffic_GBs": (traffic / (dec_ms / K * 1e-3) / 1e9) if traffic else None,
             "us_per_launch": dec_ms / K * 1e3,
             "algorithmic_bytes_per_launch": bytes_per_utt,

@@ -6,36 +6,36 @@
 // never move: 256 workgroups, one per CU, 512 threads each; workgroup c keeps the 16 gate rows of
 // attention-LSTM units 4c..4c+3 and of decoder-LSTM units 4c..4c+3 in its register file for the
 // whole utterance (8 waves x 64 lanes x 136 VGPRs = 272 KB per CU), wave w owning gate rows w and
-// w + 8 of each (16 waves x 68 VGPRs leaves too few working registers under the 128-VGPR cap).  What crosses CUs per step is only the state: six all-gather edges
+// w + 8 of each (16 waves x 68 VGPRs leaves too few working registers under the 128-VGPR cap).
+// What crosses CUs per step is only the state, FIVE all-gather edges:
 //     x (256 values) -> all      h_att (1024) -> all      partial energies (8 x T) -> all
 //     h_dec (1024) -> all        mel + gate (81) -> 16
-// -- five all-gather edges.  Neither the attention CONTEXT nor the attention WEIGHTS cross: every consumer of the
-// context is linear in it, so each workgroup folds its own context columns into the encoder memory once per launch
-// -- P[row][t] = W[row][ctx cols] . memory[t] -- and takes  sum_t w_t P[row][t]  instead of
-// W[row][ctx cols] . (sum_t w_t memory[t]);  and the weights w are a 100-element softmax that EVERY workgroup
-// computes for itself from the partial energies it gathers anyway (lane <-> steps lane, lane + 64: exactly the
-// registers the folded products need), which is cheaper than a sixth edge to broadcast them.
 // carried by data-tagged 8-byte granules {tag = step + 1, value} (one relaxed agent-scope store per
 // value; readers re-read until the tag matches -- MI355X_MICROARCH.md hand-off recipe R2, the
 // scheme the encoder BiLSTM already uses): no flags, no fences, placement-independent.  Two slots
 // per value by step parity; a slot is rewritten two steps later, after every reader has passed an
-// all-to-all dependency on its producer.  tools/ubench_edges.hip measures the skeleton (edges
+// all-to-all dependency on its producer.  tools/ubench_edges.hip measures a six-edge skeleton (edges
 // only): 10.8 us per step = 1.8 us per edge.
+// Neither the attention CONTEXT nor the attention WEIGHTS cross (round 1 had a sixth edge for the context):
+//   * every consumer of the context is linear in it, so each workgroup folds its own context columns into the
+//     encoder memory once per launch -- P[row][t] = W[row][ctx cols] . memory[t], lane <-> steps lane, lane + 64 --
+//     and takes  sum_t w_t P[row][t]  instead of  W[row][ctx cols] . (sum_t w_t memory[t]);
+//   * the weights w are a 100-element softmax that EVERY workgroup computes for itself from the partial energies
+//     (it lands in exactly the registers the folded products need), which is cheaper than an edge to broadcast them.
 //
 // Roles on top of the LSTM slices (disjoint workgroups, per chunk b):
-//   attention, 8 per chunk: 16 of the 128 attention dims each -- query rows in registers, its
-//     [T][64] slice of the encoder memory and [T][16] of processed_memory in LDS; partial
-//     energies -> (edge) -> masked softmax (every one of the 8 recomputes it) -> 64 context
-//     columns; afterwards, off the critical path, the NEXT step's location features for its dims
-//     with the conv(2->32,k31) and dense(32->128) folded into one 62-tap filter per dim;
-//   projection + prenet, 16 per chunk: 5-6 rows of [W_p ; w_gate] in registers -> mel -> (edge)
+//   attention, 8 per chunk: 16 of the 128 attention dims each -- query rows and [T][16] of processed_memory in
+//     LDS; partial energies -> (edge, to everybody); afterwards, off the critical path, the NEXT step's location
+//     features for its dims with the conv(2->32,k31) and dense(32->128) folded into one 62-tap filter per dim;
+//     the context itself is formed once, at the end of the launch, for the state that is written back;
+//   projection + prenet, 16 per chunk: 5-6 rows of [W_p ; w_gate] -> mel -> (edge among the 16)
 //     -> frame store, gate, stop rule (mod.rs:319-324), prenet layer 1 (recomputed by all 16, W0 in
 //     LDS), 16 layer-2 columns -> x(s+1).  The x granules carry the chunk's "still active" bit, so
 //     every workgroup learns of a stop with the data it waits for anyway, and the launch ends by
 //     itself when no chunk is active.
-// Only the column blocks that depend on the newest vector sit on the critical path (x for the
-// attention LSTM, ctx for the decoder LSTM); the other column blocks are accumulated per lane
-// while the producers of the next vector are busy, and one DPP wave reduction closes each row.
+// Only the pieces that depend on the newest vector sit on the critical path (x for the attention LSTM, the
+// softmax for the decoder LSTM); the other column blocks are accumulated per lane while the producers of the
+// next vector are busy, and one DPP wave reduction closes each row.
 //
 // Every spin is bounded and watches a global error word: a lost workgroup (grid not co-resident)
 // drains the whole launch in microseconds and surfaces as XDTTS_ERR_HIP on the host.
