@@ -266,13 +266,28 @@ def main():
         all_utts = wl.config4(pkg, n_batches=world)
         share, chunks, steps, owner = shard.plan_share(lambda ids: wl.chunk_utterance(pkg, ids), all_utts, rank, world, wl.FRAMES_PER_ID_BATCH)
         bo = pkg.default_opts(dropout_seed=1, item_base=0)
-        shard.run_share(model, vocoder, share, chunks, steps, owner, bo)      # warm-up
+        # A rank that fails here must still meet the others at the barriers and in the all-gather (the headline
+        # line is already measured and has to be printed): its share then counts as failed, seconds = -1.
+        res, share_err = None, None
+        try:
+            shard.run_share(model, vocoder, share, chunks, steps, owner, bo)      # warm-up
+        except Exception as e:  # noqa: BLE001
+            share_err = repr(e)
         barrier()
-        res = shard.run_share(model, vocoder, share, chunks, steps, owner, bo)
+        if share_err is None:
+            try:
+                res = shard.run_share(model, vocoder, share, chunks, steps, owner, bo)
+            except Exception as e:  # noqa: BLE001
+                share_err = repr(e)
         barrier()
-        log("config3/4 share done")
+        log("config3/4 share done" if share_err is None else "config3/4 share FAILED: " + share_err)
+        counters = res if res is not None else {"frames": 0, "samples": 0, "seconds": -1.0}
+        totals, max_s, per_rank = shard.gather_counters(counters, dist, device=red_dev if dist else "cpu")
+        share_ok = all(r["seconds"] >= 0 for r in per_rank)
+    if not args.no_extras and not share_ok:
+        extra["config3"] = extra["config4"] = {"error": "a rank's share failed", "this_rank": share_err, "per_rank": per_rank}
+    if not args.no_extras and share_ok:
         fr, t_mel, tm, voc_ms = res["frames"], res["mel_gen_seconds"], res["timings"], res["vocoder_seconds"] * 1e3
-        totals, max_s, per_rank = shard.gather_counters(res, dist, device=red_dev if dist else "cpu")
         it = tm["steps"]
         act = float(sum(steps))                                                    # active chunk-steps of this rank
         dsec = tm["decoder_ms"] * 1e-3
@@ -303,8 +318,10 @@ def main():
             "vocoder_ms_this_rank": voc_ms,
             "per_rank": per_rank,
         }
+    if not args.no_extras:
         # ---- configs[4]: Griffin-Lim only, 1000 frames ------------------------------------------------
         if rank == 0:
+          try:
             rng = np.random.default_rng(5)
             F5 = 1000
             S5 = np.abs(rng.standard_normal((513, F5))).astype(np.float32)   # timing does not depend on the values
@@ -320,11 +337,16 @@ def main():
             c5["note"] = "state (S, angles, previous spectrum) lives in LDS for the whole call, so `achieved` is algorithmic bytes per second (12 308 B per frame per iteration, SURVEY 8d); measured HBM traffic: profiles/"
             extra["config5"] = c5
             log("config5 done")
+          except Exception as e:  # noqa: BLE001  (the headline line must still be printed)
+            extra["config5"] = {"error": repr(e)}
         out["extra"] = extra
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+            except Exception as e:  # noqa: BLE001
+                out["cpu_baseline"] = {"error": repr(e)}
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
