@@ -288,8 +288,146 @@ __global__ __launch_bounds__(256) void k_prenet(DecoderBufs d, int i, int flush,
 // Here a chunk is PRENET_SPLIT blocks of 1024 threads: the partial rows, W0 and half of W1 are read
 // once per block (22 MB per step in total), all of them in flight at kernel entry.
 constexpr int PRENET_SPLIT = 2, PRENET_BT = 1024;
+// Batched mode: the location features of step s depend only on the attention weights of step s-1, so they ride along
+// in the prenet launch of step s as extra 1024-thread blocks (the prenet occupies 2 B of the 256 CUs for ~6 us): a
+// block takes eight 8-step tiles of one chunk, four at a time, one per 256-thread group (two blocks per 100-step
+// chunk: with the prenet's two that is 4 B blocks of 1024 threads, one round on 256 CUs up to 64 chunks).  As the tail of the context kernel -- where
+// they were first -- they cost every lock-step iteration 5 us (94 weight registers per thread and two to four
+// barrier rounds on its critical path).
+__device__ __forceinline__ int loc_blocks_per_chunk(int T) { return ((T + LOC_TT - 1) / LOC_TT + 7) / 8; }
+__device__ __forceinline__ void location_blocks(const DecoderBufs &d, int i, int lb, const float *__restrict__ loc_convT,
+                                                const float *__restrict__ loc_denseT) {
+  constexpr int TT = LOC_TT, PADK = (LOC_K - 1) / 2;
+  const int T = d.T, per = loc_blocks_per_chunk(T), b = lb / per;
+  const int tid = threadIdx.x, gq = tid >> 8, ltid = tid & 255;
+  const int step = d.ctl[0] + i;
+  const bool act = step < d.nframes[b];
+  // the weights of step s-1: aw, and the cumulative ones the previous node's context kernel wrote (ping-pong by parity);
+  // the whole chunk's go to LDS first -- loads retire in issue order, and the 94 filter weights below are slower
+  const float *aw = d.aw + b * T, *awc = ((i & 1) ? d.awc2 : d.awc) + b * T;
+  __shared__ __attribute__((aligned(16))) float s_aw[2][T_MAX + 2 * PADK], s_lc[4][TT][LOC_F];
+  for (int k = tid; k < 2 * (T + 2 * PADK); k += PRENET_BT) {
+    const int c = k / (T + 2 * PADK), t = k % (T + 2 * PADK) - PADK;
+    s_aw[c][t + PADK] = (t >= 0 && t < T) ? (c ? awc[t] : aw[t]) : 0.f;  // zero-padded: channel 0 = previous weights, 1 = cumulative
+  }
+  LocWeights lw;
+  location_weights(lw, loc_convT, loc_denseT);  // (filter tid & 31, dim tid & 127: the same within every 256-thread group)
+  __syncthreads();
+  const int f = ltid & 31, tl = ltid >> 5;   // conv role: one (t, filter) output per thread
+  const int a = ltid & 127, th = ltid >> 7;  // dense role: attention dim a, 4 time steps
+#pragma unroll
+  for (int round = 0; round < 2; ++round) {
+    const int tile = 8 * (lb % per) + 4 * round + gq, t0 = tile * TT;
+    const bool on = act && t0 < T;
+    if (round) __syncthreads();  // the first round's readers are done with s_lc
+    if (on) {  // the window of output step t0 + tl starts at padded index t0 + tl
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < LOC_K; ++k) acc = fmaf(lw.cw[k], s_aw[0][t0 + tl + k], acc);
+#pragma unroll
+      for (int k = 0; k < LOC_K; ++k) acc = fmaf(lw.cw[LOC_K + k], s_aw[1][t0 + tl + k], acc);
+      s_lc[gq][tl][f] = acc;
+    }
+    __syncthreads();
+    if (on) {
+#pragma unroll
+      for (int q = 0; q < TT / 2; ++q) {
+        const int tloc = th * (TT / 2) + q, t = t0 + tloc;
+        if (t >= T) break;
+        float acc = 0.f;
+#pragma unroll
+        for (int g = 0; g < LOC_F; g += 4) {  // (one 16-byte broadcast read per four products: the block is LDS-issue bound)
+          const float4 lc = *reinterpret_cast<const float4 *>(&s_lc[gq][tloc][g]);
+          acc = fmaf(lw.wd[g], lc.x, acc);
+          acc = fmaf(lw.wd[g + 1], lc.y, acc);
+          acc = fmaf(lw.wd[g + 2], lc.z, acc);
+          acc = fmaf(lw.wd[g + 3], lc.w, acc);
+        }
+        d.loc[((size_t)b * T + t) * ATT_DIM + a] = acc;
+      }
+    }
+  }
+}
+// The same for T <= LOC_MFMA_T (the reference's window is 100) on the matrix cores, ONE block per chunk: both layers
+// are GEMMs over the chunk's time steps --  lc[T][32] = im2col(w_prev, w_cum)[T][62] . conv[62][32]  and
+// loc[T][128] = lc[T][32] . dense[32][128]  -- 224 + 448 v_mfma_f32_16x16x4_f32 per chunk against 608 k FMAs that each
+// need an LDS operand (measured: the FMA form keeps a 1024-thread block busy for ~5 us, longer than the prenet it
+// rides with).  Operands come from LDS: lane l of an A fragment is (row l % 16, k l / 16), of a B fragment
+// (k l / 16, column l % 16); a D register r of lane l is (row 4 (l / 16) + r, column l % 16).
+constexpr int LOC_MFMA_T = 128;
+__device__ __forceinline__ void location_chunk_mfma(const DecoderBufs &d, int i, int b, const float *__restrict__ loc_convT,
+                                                    const float *__restrict__ loc_denseT) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  constexpr int PADK = (LOC_K - 1) / 2, KC = 64;  // conv contraction: 2 x 31 taps, padded to 64
+  const int T = d.T, MT = (T + 15) / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fi = lane & 15, fg = lane >> 4;
+  __shared__ __attribute__((aligned(16))) float s_aw[2][LOC_MFMA_T + 2 * PADK + 2], s_cw[KC][LOC_F + 1], s_wd[LOC_F][ATT_DIM], s_lc[LOC_MFMA_T][LOC_F + 1];  // (+1: fragment reads walk the rows)
+  const int step = d.ctl[0] + i;
+  const bool act = step < d.nframes[b];
+  const float *aw = d.aw + b * T, *awc = ((i & 1) ? d.awc2 : d.awc) + b * T;  // weights of step s-1 (cumulative: ping-pong by parity)
+  constexpr int SZ = LOC_MFMA_T + 2 * PADK + 2;
+  for (int k = tid; k < 2 * SZ; k += PRENET_BT) {
+    const int c = k / SZ, t = k % SZ - PADK;
+    s_aw[c][t + PADK] = (t >= 0 && t < T) ? (c ? awc[t] : aw[t]) : 0.f;  // zero-padded: channel 0 = previous weights, 1 = cumulative
+  }
+  for (int k = tid; k < KC * LOC_F; k += PRENET_BT) s_cw[k / LOC_F][k % LOC_F] = k < 2 * LOC_K * LOC_F ? loc_convT[k] : 0.f;  // [c][k][f]; rows 62, 63 zero
+  for (int k = tid; k < LOC_F * ATT_DIM; k += PRENET_BT) s_wd[0][k] = loc_denseT[k];                             // [f][a]
+  __syncthreads();
+  if (!act) return;  // (block-uniform)
+  // ---- conv: (time tile mt, filter tile nt) per wave ----
+  for (int tp = wave; tp < 2 * MT; tp += PRENET_BT / 64) {
+    const int mt = tp >> 1, nt = tp & 1;
+    f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;  // two chains: a dependent MFMA waits ~40 cycles
+#pragma unroll
+    for (int ks = 0; ks < KC / 4; ++ks) {
+      const int kk = 4 * ks + fg, c = kk >= LOC_K, k = kk - (c ? LOC_K : 0);  // (kk = 62, 63: c = 1, k = 31, 32 -- weight rows are zero)
+      const float av = s_aw[c][16 * mt + fi + k];
+      const float bv = s_cw[kk][16 * nt + fi];
+      if (ks & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc1, 0, 0, 0);
+      else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s_lc[16 * mt + 4 * fg + r][16 * nt + fi] = acc0[r] + acc1[r];
+  }
+  __syncthreads();
+  // ---- dense: (time tile mt, dim tile nt = wave % 8) per wave; the wave's eight B fragments stay in registers ----
+  {
+    const int nt = wave & 7;
+    float bw[LOC_F / 4];
+#pragma unroll
+    for (int ks = 0; ks < LOC_F / 4; ++ks) bw[ks] = s_wd[4 * ks + fg][16 * nt + fi];
+    // its (up to) four time tiles mt = wave / 8 + 2 j side by side: four independent accumulator chains
+    constexpr int NJ = LOC_MFMA_T / 16 / 2;
+    f32x4 acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < LOC_F / 4; ++ks)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int mt = (wave >> 3) + 2 * j;  // (rows past T: zero-weight steps of the conv, finite; their results are dropped)
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(s_lc[16 * mt + fi][4 * ks + fg], bw[ks], acc[j], 0, 0, 0);
+      }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = 16 * ((wave >> 3) + 2 * j) + 4 * fg + r;
+        if (t < T) d.loc[((size_t)b * T + t) * ATT_DIM + 16 * nt + fi] = acc[j][r];
+      }
+  }
+}
+
 __global__ __launch_bounds__(PRENET_BT) void k_prenet_b(DecoderBufs d, int i, int flush, const float *__restrict__ W0T,
-                                                        const float *__restrict__ W1T, const float *__restrict__ proj_b) {
+                                                        const float *__restrict__ W1T, const float *__restrict__ proj_b,
+                                                        const float *__restrict__ loc_convT, const float *__restrict__ loc_denseT) {
+  if ((int)blockIdx.x >= PRENET_SPLIT * d.B) {  // location role (never in a flush launch: its grid ends with the prenet blocks)
+    if (d.T <= LOC_MFMA_T)
+      location_chunk_mfma(d, i, (int)blockIdx.x - PRENET_SPLIT * d.B, loc_convT, loc_denseT);
+    else
+      location_blocks(d, i, (int)blockIdx.x - PRENET_SPLIT * d.B, loc_convT, loc_denseT);
+    return;
+  }
   constexpr int HALF = PRENET / PRENET_SPLIT;          // layer-2 columns of this block
   constexpr int NPART = PRENET_BT / 32;                // 32 row groups of the partial-mel reduction
   constexpr int ROWS = (PM_ROWS + NPART - 1) / NPART;  // 9 rows per group
@@ -742,8 +880,7 @@ __global__ __launch_bounds__(256) void k_qenergy(DecoderBufs d, int i, int cur, 
 // the encoder memory is spread over several CUs; it is issued as 16-byte lane-consecutive loads,
 // prefetched at kernel entry (addresses do not depend on the softmax).  Block 0 also stores the
 // new attention weights.
-__global__ __launch_bounds__(256) void k_softmax_ctx(DecoderBufs d, int i, const float *__restrict__ proj_wc,
-                                                     const float *__restrict__ loc_convT, const float *__restrict__ loc_denseT) {
+__global__ __launch_bounds__(256) void k_softmax_ctx(DecoderBufs d, int i, const float *__restrict__ proj_wc) {
 #ifdef XDTTS_LSTM_PROBE
   const unsigned long long t_in = wall_clock64();
   unsigned long long t_sm = 0, t_ctx = 0;
@@ -756,13 +893,10 @@ __global__ __launch_bounds__(256) void k_softmax_ctx(DecoderBufs d, int i, const
   __shared__ __attribute__((aligned(16))) float s_e[T_MAX], s_part[TG][CTX_COLS], s_ctx[CTX_COLS];
   const int c4 = tid % C4, tg = tid / C4;
   const float4 *mem = reinterpret_cast<const float4 *>(d.memory + (size_t)b * T * EMB) + cblk * C4;
-  // Batched mode: the NEXT step's location features are this kernel's tail (every block holds the whole
-  // softmax, so the 8 blocks of a chunk split the time tiles) instead of a launch of their own; the
-  // cumulative weights ping-pong between two buffers by step parity because the other blocks of the
-  // chunk still read the old ones while block 0 writes the new.
+  // Batched mode: the cumulative weights ping-pong between two buffers by step parity because the other blocks of
+  // the chunk still read the old ones while block 0 writes the new (the next step's location features are
+  // computed from them by the location blocks of the next prenet launch, location_blocks above).
   const bool batched = d.xf != nullptr;
-  __shared__ float s_awc[T_MAX];
-  LocWeights lw;
   const float *awc_in = batched && (i & 1) ? d.awc2 : d.awc;
   float *awc_out = batched ? ((i & 1) ? d.awc : d.awc2) : d.awc;
   const int nv = d.n_valid[b];
@@ -794,7 +928,6 @@ __global__ __launch_bounds__(256) void k_softmax_ctx(DecoderBufs d, int i, const
     const int t = tg + TG * u;
     pf[u] = t < T ? mem[(size_t)t * (EMB / 4) + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  if (batched) location_weights(lw, loc_convT, loc_denseT);
   asm volatile("" ::: "memory");
   if (tid < T) {
     float e = 0.f;
@@ -826,7 +959,6 @@ __global__ __launch_bounds__(256) void k_softmax_ctx(DecoderBufs d, int i, const
   __syncthreads();
   for (int t = tid; t < T; t += 256) {
     const float wv = s_e[t], cum = (t == tid ? awc_pre : awc_in[b * T + t]) + wv;
-    s_awc[t] = cum;
     if (act && cblk == 0) {
       d.aw[b * T + t] = wv;
       awc_out[b * T + t] = cum;
@@ -877,8 +1009,6 @@ __global__ __launch_bounds__(256) void k_softmax_ctx(DecoderBufs d, int i, const
 #ifdef XDTTS_LSTM_PROBE
   t_ctx = wall_clock64();
 #endif
-  if (batched && act)
-    for (int tile = cblk; tile * LOC_TT < T; tile += CTX_BLOCKS) location_tile(d, b, tile, s_e, s_awc, lw);
 #ifdef XDTTS_LSTM_PROBE
   if (tid == 0 && step == 100 && (b % 17 == 0) && (cblk == 0 || cblk == 7))
     printf("probe softmax_ctx blk (%d,%d) in %llu softmax_done %llu ctx_pmel_done %llu out %llu\n", b, cblk, t_in % 1000000ull, t_sm % 1000000ull, t_ctx % 1000000ull, wall_clock64() % 1000000ull);
@@ -918,7 +1048,8 @@ void launch_decoder_steps(const DecoderBufs &d, const DeviceWeights &w, int nste
       switch (k) {
         case 'p':
           if (batched)
-            hipLaunchKernelGGL(k_prenet_b, dim3(PRENET_SPLIT * d.B), dim3(PRENET_BT), 0, s, d, i, 0, w.pre0T.p, w.pre1T.p, w.proj_b.p);
+            hipLaunchKernelGGL(k_prenet_b, dim3(PRENET_SPLIT * d.B + d.B * (d.T <= LOC_MFMA_T ? 1 : ((d.T + LOC_TT - 1) / LOC_TT + 7) / 8)), dim3(PRENET_BT), 0, s, d, i, 0, w.pre0T.p, w.pre1T.p,
+                               w.proj_b.p, w.loc_conv.p, w.loc_denseT.p);
           else
             hipLaunchKernelGGL(k_prenet, dim3(PRENET_BLOCKS * d.B), dim3(256), 0, s, d, i, 0, w.pre0T.p, w.pre1T.p,
                                w.proj_b.p);
@@ -935,7 +1066,7 @@ void launch_decoder_steps(const DecoderBufs &d, const DeviceWeights &w, int nste
                              reinterpret_cast<const float4 *>(w.q_w.p), w.v_w.p);
           break;
         case 's':
-          hipLaunchKernelGGL(k_softmax_ctx, dim3(CTX_BLOCKS * d.B), dim3(256), 0, s, d, i, w.proj_wc.p, w.loc_conv.p, w.loc_denseT.p);
+          hipLaunchKernelGGL(k_softmax_ctx, dim3(CTX_BLOCKS * d.B), dim3(256), 0, s, d, i, w.proj_wc.p);
           break;
         case 'd':
           if (batched) {
@@ -967,7 +1098,7 @@ void launch_decoder_single_step(const DecoderBufs &d, const DeviceWeights &w, hi
   hipLaunchKernelGGL((k_lstm<ATT_COLS, 0>), dim3(NBLK), dim3(256), 0, s, d, 0, 0, reinterpret_cast<const float4 *>(w.att_w.p), w.att_b.p, q4,
                      w.loc_conv.p, w.loc_denseT.p);
   hipLaunchKernelGGL(k_qenergy, dim3(ATT_DIM / 4, 1), dim3(256), 0, s, d, 0, 0, reinterpret_cast<const float4 *>(w.q_w.p), w.v_w.p);
-  hipLaunchKernelGGL(k_softmax_ctx, dim3(CTX_BLOCKS * d.B), dim3(256), 0, s, d, 0, w.proj_wc.p, w.loc_conv.p, w.loc_denseT.p);
+  hipLaunchKernelGGL(k_softmax_ctx, dim3(CTX_BLOCKS * d.B), dim3(256), 0, s, d, 0, w.proj_wc.p);
   hipLaunchKernelGGL((k_lstm<DEC_COLS, 1>), dim3(loc_tiles * d.B + NBLK), dim3(256), 0, s, d, 0, 0, reinterpret_cast<const float4 *>(w.dec_w.p),
                      w.dec_b.p, wh4, w.loc_conv.p, w.loc_denseT.p);
   hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, s, d, 1);
@@ -977,7 +1108,7 @@ void launch_decoder_single_step(const DecoderBufs &d, const DeviceWeights &w, hi
 // After the last step of a sequence: finishes the projection of the final step (frames, gate).
 void launch_decoder_flush(const DecoderBufs &d, const DeviceWeights &w, hipStream_t s) {
   if (d.xf)
-    hipLaunchKernelGGL(k_prenet_b, dim3(PRENET_SPLIT * d.B), dim3(PRENET_BT), 0, s, d, 0, 1, w.pre0T.p, w.pre1T.p, w.proj_b.p);
+    hipLaunchKernelGGL(k_prenet_b, dim3(PRENET_SPLIT * d.B), dim3(PRENET_BT), 0, s, d, 0, 1, w.pre0T.p, w.pre1T.p, w.proj_b.p, w.loc_conv.p, w.loc_denseT.p);
   else
     hipLaunchKernelGGL(k_prenet, dim3(PRENET_BLOCKS * d.B), dim3(256), 0, s, d, 0, 1, w.pre0T.p, w.pre1T.p, w.proj_b.p);
   HIP_CHECK(hipGetLastError());
