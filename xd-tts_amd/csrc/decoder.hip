@@ -348,15 +348,16 @@ __device__ __forceinline__ void location_blocks(const DecoderBufs &d, int i, int
     }
   }
 }
-// The same for T <= LOC_MFMA_T (the reference's window is 100) on the matrix cores, ONE block per chunk: both layers
+// The same for T <= LOC_MFMA_T (the reference's window is 100) on the matrix cores, two blocks per chunk: both layers
 // are GEMMs over the chunk's time steps --  lc[T][32] = im2col(w_prev, w_cum)[T][62] . conv[62][32]  and
 // loc[T][128] = lc[T][32] . dense[32][128]  -- 224 + 448 v_mfma_f32_16x16x4_f32 per chunk against 608 k FMAs that each
 // need an LDS operand (measured: the FMA form keeps a 1024-thread block busy for ~5 us, longer than the prenet it
 // rides with).  Operands come from LDS: lane l of an A fragment is (row l % 16, k l / 16), of a B fragment
 // (k l / 16, column l % 16); a D register r of lane l is (row 4 (l / 16) + r, column l % 16).
 constexpr int LOC_MFMA_T = 128;
-__device__ __forceinline__ void location_chunk_mfma(const DecoderBufs &d, int i, int b, const float *__restrict__ loc_convT,
+__device__ __forceinline__ void location_chunk_mfma(const DecoderBufs &d, int i, int lb, const float *__restrict__ loc_convT,
                                                     const float *__restrict__ loc_denseT) {
+  const int b = lb >> 1, half = lb & 1;  // two blocks per chunk: time tiles 0..3 and 4..7
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   constexpr int PADK = (LOC_K - 1) / 2, KC = 64;  // conv contraction: 2 x 31 taps, padded to 64
   const int T = d.T, MT = (T + 15) / 16;
@@ -375,8 +376,9 @@ __device__ __forceinline__ void location_chunk_mfma(const DecoderBufs &d, int i,
   __syncthreads();
   if (!act) return;  // (block-uniform)
   // ---- conv: (time tile mt, filter tile nt) per wave ----
-  for (int tp = wave; tp < 2 * MT; tp += PRENET_BT / 64) {
-    const int mt = tp >> 1, nt = tp & 1;
+  for (int tp = wave; tp < 8; tp += PRENET_BT / 64) {  // (waves 0..7)
+    const int mt = 4 * half + (tp >> 1), nt = tp & 1;
+    if (mt >= MT) continue;
     f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;  // two chains: a dependent MFMA waits ~40 cycles
 #pragma unroll
     for (int ks = 0; ks < KC / 4; ++ks) {
@@ -396,8 +398,8 @@ __device__ __forceinline__ void location_chunk_mfma(const DecoderBufs &d, int i,
     float bw[LOC_F / 4];
 #pragma unroll
     for (int ks = 0; ks < LOC_F / 4; ++ks) bw[ks] = s_wd[4 * ks + fg][16 * nt + fi];
-    // its (up to) four time tiles mt = wave / 8 + 2 j side by side: four independent accumulator chains
-    constexpr int NJ = LOC_MFMA_T / 16 / 2;
+    // its two time tiles mt = 4 half + wave / 8 + 2 j side by side: independent accumulator chains
+    constexpr int NJ = 2;
     f32x4 acc[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -405,14 +407,14 @@ __device__ __forceinline__ void location_chunk_mfma(const DecoderBufs &d, int i,
     for (int ks = 0; ks < LOC_F / 4; ++ks)
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        const int mt = (wave >> 3) + 2 * j;  // (rows past T: zero-weight steps of the conv, finite; their results are dropped)
+        const int mt = 4 * half + (wave >> 3) + 2 * j;  // (rows past the chunk's tiles hold stale LDS; their results are dropped)
         acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(s_lc[16 * mt + fi][4 * ks + fg], bw[ks], acc[j], 0, 0, 0);
       }
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int t = 16 * ((wave >> 3) + 2 * j) + 4 * fg + r;
+        const int t = 16 * (4 * half + (wave >> 3) + 2 * j) + 4 * fg + r;
         if (t < T) d.loc[((size_t)b * T + t) * ATT_DIM + 16 * nt + fi] = acc[j][r];
       }
   }
@@ -1048,7 +1050,7 @@ void launch_decoder_steps(const DecoderBufs &d, const DeviceWeights &w, int nste
       switch (k) {
         case 'p':
           if (batched)
-            hipLaunchKernelGGL(k_prenet_b, dim3(PRENET_SPLIT * d.B + d.B * (d.T <= LOC_MFMA_T ? 1 : ((d.T + LOC_TT - 1) / LOC_TT + 7) / 8)), dim3(PRENET_BT), 0, s, d, i, 0, w.pre0T.p, w.pre1T.p,
+            hipLaunchKernelGGL(k_prenet_b, dim3(PRENET_SPLIT * d.B + d.B * (d.T <= LOC_MFMA_T ? 2 : ((d.T + LOC_TT - 1) / LOC_TT + 7) / 8)), dim3(PRENET_BT), 0, s, d, i, 0, w.pre0T.p, w.pre1T.p,
                                w.proj_b.p, w.loc_conv.p, w.loc_denseT.p);
           else
             hipLaunchKernelGGL(k_prenet, dim3(PRENET_BLOCKS * d.B), dim3(256), 0, s, d, i, 0, w.pre0T.p, w.pre1T.p,
