@@ -647,14 +647,15 @@ __global__ __launch_bounds__(256) void k_lstm(DecoderBufs d, int i, int cur, con
 // D2 / D4 for batches (B >= BATCH_MFMA_MIN chunks in lock-step): the LSTM pre-activations become
 // a GEMM  G[16 rows of a block][B chunks] = W[16 x K] . X^T[K x B]  on the exact-fp32 matrix
 // cores (v_mfma_f32_16x16x4_f32).  Still weight-streaming: a block owns the same 4 hidden units
-// (16 gate rows), its sixteen waves split K, every weight is read from HBM once per step and feeds
-// 4 MFMAs per 16-chunk tile straight from the load (the weights are pre-laid in fragment order,
-// weights.h); the activations come from L2 with 64-byte segments per chunk (four waves per SIMD
-// hide that latency).  Accumulators of the sixteen K-slices meet in LDS; wave t then holds, per lane, the four gates of (chunk 16t + lane%16,
-// unit lane/16) -- exactly the MFMA D layout -- and does the cell update in place.
+// (16 gate rows), its MFMA_WAVES (8) waves split K, every weight is read once per step -- from the Infinity
+// Cache, which holds the 71 MB between steps as long as the loads are plain ones -- and feeds 4 MFMAs per
+// 16-chunk tile straight from the load (the weights are pre-laid in fragment order, weights.h); the
+// activations come from L2 with 64-byte segments per chunk.  Accumulators of the K-slices meet in LDS; wave t
+// then holds, per lane, the four gates of (chunk 16t + lane%16, unit lane/16) -- exactly the MFMA D layout --
+// and does the cell update in place.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Operands: the weights in MFMA A-fragment order (weights.h) stream from HBM, one 16-byte load per
+// Operands: the weights in MFMA A-fragment order (weights.h) stream in, one 16-byte load per
 // lane = the A operands of four MFMAs, the wave's whole slab in flight at kernel entry; the
 // activations come from the [K/4][Bpad][4] copies (kernels.h) with fully coalesced 16-byte loads,
 // software-pipelined three k-steps deep so that L2 latency hides behind the other tiles' MFMAs.
@@ -690,8 +691,11 @@ __device__ __forceinline__ void lstm_mfma_pass(const DecoderBufs &d, int n0, int
   // i.e. for the whole 42 MB HBM stream, and the MFMAs could not overlap it (measured: 5-12 us from kernel
   // entry to the first MFMA).  Both streams are issued in consumption order instead: weights three
   // k-steps ahead (HBM latency), activations two (L2).
-  float4 ring[3][NTA], wring[4];
-  constexpr int DW = 3, DX = 2;
+  float4 ring[3][NTA], wring[8];
+#ifndef XDTTS_LSTM_DW
+#define XDTTS_LSTM_DW 3  // (4 and 6 measured slower: every activation vector then queues behind more weight loads)
+#endif
+  constexpr int DW = XDTTS_LSTM_DW, DX = 2;
 #pragma unroll
   for (int p = 0; p < DW && p < JJ; ++p) {
     wring[p] = wsrc[(size_t)p * 64];  // plain loads: with the non-temporal hint of the GEMV kernels the 52-chunk iteration took 2.3 us longer
@@ -705,14 +709,14 @@ __device__ __forceinline__ void lstm_mfma_pass(const DecoderBufs &d, int n0, int
   }
 #pragma unroll
   for (int jj = 0; jj < JJ; ++jj) {
-    if (jj + DW < JJ) wring[(jj + DW) % 4] = wsrc[(size_t)(jj + DW) * 64];
+    if (jj + DW < JJ) wring[(jj + DW) % 8] = wsrc[(size_t)(jj + DW) * 64];
     if (jj + DX < JJ) {
       const float4 *sp = src(jj + DX);
 #pragma unroll
       for (int t = 0; t < NTA; ++t) ring[(jj + DX) % 3][t] = sp[16 * t];
     }
     asm volatile("" ::: "memory");
-    const float4 wv = wring[jj % 4];
+    const float4 wv = wring[jj % 8];
     const float4(&xv)[NTA] = ring[jj % 3];
     // interleave the tiles so consecutive MFMAs hit different accumulators (40-cycle dependent latency)
 #pragma unroll
@@ -742,7 +746,7 @@ __device__ __forceinline__ void lstm_mfma_pass(const DecoderBufs &d, int n0, int
     if (n < d.B) {
       const float c_old = cst[(size_t)n * ATT_RNN + unit];
       // hardware exp2 / rcp forms (device_utils.h), as in the persistent engine: this tail runs on NTA of
-      // the 16 waves while the others wait
+      // the waves while the others wait
       const float ig = fast_sigmoid(g[0] + bz.x), fgt = fast_sigmoid(g[1] + bz.y);
       const float gg = fast_tanh(g[2] + bz.z), og = fast_sigmoid(g[3] + bz.w);
       const float cn = fmaf(fgt, c_old, ig * gg);

@@ -36,7 +36,10 @@ struct ConvGemm {
 };
 
 // Device-resident, kernel-ready weights.  Everything stays fp32 (parity bar 1e-4 RMS).
-constexpr int MFMA_WAVES = 16;     // waves per block of the batched LSTM kernel: each takes 1/16 of K
+#ifndef XDTTS_MFMA_WAVES
+#define XDTTS_MFMA_WAVES 8  // (52 chunks: 46.9 us per iteration with 8, 47.2 with 16, 49.7 with 4)
+#endif
+constexpr int MFMA_WAVES = XDTTS_MFMA_WAVES;     // waves per block of the batched LSTM kernel: each takes 1/8 of K
 constexpr int BATCH_MFMA_MIN = 5;  // chunks in lock-step from which the LSTMs run as MFMA GEMMs (measured: 38 us per iteration at 5..8 chunks against 41..49 us for the GEMV kernels)
 
 struct DeviceWeights {
