@@ -709,12 +709,15 @@ __device__ __forceinline__ void lstm_mfma_pass(const DecoderBufs &d, int n0, int
   }
 #pragma unroll
   for (int jj = 0; jj < JJ; ++jj) {
-    if (jj + DW < JJ) wring[(jj + DW) % 8] = wsrc[(size_t)(jj + DW) * 64];
+    // (the activations of step jj + DX before the weights of step jj + DW: loads retire in issue order, and the other
+    // way round every activation vector waits for a weight vector that is needed a whole k-step later)
     if (jj + DX < JJ) {
       const float4 *sp = src(jj + DX);
 #pragma unroll
       for (int t = 0; t < NTA; ++t) ring[(jj + DX) % 3][t] = sp[16 * t];
     }
+    asm volatile("" ::: "memory");
+    if (jj + DW < JJ) wring[(jj + DW) % 8] = wsrc[(size_t)(jj + DW) * 64];
     asm volatile("" ::: "memory");
     const float4 wv = wring[jj % 8];
     const float4(&xv)[NTA] = ring[jj % 3];
