@@ -263,6 +263,20 @@ def test_batched_path_with_a_smaller_window(pkg, model, orc, blob):
         assert mels[b].shape == (80, st) and rms(mels[b], ref) <= 1e-5, b
 
 
+def test_batched_path_with_a_larger_window(pkg, model, orc, blob):
+    """max_chunk = 140 (> 128 encoder steps): the batched path computes the location features with the FMA
+    blocks instead of the MFMA ones, and the persistent single-chunk engine gives way to the launch path;
+    every chunk still equals its own oracle run."""
+    lens = [140, 9, 77, 131, 64, 140]
+    ids_list = [synth_ids(n, seed=120 + i) for i, n in enumerate(lens)]
+    steps = [12, 5, 9, 14, 7, 10]
+    o = pkg.default_opts(dropout_seed=29, item_base=1, max_chunk=140)
+    mels = model.infer_batch(ids_list, opts=o, fixed_steps=steps)
+    for b, (ids, st) in enumerate(zip(ids_list, steps)):
+        ref = orc.infer_chunk(blob, ids, orc.default_opts(fixed_steps=st, dropout_seed=29, item=1 + b), window=140)
+        assert mels[b].shape == (80, st) and rms(mels[b], ref) <= 1e-5, b
+
+
 def test_gemm_tile_shapes_give_identical_results(tmp_path):
     """k_gemm_nt picks 32x32 tiles for the single-utterance shapes and 64x64 once a grid fills the chip twice;
     both accumulate every output element's K products in ascending order, so a batch decoded with either
