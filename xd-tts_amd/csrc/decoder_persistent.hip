@@ -285,6 +285,31 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
     }
     nf_r = d.nframes[rb];
   }
+  // One-chunk kernel: the role's per-step weights move from LDS into the 40 registers the second chunk would need
+  // (attention: the two query rows of this wave, 8 float4; prenet: this thread's 40 layer-1 weights) -- the LDS
+  // operand reads of these two inner products were ~0.4 us of the step's critical path.
+  constexpr bool ROLE_REGS = PB == 1;
+  float rw[ROLE_REGS ? 40 : 1];
+  if (ROLE_REGS) {
+#pragma unroll
+    for (int k = 0; k < 40; ++k) rw[ROLE_REGS ? k : 0] = 0.f;
+    if (attn) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 q = w.q_w[(unsigned)((16 * rk + wave + NW * r) * (ATT_RNN / 4) + lane + 64 * j)];
+          rw[ROLE_REGS ? 16 * r + 4 * j + 0 : 0] = q.x;
+          rw[ROLE_REGS ? 16 * r + 4 * j + 1 : 0] = q.y;
+          rw[ROLE_REGS ? 16 * r + 4 * j + 2 : 0] = q.z;
+          rw[ROLE_REGS ? 16 * r + 4 * j + 3 : 0] = q.w;
+        }
+    } else if (pre) {
+      // layer 1: output tid & 255, inputs [40 hf, 40 hf + 40), hf = tid >> 8
+#pragma unroll
+      for (int k = 0; k < N_MEL / 2; ++k) rw[ROLE_REGS ? k : 0] = w.pre0T[(unsigned)(((tid >> 8) * (N_MEL / 2) + k) * PRENET + (tid & 255))];
+    }
+  }
   const uint32_t item = d.item_base + (uint32_t)rb;
   __syncthreads();
 
@@ -510,8 +535,13 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float4 v = lds4(s_hatt + rb * ATT_RNN + 256 * j + L4);
-        q0 = dot4(lds4(s_qw + 4 * (j * PT + TID)), v, q0);
-        q1 = dot4(lds4(s_qw + 4 * ((4 + j) * PT + TID)), v, q1);
+        if (ROLE_REGS) {
+          q0 = dot4(make_float4(rw[ROLE_REGS ? 4 * j : 0], rw[ROLE_REGS ? 4 * j + 1 : 0], rw[ROLE_REGS ? 4 * j + 2 : 0], rw[ROLE_REGS ? 4 * j + 3 : 0]), v, q0);
+          q1 = dot4(make_float4(rw[ROLE_REGS ? 16 + 4 * j : 0], rw[ROLE_REGS ? 17 + 4 * j : 0], rw[ROLE_REGS ? 18 + 4 * j : 0], rw[ROLE_REGS ? 19 + 4 * j : 0]), v, q1);
+        } else {
+          q0 = dot4(lds4(s_qw + 4 * (j * PT + TID)), v, q0);
+          q1 = dot4(lds4(s_qw + 4 * ((4 + j) * PT + TID)), v, q1);
+        }
       }
       q0 = wave_sum(q0);
       q1 = wave_sum(q1);
@@ -684,8 +714,19 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
         // layer 1: output tid & 255, inputs [40 hf, 40 hf + 40), hf = tid >> 8
         const unsigned HW = (unsigned)((tid >> 8) * (N_MEL / 2) * PRENET + (tid & 255)), HM = (unsigned)((tid >> 8) * (N_MEL / 2));
         float acc = 0.f;
+        if (ROLE_REGS) {
+#pragma unroll
+          for (int k = 0; k < N_MEL / 2; k += 4) {  // (16-byte broadcast reads of the frame)
+            const float4 m = lds4(s_mel + HM + k);
+            acc = fmaf(rw[ROLE_REGS ? k : 0], m.x, acc);
+            acc = fmaf(rw[ROLE_REGS ? k + 1 : 0], m.y, acc);
+            acc = fmaf(rw[ROLE_REGS ? k + 2 : 0], m.z, acc);
+            acc = fmaf(rw[ROLE_REGS ? k + 3 : 0], m.w, acc);
+          }
+        } else {
 #pragma unroll 8
-        for (int k = 0; k < N_MEL / 2; ++k) acc = fmaf(s_W0[HW + PRENET * k], s_mel[HM + k], acc);
+          for (int k = 0; k < N_MEL / 2; ++k) acc = fmaf(s_W0[HW + PRENET * k], s_mel[HM + k], acc);
+        }
         s_l1[TID] = acc;
         __syncthreads();
         // every wave finishes layer 1 for the inputs its lanes consume (ReLU, dropout) -- no second
