@@ -628,6 +628,20 @@ __global__ __launch_bounds__(64 * W) void k_gl_persistent(GlBufs g, GlPersist p,
       }
     }
     GLP_MARK(10);  // B0: publish
+    // First poll of the neighbours' granules, issued NOW: the loads' round trip (~1 us) overlaps the own overlap-add
+    // below; the neighbours run in lock-step with this workgroup, so their stores are usually on their way already.
+    // What is not there yet is polled again in B2.
+    constexpr int U0 = 3;
+    u64 ev_l[U0], ev_r[U0];
+    {
+      const u64 *gl0 = inL + (size_t)par * 2 * GLP_HALO, *gr0 = gl0 + GLP_HALO;
+#pragma unroll
+      for (int u = 0; u < U0; ++u) {
+        const int k = tid + u * nthr;
+        ev_l[u] = (k < GLP_HALO && !seg_first) ? __hip_atomic_load(gl0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        ev_r[u] = (k < GLP_HALO && outR != nullptr) ? __hip_atomic_load(gr0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+      }
+    }
     // ---- B1: overlap-add of the own frames over the block's range (not yet normalised) -> yb.
     // float4 per thread; the 256-sample chunk index is wave-uniform, so the frame loop does not diverge.
     {
@@ -667,11 +681,22 @@ __global__ __launch_bounds__(64 * W) void k_gl_persistent(GlBufs g, GlPersist p,
         hl[u] = hr[u] = 0.f;
         dl[u] = !(in && has_l);
         dr[u] = !(in && has_r);
+        if (!dl[u] && (unsigned)(ev_l[u] >> 32) == want) {  // the early poll already brought it
+          hl[u] = __uint_as_float((unsigned)ev_l[u]);
+          dl[u] = true;
+        }
+        if (!dr[u] && (unsigned)(ev_r[u] >> 32) == want) {
+          hr[u] = __uint_as_float((unsigned)ev_r[u]);
+          dr[u] = true;
+        }
       }
       const u64 *gl_ = inL + (size_t)par * 2 * GLP_HALO, *gr_ = gl_ + GLP_HALO;
       unsigned spins = 0;
       GLP_MARK(4);  // middle samples
-      for (;;) {
+      bool pending = false;
+#pragma unroll
+      for (int u = 0; u < U; ++u) pending = pending || !dl[u] || !dr[u];
+      while (pending) {
         u64 vl[U], vr[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
