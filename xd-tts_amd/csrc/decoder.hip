@@ -663,7 +663,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // tiles form a prefix): NTA = active tiles of this pass, a compile-time count per code path.
 template <int NCOLS, int KIND, int NTA>
 __device__ __forceinline__ void lstm_mfma_pass(const DecoderBufs &d, int n0, int cur, int step, int blk, const float4 *__restrict__ wsrc,
-                                               const float4 bz, const float4 we, float *s_acc, float *s_h, unsigned long long d_probe_entry = 0) {
+                                               const float4 bz, const float4 we, float *s_acc, float *s_h, unsigned long long active,
+                                               unsigned long long d_probe_entry = 0) {  // active: bit j = chunk n0 + j still runs at this step
   constexpr int NW = MFMA_WAVES, KW = NCOLS / NW, JJ = KW / 16;
   constexpr int N0 = KIND == 0 ? PRENET : ATT_RNN, N1 = EMB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fi = lane & 15, fg = lane >> 4;
@@ -754,7 +755,7 @@ __device__ __forceinline__ void lstm_mfma_pass(const DecoderBufs &d, int n0, int
       const float gg = fast_tanh(g[2] + bz.z), og = fast_sigmoid(g[3] + bz.w);
       const float cn = fmaf(fgt, c_old, ig * gg);
       hn = og * fast_tanh(cn);
-      if (step < d.nframes[n]) {
+      if ((active >> (16 * wave + fi)) & 1ull) {
         cst[(size_t)n * ATT_RNN + unit] = cn;
         h_out[(size_t)n * ATT_RNN + unit] = hn;
         hf_out[((size_t)blk * d.Bpad + n) * 4 + fg] = hn;
@@ -771,7 +772,7 @@ __device__ __forceinline__ void lstm_mfma_pass(const DecoderBufs &d, int n0, int
     if (tid < MEL_LD * (64 * NW / MEL_LD))
       for (int bl = tid / MEL_LD; bl < nb; bl += 64 * NW / MEL_LD) {
         const float4 h4 = *reinterpret_cast<const float4 *>(s_h + 4 * bl);
-        if (step < d.nframes[n0 + bl])
+        if ((active >> bl) & 1ull)  // (no step-limit load inside this loop: it ran once per chunk pass on the kernel's tail)
           d.pmel[((size_t)(n0 + bl) * PM_ROWS + CTX_BLOCKS + blk) * MEL_LD + m] =
               fmaf(we.w, h4.w, fmaf(we.z, h4.z, fmaf(we.y, h4.y, we.x * h4.x)));
       }
@@ -808,10 +809,10 @@ __global__ __launch_bounds__(64 * MFMA_WAVES) void k_lstm_mfma(DecoderBufs d, in
   __shared__ __attribute__((aligned(16))) float s_acc[NW * 4 * 64 * 4];  // [K-slice][tile][lane][gate]
   __shared__ __attribute__((aligned(16))) float s_h[64 * 4];             // [chunk in super-tile][unit]
   switch (nta) {
-    case 1: lstm_mfma_pass<NCOLS, KIND, 1>(d, n0, cur, step, blk, wsrc, bz, we, s_acc, s_h, t_entry); break;
-    case 2: lstm_mfma_pass<NCOLS, KIND, 2>(d, n0, cur, step, blk, wsrc, bz, we, s_acc, s_h, t_entry); break;
-    case 3: lstm_mfma_pass<NCOLS, KIND, 3>(d, n0, cur, step, blk, wsrc, bz, we, s_acc, s_h, t_entry); break;
-    case 4: lstm_mfma_pass<NCOLS, KIND, 4>(d, n0, cur, step, blk, wsrc, bz, we, s_acc, s_h, t_entry); break;
+    case 1: lstm_mfma_pass<NCOLS, KIND, 1>(d, n0, cur, step, blk, wsrc, bz, we, s_acc, s_h, m, t_entry); break;
+    case 2: lstm_mfma_pass<NCOLS, KIND, 2>(d, n0, cur, step, blk, wsrc, bz, we, s_acc, s_h, m, t_entry); break;
+    case 3: lstm_mfma_pass<NCOLS, KIND, 3>(d, n0, cur, step, blk, wsrc, bz, we, s_acc, s_h, m, t_entry); break;
+    case 4: lstm_mfma_pass<NCOLS, KIND, 4>(d, n0, cur, step, blk, wsrc, bz, we, s_acc, s_h, m, t_entry); break;
     default: break;
   }
 }
