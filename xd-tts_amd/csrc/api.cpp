@@ -175,6 +175,7 @@ struct xdtts_tacotron2 {
                                             // chunk must be co-resident, one per CU (set from the CU count in init)
   DevBuf<float> att_h, att_c, dec_h, dec_c, aw, awc, ctx, x, loc, e_part, pmel, frames, gates;
   DevBuf<float> frag;       // batched mode: MFMA-operand copies of x, ctx, att_h[2], dec_h[2]
+  DevBuf<float> pmem_t;     // batched mode: processed_memory as [B][32][T][4]
   DevBuf<int> item_perm;    // batched mode: dropout-stream index of the (length-sorted) chunks
   DevBuf<float> dec_in_dev; // parity hook: decoder_input of xdtts_tacotron2_decoder_step
   int demoted_calls = 0;    // decoder calls since a demotion (the fast engines are probed again after PROBE_AFTER)
@@ -337,6 +338,9 @@ struct xdtts_tacotron2 {
       d.dec_hf[0] = d.att_hf[1] + (size_t)Bpad * ATT_RNN;
       d.dec_hf[1] = d.dec_hf[0] + (size_t)Bpad * DEC_RNN;
       d.awc2 = d.dec_hf[1] + (size_t)Bpad * DEC_RNN;
+      pmem_t.alloc((size_t)B * T * ATT_DIM);
+      launch_dimgroup_transpose(pm, pmem_t.p, B, T, stream);
+      d.pmem_t = pmem_t.p;
     }
     return d;
   }

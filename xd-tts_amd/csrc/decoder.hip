@@ -343,7 +343,7 @@ __device__ __forceinline__ void location_blocks(const DecoderBufs &d, int i, int
           acc = fmaf(lw.wd[g + 2], lc.z, acc);
           acc = fmaf(lw.wd[g + 3], lc.w, acc);
         }
-        d.loc[((size_t)b * T + t) * ATT_DIM + a] = acc;
+        d.loc[(((size_t)b * (ATT_DIM / 4) + (a >> 2)) * T + t) * 4 + (a & 3)] = acc;  // batched layout [B][32][T][4]
       }
     }
   }
@@ -415,7 +415,7 @@ __device__ __forceinline__ void location_chunk_mfma(const DecoderBufs &d, int i,
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int t = 16 * (4 * half + (wave >> 3) + 2 * j) + 4 * fg + r;
-        if (t < T) d.loc[((size_t)b * T + t) * ATT_DIM + 16 * nt + fi] = acc[j][r];
+        if (t < T) d.loc[(((size_t)b * (ATT_DIM / 4) + 4 * nt + (fi >> 2)) * T + t) * 4 + (fi & 3)] = acc[j][r];  // batched layout [B][32][T][4]
       }
   }
 }
@@ -846,9 +846,13 @@ __global__ __launch_bounds__(256) void k_qenergy(DecoderBufs d, int i, int cur, 
 #pragma unroll
     for (int k = 0; k < 4; ++k) hv[k] = *reinterpret_cast<const float4 *>(h + 256 * k + 4 * lane);
     // first time step of this thread: loads do not depend on q, put them in flight now
-    const size_t o0 = ((size_t)b * d.T + (tid < d.T ? tid : 0)) * ATT_DIM + blk * 4;
+    // batched mode: loc and processed_memory as [B][32][T][4], this block's 4 dims of consecutive steps contiguous
+    const bool tl = gridDim.y > 1;
+    const float *pmem = tl ? d.pmem_t : d.pmem;
+    auto at = [&](int t) { return tl ? (((size_t)b * (ATT_DIM / 4) + blk) * d.T + t) * 4 : ((size_t)b * d.T + t) * ATT_DIM + blk * 4; };
+    const size_t o0 = at(tid < d.T ? tid : 0);
     float4 l4 = *reinterpret_cast<const float4 *>(d.loc + o0);
-    float4 p4 = *reinterpret_cast<const float4 *>(d.pmem + o0);
+    float4 p4 = *reinterpret_cast<const float4 *>(pmem + o0);
     float a = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) a = dot4(w[k], hv[k], a);
@@ -859,9 +863,9 @@ __global__ __launch_bounds__(256) void k_qenergy(DecoderBufs d, int i, int cur, 
     const bool act = step < d.nframes[b];
     for (int t = tid; t < d.T; t += 256) {
       if (t != tid) {
-        const size_t o = ((size_t)b * d.T + t) * ATT_DIM + blk * 4;
+        const size_t o = at(t);
         l4 = *reinterpret_cast<const float4 *>(d.loc + o);
-        p4 = *reinterpret_cast<const float4 *>(d.pmem + o);
+        p4 = *reinterpret_cast<const float4 *>(pmem + o);
       }
       float e;
       if (gridDim.y > 1) {  // batched mode: hardware exp2 / rcp tanh, as the persistent engine uses
@@ -1029,6 +1033,22 @@ __global__ __launch_bounds__(256) void k_softmax_ctx(DecoderBufs d, int i, const
 }  // namespace
 
 size_t decoder_pmel_floats(int B) { return (size_t)B * PM_ROWS * MEL_LD; }
+
+namespace {
+__global__ void k_dimgroup_transpose(const float4 *__restrict__ in, float4 *out, int B, int T) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // float4 index of the [B][T][32] input
+  if (i >= (size_t)B * T * (ATT_DIM / 4)) return;
+  const int g = (int)(i % (ATT_DIM / 4)), t = (int)((i / (ATT_DIM / 4)) % T), b = (int)(i / ((size_t)(ATT_DIM / 4) * T));
+  out[((size_t)b * (ATT_DIM / 4) + g) * T + t] = in[i];
+}
+}  // namespace
+
+void launch_dimgroup_transpose(const float *in, float *out, int B, int T, hipStream_t s) {
+  const size_t n = (size_t)B * T * (ATT_DIM / 4);
+  hipLaunchKernelGGL(k_dimgroup_transpose, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const float4 *>(in),
+                     reinterpret_cast<float4 *>(out), B, T);
+  HIP_CHECK(hipGetLastError());
+}
 
 void launch_decoder_init(const DecoderBufs &d, const int *limits_dev, hipStream_t s) {
   // partial-mel rows are summed unconditionally; padding columns 81..83 and a first step's rows

@@ -41,7 +41,12 @@ struct DecoderBufs {
   float *awc2;           // [B][T] second cumulative-weights buffer (ping-pong by step parity, batched mode)
   const int *item_perm;  // [B] dropout-stream index of chunk b (the batch is sorted by length), or null = b
   const float *dec_in;   // parity hook (xdtts_tacotron2_decoder_step): decoder_input [B][80] of this step, or null
+  // Batched mode: processed_memory a second time as [B][32 dim groups][T][4] -- the energies kernel reads 4 dims of
+  // every time step, 16 bytes out of each 512-byte row of the [T][128] layout; in batched mode `loc` has this layout too
+  const float *pmem_t;
 };
+// [B][T][128] -> [B][32][T][4]
+void launch_dimgroup_transpose(const float *in, float *out, int B, int T, hipStream_t s);
 
 // Enqueues `nsteps` decoder steps on `s` (5 kernels each) and advances the device step base.
 void launch_decoder_steps(const DecoderBufs &d, const DeviceWeights &w, int nsteps, hipStream_t s);
