@@ -284,9 +284,9 @@ struct xdtts_tacotron2 {
   DecoderBufs decoder_bufs(int B, int T, const float *mem, const float *pm, const xdtts_infer_opts &o) {
     const int ms = o.max_steps;
     att_h.alloc((size_t)2 * B * ATT_RNN);
-    att_c.alloc((size_t)B * ATT_RNN);
+    att_c.alloc((size_t)((B + 15) / 16 * 16) * ATT_RNN);  // (batched mode: [256][Bpad][4])
     dec_h.alloc((size_t)2 * B * DEC_RNN);
-    dec_c.alloc((size_t)B * DEC_RNN);
+    dec_c.alloc((size_t)((B + 15) / 16 * 16) * DEC_RNN);
     aw.alloc((size_t)B * T);
     awc.alloc((size_t)B * T);
     ctx.alloc((size_t)B * EMB);

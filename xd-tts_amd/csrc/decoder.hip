@@ -748,7 +748,8 @@ __device__ __forceinline__ void lstm_mfma_pass(const DecoderBufs &d, int n0, int
     const int n = n0 + 16 * wave + fi, unit = blk * 4 + fg;
     float hn = 0.f;
     if (n < d.B) {
-      const float c_old = cst[(size_t)n * ATT_RNN + unit];
+      const size_t ci = ((size_t)blk * d.Bpad + n) * 4 + fg;  // batched cell state: [256 blocks][Bpad][4 units], one 256-byte run per tile
+      const float c_old = cst[ci];
       // hardware exp2 / rcp forms (device_utils.h), as in the persistent engine: this tail runs on NTA of
       // the waves while the others wait
       const float ig = fast_sigmoid(g[0] + bz.x), fgt = fast_sigmoid(g[1] + bz.y);
@@ -756,7 +757,7 @@ __device__ __forceinline__ void lstm_mfma_pass(const DecoderBufs &d, int n0, int
       const float cn = fmaf(fgt, c_old, ig * gg);
       hn = og * fast_tanh(cn);
       if ((active >> (16 * wave + fi)) & 1ull) {
-        cst[(size_t)n * ATT_RNN + unit] = cn;
+        cst[ci] = cn;
         h_out[(size_t)n * ATT_RNN + unit] = hn;
         hf_out[((size_t)blk * d.Bpad + n) * 4 + fg] = hn;
       }
@@ -1051,6 +1052,10 @@ void launch_dimgroup_transpose(const float *in, float *out, int B, int T, hipStr
 }
 
 void launch_decoder_init(const DecoderBufs &d, const int *limits_dev, hipStream_t s) {
+  if (d.xf) {  // batched mode keeps the cell states in the LSTM kernel's own order, padded to Bpad chunks
+    HIP_CHECK(hipMemsetAsync(d.att_c, 0, sizeof(float) * (size_t)d.Bpad * ATT_RNN, s));
+    HIP_CHECK(hipMemsetAsync(d.dec_c, 0, sizeof(float) * (size_t)d.Bpad * DEC_RNN, s));
+  }
   // partial-mel rows are summed unconditionally; padding columns 81..83 and a first step's rows
   // must read as zero
   HIP_CHECK(hipMemsetAsync(d.pmel, 0, decoder_pmel_floats(d.B) * sizeof(float), s));
