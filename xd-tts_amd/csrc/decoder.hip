@@ -758,7 +758,7 @@ __device__ __forceinline__ void lstm_mfma_pass(const DecoderBufs &d, int n0, int
       hn = og * fast_tanh(cn);
       if ((active >> (16 * wave + fi)) & 1ull) {
         cst[ci] = cn;
-        h_out[(size_t)n * ATT_RNN + unit] = hn;
+        if (KIND == 0) h_out[(size_t)n * ATT_RNN + unit] = hn;  // (row-major copy: the energies kernel reads it; nobody reads dec_h that way)
         hf_out[((size_t)blk * d.Bpad + n) * 4 + fg] = hn;
       }
     }
