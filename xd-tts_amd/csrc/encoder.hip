@@ -47,9 +47,11 @@ __global__ __launch_bounds__(1024) void k_bilstm_coop(const float *__restrict__ 
   if (tid < ENC_H) h[tid] = 0.f;
   if (tid == 0) dead = 0;
   __syncthreads();
+  float xnext = q == 0 ? xp[(size_t)(dir ? T - 1 : 0) * (4 * ENC_H) + row] : 0.f;  // the input projection runs one step ahead of its use
   for (int s = 0; s < T; ++s) {
     const int t = dir ? T - 1 - s : s;
-    const float xin = q == 0 ? xp[(size_t)t * (4 * ENC_H) + row] : 0.f;
+    const float xin = xnext;
+    if (q == 0 && s + 1 < T) xnext = xp[(size_t)(dir ? T - 2 - s : s + 1) * (4 * ENC_H) + row];
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
     for (int j = 0; j < 64; j += 4) {
