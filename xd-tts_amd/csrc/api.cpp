@@ -168,6 +168,10 @@ struct xdtts_tacotron2 {
   DevBuf<int> enc_err;
   DevBuf<unsigned long long> dec_exchange;  // granule buffers of the persistent decoder
   DevBuf<int> dec_err;
+  DevBuf<unsigned long long> att_exchange;
+  // batched mode: energies, softmax and context in one launch (XDTTS_ATT_FUSED=0: the two-kernel form; also after
+  // an exchange of that launch timed out)
+  bool att_fused = []() { const char *e = getenv("XDTTS_ATT_FUSED"); return !(e && e[0] == '0'); }();
   int persist_state = -1;                   // -1 unknown, 0 unavailable on this device / demoted, 1 usable
   bool persist_probe_ok = false;            // the device can host the persistent grid (occupancy probe)
   bool coop_ok = true;                      // cooperative encoder BiLSTM usable (cleared after a timed-out exchange)
@@ -341,6 +345,11 @@ struct xdtts_tacotron2 {
       pmem_t.alloc((size_t)B * T * ATT_DIM);
       launch_dimgroup_transpose(pm, pmem_t.p, B, T, stream);
       d.pmem_t = pmem_t.p;
+      if (att_fused && T <= T_MAX) {  // one-launch attention: partial energies cross as tagged granules
+        att_exchange.alloc((size_t)B * ATT_EXCHANGE_BLOCKS * T);
+        d.ep_g = att_exchange.p;
+        d.att_err = dec_err.p;
+      }
     }
     return d;
   }
@@ -539,6 +548,20 @@ struct xdtts_tacotron2 {
       // the projection of step s is completed by the first kernel of step s+1: finish the last one
       launch_decoder_flush(d, w, stream);
       fetch();
+    }
+    if (d.ep_g) {
+      int e = 0;
+      HIP_CHECK(hipMemcpyAsync(&e, dec_err.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+      HIP_CHECK(hipStreamSynchronize(stream));
+      if (e) {  // a block of the one-launch attention never saw its neighbours' energies: not silent, not fatal
+        HIP_CHECK(hipMemsetAsync(dec_err.p, 0, sizeof(int), stream));
+        att_fused = false;
+        std::fprintf(stderr, "libxdtts_hip: batched attention exchange timed out; this handle now uses the "
+                             "two-kernel attention\n");
+        DecoderBufs d2 = d;
+        d2.ep_g = nullptr;
+        return run_decoder(d2, lim);
+      }
     }
     int steps = 0;
     for (int b = 0; b < d.B; ++b) steps = std::max(steps, host_ctl[2 + b]);

@@ -1031,6 +1031,190 @@ __global__ __launch_bounds__(256) void k_softmax_ctx(DecoderBufs d, int i, const
 #endif
 }
 
+
+// D3 for batches as ONE launch: CTX_BLOCKS (8) blocks per chunk, block (b, cblk) owns 16 of the 128 attention dims for
+// the energies and 64 of the 512 context columns.  What the two kernels above hand over through a grid boundary --
+// the partial energies, T floats per block -- crosses here the way the persistent engine's edges do: 8-byte
+// {tag = step + 1, value} granules, stored and polled with relaxed agent-scope (sc1) accesses, no fence, no
+// counter.  Every block publishes before it polls, the 8 blocks of a chunk are neighbours in dispatch order and
+// a CU holds at least two of them, so the wait is short; a bounded spin sets d.att_err instead of hanging (the host
+// then decodes the request again with the two-kernel form, api.cpp).  Chunks that have stopped leave at once.
+typedef unsigned long long u64;
+constexpr int AB_DIMS = ATT_DIM / CTX_BLOCKS;
+constexpr unsigned AB_SPIN_LIMIT = 1u << 20;
+static_assert(AB_DIMS == 16 && CTX_BLOCKS == ATT_EXCHANGE_BLOCKS, "four waves x four attention dims per block");
+__global__ __launch_bounds__(256) void k_attention_b(DecoderBufs d, int i, int cur, const float4 *__restrict__ Wq,
+                                                     const float *__restrict__ v_w, const float *__restrict__ proj_wc) {
+  const int b = blockIdx.x / CTX_BLOCKS, cblk = blockIdx.x % CTX_BLOCKS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int T = d.T;
+  const int step = d.ctl[0] + i;
+  if (step >= d.nframes[b]) return;  // (the step limits change in the prenet kernel only: all 8 blocks of a chunk agree)
+  constexpr int C4 = CTX_COLS / 4, TG = 256 / C4;  // 16 float4 columns x 16 time groups
+  constexpr int CTX_PF = 7;
+  __shared__ __attribute__((aligned(16))) float s_e[T_MAX], s_eg[4][T_MAX], s_part[TG][CTX_COLS], s_ctx[CTX_COLS];
+  // ---- loads in the order they are needed (vmcnt retires in issue order) ----
+  const int gq = 4 * cblk + wave;  // this wave's group of four attention dims
+  float4 hv[4], wq[4][4];
+  {
+    const float *h = d.att_h[cur ^ 1] + (size_t)b * ATT_RNN;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) hv[k] = *reinterpret_cast<const float4 *>(h + 256 * k + 4 * lane);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) wq[r][k] = Wq[(size_t)(4 * gq + r) * (ATT_RNN / 4) + lane + 64 * k];
+  }
+  const float *locg = d.loc + ((size_t)b * (ATT_DIM / 4) + gq) * T * 4, *pmg = d.pmem_t + ((size_t)b * (ATT_DIM / 4) + gq) * T * 4;
+  float4 l4[2], p4[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int t = lane + 64 * u < T ? lane + 64 * u : 0;
+    l4[u] = *reinterpret_cast<const float4 *>(locg + 4 * t);
+    p4[u] = *reinterpret_cast<const float4 *>(pmg + 4 * t);
+  }
+  const float4 v4 = *reinterpret_cast<const float4 *>(v_w + 4 * gq);
+  const float *awc_in = (i & 1) ? d.awc2 : d.awc;
+  float *awc_out = (i & 1) ? d.awc : d.awc2;
+  const int nv = d.n_valid[b];
+  const float awc_pre = tid < T ? awc_in[b * T + tid] : 0.f;
+  asm volatile("" ::: "memory");
+  const int pm_m = tid >> 1, pm_half = tid & 1;
+  float4 wc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    wc[k] = pm_m <= N_MEL ? reinterpret_cast<const float4 *>(proj_wc + ((size_t)cblk * (N_MEL + 1) + pm_m) * CTX_COLS + 32 * pm_half)[k]
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
+  const int c4 = tid % C4, tg = tid / C4;
+  const float4 *mem = reinterpret_cast<const float4 *>(d.memory + (size_t)b * T * EMB) + cblk * C4;
+  float4 pf[CTX_PF];
+#pragma unroll
+  for (int u = 0; u < CTX_PF; ++u) {
+    const int t = tg + TG * u;
+    pf[u] = t < T ? mem[(size_t)t * (EMB / 4) + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  asm volatile("" ::: "memory");
+  // ---- processed query: the four rows of this wave's dims, no LDS (wave_sum leaves the total in every lane) ----
+  float4 q4;
+  {
+    float a[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      a[r] = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a[r] = dot4(wq[r][k], hv[k], a[r]);
+      a[r] = wave_sum(a[r]);
+    }
+    q4 = make_float4(a[0], a[1], a[2], a[3]);
+  }
+  // ---- energies of this wave's four dims for every time step ----
+  auto energy = [&](const float4 l, const float4 p) {
+    float e = v4.x * fast_tanh(q4.x + l.x + p.x);
+    e = fmaf(v4.y, fast_tanh(q4.y + l.y + p.y), e);
+    e = fmaf(v4.z, fast_tanh(q4.z + l.z + p.z), e);
+    return fmaf(v4.w, fast_tanh(q4.w + l.w + p.w), e);
+  };
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+    if (lane + 64 * u < T) s_eg[wave][lane + 64 * u] = energy(l4[u], p4[u]);
+  for (int t = lane + 128; t < T; t += 64)
+    s_eg[wave][t] = energy(*reinterpret_cast<const float4 *>(locg + 4 * t), *reinterpret_cast<const float4 *>(pmg + 4 * t));
+  __syncthreads();
+  // ---- exchange: publish this block's 16-dim partial, collect the chunk's eight ----
+  const unsigned want = (unsigned)step + 1u;
+  u64 *slots = d.ep_g + (size_t)b * CTX_BLOCKS * T;
+  for (int t = tid; t < T; t += 256) {
+    const float e = (s_eg[0][t] + s_eg[1][t]) + (s_eg[2][t] + s_eg[3][t]);
+    __hip_atomic_store(slots + (size_t)cblk * T + t, ((u64)want << 32) | (u64)__float_as_uint(e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  for (int t = tid; t < T; t += 256) {
+    float part[CTX_BLOCKS];
+    unsigned pending = (1u << CTX_BLOCKS) - 1u, spins = 0;
+#pragma unroll
+    for (int k = 0; k < CTX_BLOCKS; ++k) part[k] = 0.f;
+    while (pending) {
+      u64 g[CTX_BLOCKS];
+#pragma unroll
+      for (int k = 0; k < CTX_BLOCKS; ++k)
+        if (pending >> k & 1u) g[k] = __hip_atomic_load(slots + (size_t)k * T + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int k = 0; k < CTX_BLOCKS; ++k)
+        if ((pending >> k & 1u) && (unsigned)(g[k] >> 32) == want) {
+          part[k] = __uint_as_float((unsigned)g[k]);
+          pending &= ~(1u << k);
+        }
+      if (pending) {
+        if (++spins > AB_SPIN_LIMIT || ((spins & 127u) == 0 && __hip_atomic_load(d.att_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+          atomicExch(d.att_err, 1);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    float e = part[0];
+#pragma unroll
+    for (int k = 1; k < CTX_BLOCKS; ++k) e += part[k];
+    s_e[t] = t >= nv ? -INFINITY : e;
+  }
+  __syncthreads();
+  // ---- softmax (every block of the chunk computes the same one), new weights, context slice, partial mel:
+  //      as k_softmax_ctx ----
+  if (wave == 0) {
+    float m = -INFINITY;
+    for (int t = lane; t < T; t += 64) m = fmaxf(m, s_e[t]);
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int t = lane; t < T; t += 64) {
+      const float ex = fast_exp(s_e[t] - m);
+      s_e[t] = ex;
+      sum += ex;
+    }
+    sum = wave_sum(sum);
+    for (int t = lane; t < T; t += 64) s_e[t] = s_e[t] / sum;
+  }
+  __syncthreads();
+  if (cblk == 0)
+    for (int t = tid; t < T; t += 256) {
+      const float wv = s_e[t];
+      d.aw[b * T + t] = wv;
+      awc_out[b * T + t] = (t == tid ? awc_pre : awc_in[b * T + t]) + wv;
+    }
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  int k = 0;
+  for (int t0 = tg; t0 < T; t0 += TG * CTX_PF) {
+#pragma unroll
+    for (int u = 0; u < CTX_PF; ++u) {
+      const int t = t0 + TG * u;
+      const float wv = t < T ? s_e[t] : 0.f;
+      const float4 mv = k == 0 ? pf[u] : (t < T ? mem[(size_t)t * (EMB / 4) + c4] : make_float4(0.f, 0.f, 0.f, 0.f));
+      acc.x = fmaf(wv, mv.x, acc.x);
+      acc.y = fmaf(wv, mv.y, acc.y);
+      acc.z = fmaf(wv, mv.z, acc.z);
+      acc.w = fmaf(wv, mv.w, acc.w);
+    }
+    ++k;
+  }
+  *reinterpret_cast<float4 *>(&s_part[tg][4 * c4]) = acc;
+  __syncthreads();
+  if (tid < CTX_COLS) {
+    float v = 0.f;
+#pragma unroll
+    for (int g = 0; g < TG; ++g) v += s_part[g][tid];
+    s_ctx[tid] = v;
+    const int j = cblk * CTX_COLS + tid;
+    d.ctx[b * EMB + j] = v;
+    d.ctxf[((size_t)(j >> 2) * d.Bpad + b) * 4 + (j & 3)] = v;
+  }
+  __syncthreads();
+  {
+    float pv = 0.f;
+#pragma unroll
+    for (int k2 = 0; k2 < 8; ++k2) pv = dot4(wc[k2], *reinterpret_cast<const float4 *>(&s_ctx[32 * pm_half + 4 * k2]), pv);
+    pv += dpp_move<0xB1, 0xf>(0.f, pv);  // lanes 2j, 2j+1 hold the two halves of row m
+    if (pm_half == 0 && pm_m <= N_MEL) d.pmel[((size_t)b * PM_ROWS + cblk) * MEL_LD + pm_m] = pv;
+  }
+}
+
 }  // namespace
 
 size_t decoder_pmel_floats(int B) { return (size_t)B * PM_ROWS * MEL_LD; }
@@ -1059,6 +1243,7 @@ void launch_decoder_init(const DecoderBufs &d, const int *limits_dev, hipStream_
   // partial-mel rows are summed unconditionally; padding columns 81..83 and a first step's rows
   // must read as zero
   HIP_CHECK(hipMemsetAsync(d.pmel, 0, decoder_pmel_floats(d.B) * sizeof(float), s));
+  if (d.ep_g) HIP_CHECK(hipMemsetAsync(d.ep_g, 0, sizeof(unsigned long long) * (size_t)d.B * CTX_BLOCKS * d.T, s));  // step tags restart at 1
   hipLaunchKernelGGL(k_decoder_init, dim3(d.B), dim3(256), 0, s, d, limits_dev);
   HIP_CHECK(hipGetLastError());
 }
@@ -1098,10 +1283,16 @@ void launch_decoder_steps(const DecoderBufs &d, const DeviceWeights &w, int nste
                                w.loc_conv.p, w.loc_denseT.p);
           break;
         case 'q':
+          if (batched && d.ep_g) {  // energies + softmax + context in one launch ('s' is then a no-op)
+            hipLaunchKernelGGL(k_attention_b, dim3(CTX_BLOCKS * d.B), dim3(256), 0, s, d, i, cur, reinterpret_cast<const float4 *>(w.q_w.p),
+                               w.v_w.p, w.proj_wc.p);
+            break;
+          }
           hipLaunchKernelGGL(k_qenergy, dim3(ATT_DIM / 4, batched ? std::max(2, (d.B + QE_GROUP - 1) / QE_GROUP) : 1), dim3(256), 0, s, d, i, cur,
                              reinterpret_cast<const float4 *>(w.q_w.p), w.v_w.p);
           break;
         case 's':
+          if (batched && d.ep_g) break;
           hipLaunchKernelGGL(k_softmax_ctx, dim3(CTX_BLOCKS * d.B), dim3(256), 0, s, d, i, w.proj_wc.p);
           break;
         case 'd':

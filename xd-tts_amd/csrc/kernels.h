@@ -44,7 +44,13 @@ struct DecoderBufs {
   // Batched mode: processed_memory a second time as [B][32 dim groups][T][4] -- the energies kernel reads 4 dims of
   // every time step, 16 bytes out of each 512-byte row of the [T][128] layout; in batched mode `loc` has this layout too
   const float *pmem_t;
+  // Batched mode, one-launch attention (k_attention_b): the 8 blocks of a chunk exchange their partial energies as
+  // {tag = step + 1, value} granules [B][8][T]; null = the energies / context kernel pair.  att_err: set by a block
+  // whose bounded spin ran out.
+  unsigned long long *ep_g;
+  int *att_err;
 };
+constexpr int ATT_EXCHANGE_BLOCKS = 8;  // granule rows per chunk (CTX_BLOCKS in decoder.hip)
 // [B][T][128] -> [B][32][T][4]
 void launch_dimgroup_transpose(const float *in, float *out, int B, int T, hipStream_t s);
 
