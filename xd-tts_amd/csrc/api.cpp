@@ -171,7 +171,7 @@ struct xdtts_tacotron2 {
   DevBuf<unsigned long long> att_exchange;
   // batched mode: energies, softmax and context in one launch (XDTTS_ATT_FUSED=0: the two-kernel form; also after
   // an exchange of that launch timed out)
-  bool att_fused = []() { const char *e = getenv("XDTTS_ATT_FUSED"); return !(e && e[0] == '0'); }();
+  int att_fused = []() { const char *e = getenv("XDTTS_ATT_FUSED"); return e ? atoi(e) : 2; }();  // 2: with the attention LSTM
   int persist_state = -1;                   // -1 unknown, 0 unavailable on this device / demoted, 1 usable
   bool persist_probe_ok = false;            // the device can host the persistent grid (occupancy probe)
   bool coop_ok = true;                      // cooperative encoder BiLSTM usable (cleared after a timed-out exchange)
@@ -345,10 +345,12 @@ struct xdtts_tacotron2 {
       pmem_t.alloc((size_t)B * T * ATT_DIM);
       launch_dimgroup_transpose(pm, pmem_t.p, B, T, stream);
       d.pmem_t = pmem_t.p;
-      if (att_fused && T <= T_MAX) {  // one-launch attention: partial energies cross as tagged granules
-        att_exchange.alloc((size_t)B * ATT_EXCHANGE_BLOCKS * T);
+      if (att_fused > 0 && T <= T_MAX) {  // one-launch attention: partial energies cross as tagged granules
+        const size_t ne = (size_t)B * ATT_EXCHANGE_BLOCKS * T;
+        att_exchange.alloc(ne + (size_t)B * ATT_RNN);
         d.ep_g = att_exchange.p;
         d.att_err = dec_err.p;
+        if (att_fused > 1 && B <= 64) d.hg = att_exchange.p + ne;  // ... and the attention LSTM in the same launch
       }
     }
     return d;
@@ -526,6 +528,10 @@ struct xdtts_tacotron2 {
                            "this handle now uses the launch-per-stage decoder (probed again after %d calls)\n", PROBE_AFTER);
       launch_decoder_init(d, limits.p, stream);
     }
+    // the launch that holds the attention LSTM and the attention needs its 256 blocks resident together: like the
+    // persistent engine's, such launches of different handles never overlap
+    std::unique_lock<std::recursive_mutex> chip;
+    if (d.hg) chip = std::unique_lock<std::recursive_mutex>(chip_mutex(device));
     if (!d.use_gate) {  // deterministic work: every chunk runs to its cap
       while (launched < max_lim) {
         replay_steps(d);
@@ -555,11 +561,12 @@ struct xdtts_tacotron2 {
       HIP_CHECK(hipStreamSynchronize(stream));
       if (e) {  // a block of the one-launch attention never saw its neighbours' energies: not silent, not fatal
         HIP_CHECK(hipMemsetAsync(dec_err.p, 0, sizeof(int), stream));
-        att_fused = false;
+        att_fused = 0;
         std::fprintf(stderr, "libxdtts_hip: batched attention exchange timed out; this handle now uses the "
-                             "two-kernel attention\n");
+                             "separate attention kernels\n");
         DecoderBufs d2 = d;
         d2.ep_g = nullptr;
+        d2.hg = nullptr;
         return run_decoder(d2, lim);
       }
     }

@@ -661,10 +661,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // software-pipelined three k-steps deep so that L2 latency hides behind the other tiles' MFMAs.
 // Tiles whose 16 chunks have all stopped are skipped (the batch is sorted by length, so the active
 // tiles form a prefix): NTA = active tiles of this pass, a compile-time count per code path.
-template <int NCOLS, int KIND, int NTA>
+struct NoHook {
+  __device__ __forceinline__ void operator()() const {}
+};
+// after_loop: runs once this wave has issued its last operand load (and the cell-state load of the tail): the
+// attention-LSTM launch puts the loads of its attention phase there, behind nothing the LSTM pass still waits for
+template <int NCOLS, int KIND, int NTA, class Hook = NoHook>
 __device__ __forceinline__ void lstm_mfma_pass(const DecoderBufs &d, int n0, int cur, int step, int blk, const float4 *__restrict__ wsrc,
                                                const float4 bz, const float4 we, float *s_acc, float *s_h, unsigned long long active,
-                                               unsigned long long d_probe_entry = 0) {  // active: bit j = chunk n0 + j still runs at this step
+                                               unsigned long long d_probe_entry = 0, Hook after_loop = Hook()) {  // active: bit j = chunk n0 + j still runs at this step
   constexpr int NW = MFMA_WAVES, KW = NCOLS / NW, JJ = KW / 16;
   constexpr int N0 = KIND == 0 ? PRENET : ATT_RNN, N1 = EMB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fi = lane & 15, fg = lane >> 4;
@@ -692,14 +697,17 @@ __device__ __forceinline__ void lstm_mfma_pass(const DecoderBufs &d, int n0, int
   // i.e. for the whole 42 MB HBM stream, and the MFMAs could not overlap it (measured: 5-12 us from kernel
   // entry to the first MFMA).  Both streams are issued in consumption order instead: weights three
   // k-steps ahead (HBM latency), activations two (L2).
-  float4 ring[3][NTA], wring[8];
 #ifndef XDTTS_LSTM_DW
 #define XDTTS_LSTM_DW 3  // (4 and 6 measured slower: every activation vector then queues behind more weight loads)
 #endif
-  constexpr int DW = XDTTS_LSTM_DW, DX = 2;
+#ifndef XDTTS_LSTM_DX
+#define XDTTS_LSTM_DX 2  // activations: 1 -> 41.0, 2 -> 38.5, 3 -> 38.5 (DW 3) / 38.8 (DW 4), 4 -> 39.1-39.7, 6 -> 41.2 us per 52-chunk iteration
+#endif
+  constexpr int DW = XDTTS_LSTM_DW, DX = XDTTS_LSTM_DX, RX = DX + 1;
+  float4 ring[RX][NTA], wring[8];
 #pragma unroll
-  for (int p = 0; p < DW && p < JJ; ++p) {
-    wring[p] = wsrc[(size_t)p * 64];  // plain loads: with the non-temporal hint of the GEMV kernels the 52-chunk iteration took 2.3 us longer
+  for (int p = 0; p < (DW > DX ? DW : DX) && p < JJ; ++p) {
+    if (p < DW) wring[p] = wsrc[(size_t)p * 64];  // plain loads: with the non-temporal hint of the GEMV kernels the 52-chunk iteration took 2.3 us longer
                                       // (the 71 MB of weights fit the 256 MB Infinity Cache and are read again 50 us later)
     if (p < DX) {
       const float4 *sp = src(p);
@@ -715,13 +723,13 @@ __device__ __forceinline__ void lstm_mfma_pass(const DecoderBufs &d, int n0, int
     if (jj + DX < JJ) {
       const float4 *sp = src(jj + DX);
 #pragma unroll
-      for (int t = 0; t < NTA; ++t) ring[(jj + DX) % 3][t] = sp[16 * t];
+      for (int t = 0; t < NTA; ++t) ring[(jj + DX) % RX][t] = sp[16 * t];  // (non-temporal: 38.5 -> 45 us per iteration, the 32 CUs of an XCD share these lines in L2)
     }
     asm volatile("" ::: "memory");
     if (jj + DW < JJ) wring[(jj + DW) % 8] = wsrc[(size_t)(jj + DW) * 64];
     asm volatile("" ::: "memory");
     const float4 wv = wring[jj % 8];
-    const float4(&xv)[NTA] = ring[jj % 3];
+    const float4(&xv)[NTA] = ring[jj % RX];
     // interleave the tiles so consecutive MFMAs hit different accumulators (40-cycle dependent latency)
 #pragma unroll
     for (int t = 0; t < NTA; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, xv[t].x, acc[t], 0, 0, 0);
@@ -733,14 +741,20 @@ __device__ __forceinline__ void lstm_mfma_pass(const DecoderBufs &d, int n0, int
     for (int t = 0; t < NTA; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, xv[t].w, acc[t], 0, 0, 0);
   }
   PROBE(1);
+  float *h_out = KIND == 0 ? d.att_h[cur ^ 1] : d.dec_h[cur ^ 1];
+  float *hf_out = KIND == 0 ? d.att_hf[cur ^ 1] : d.dec_hf[cur ^ 1];
+  float *cst = KIND == 0 ? d.att_c : d.dec_c;
+  // batched cell state: [256 blocks][Bpad][4 units], one 256-byte run per tile
+  const size_t ci = ((size_t)blk * d.Bpad + n0 + 16 * (wave < NTA ? wave : 0) + fi) * 4 + fg;
+  float c_old = 0.f;
+  if (wave < NTA && n0 + 16 * wave + fi < d.B) c_old = cst[ci];
+  asm volatile("" ::: "memory");
+  after_loop();
   // [K-slice][tile][lane][gate]
 #pragma unroll
   for (int t = 0; t < NTA; ++t) *reinterpret_cast<f32x4 *>(s_acc + ((size_t)(wave * 4 + t) * 64 + lane) * 4) = acc[t];
   __syncthreads();
   PROBE(2);
-  float *h_out = KIND == 0 ? d.att_h[cur ^ 1] : d.dec_h[cur ^ 1];
-  float *hf_out = KIND == 0 ? d.att_hf[cur ^ 1] : d.dec_hf[cur ^ 1];
-  float *cst = KIND == 0 ? d.att_c : d.dec_c;
   if (wave < NTA) {  // wave t finalises chunk tile t: lane = (chunk fi, unit fg), regs = gates i,f,g,o
     f32x4 g = *reinterpret_cast<const f32x4 *>(s_acc + ((size_t)wave * 64 + lane) * 4);
 #pragma unroll
@@ -748,8 +762,6 @@ __device__ __forceinline__ void lstm_mfma_pass(const DecoderBufs &d, int n0, int
     const int n = n0 + 16 * wave + fi, unit = blk * 4 + fg;
     float hn = 0.f;
     if (n < d.B) {
-      const size_t ci = ((size_t)blk * d.Bpad + n) * 4 + fg;  // batched cell state: [256 blocks][Bpad][4 units], one 256-byte run per tile
-      const float c_old = cst[ci];
       // hardware exp2 / rcp forms (device_utils.h), as in the persistent engine: this tail runs on NTA of
       // the waves while the others wait
       const float ig = fast_sigmoid(g[0] + bz.x), fgt = fast_sigmoid(g[1] + bz.y);
@@ -758,7 +770,13 @@ __device__ __forceinline__ void lstm_mfma_pass(const DecoderBufs &d, int n0, int
       hn = og * fast_tanh(cn);
       if ((active >> (16 * wave + fi)) & 1ull) {
         cst[ci] = cn;
-        if (KIND == 0) h_out[(size_t)n * ATT_RNN + unit] = hn;  // (row-major copy: the energies kernel reads it; nobody reads dec_h that way)
+        if (KIND == 0) {  // (row-major copy: the energies kernel reads it; nobody reads dec_h that way)
+          if (d.hg)
+            __hip_atomic_store(d.hg + (size_t)n * ATT_RNN + unit, ((unsigned long long)((unsigned)step + 1u) << 32) | (unsigned long long)__float_as_uint(hn),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else
+            h_out[(size_t)n * ATT_RNN + unit] = hn;
+        }
         hf_out[((size_t)blk * d.Bpad + n) * 4 + fg] = hn;
       }
     }
@@ -1032,68 +1050,140 @@ __global__ __launch_bounds__(256) void k_softmax_ctx(DecoderBufs d, int i, const
 }
 
 
-// D3 for batches as ONE launch: CTX_BLOCKS (8) blocks per chunk, block (b, cblk) owns 16 of the 128 attention dims for
-// the energies and 64 of the 512 context columns.  What the two kernels above hand over through a grid boundary --
-// the partial energies, T floats per block -- crosses here the way the persistent engine's edges do: 8-byte
-// {tag = step + 1, value} granules, stored and polled with relaxed agent-scope (sc1) accesses, no fence, no
-// counter.  Every block publishes before it polls, the 8 blocks of a chunk are neighbours in dispatch order and
-// a CU holds at least two of them, so the wait is short; a bounded spin sets d.att_err instead of hanging (the host
-// then decodes the request again with the two-kernel form, api.cpp).  Chunks that have stopped leave at once.
+// D3 for batches as ONE launch: NB blocks per chunk (8 of 256 threads, or 4 of 512 inside the attention-LSTM launch
+// below), block (b, part) owns 128 / NB attention dims for the energies and 512 / NB context columns.  What the two
+// kernels above hand over through a grid boundary -- the partial energies, T floats per block -- crosses here the way
+// the persistent engine's edges do: 8-byte {tag = step + 1, value} granules, stored and polled with relaxed
+// agent-scope (sc1) accesses, no fence, no counter.  Every block publishes before it polls, the blocks of a chunk are
+// neighbours in dispatch order, so the wait is short; a bounded spin sets d.att_err instead of hanging (the host
+// then decodes the request again with the two-kernel form, api.cpp).  Chunks that have stopped are skipped.
 typedef unsigned long long u64;
-constexpr int AB_DIMS = ATT_DIM / CTX_BLOCKS;
 constexpr unsigned AB_SPIN_LIMIT = 1u << 20;
-static_assert(AB_DIMS == 16 && CTX_BLOCKS == ATT_EXCHANGE_BLOCKS, "four waves x four attention dims per block");
-__global__ __launch_bounds__(256) void k_attention_b(DecoderBufs d, int i, int cur, const float4 *__restrict__ Wq,
-                                                     const float *__restrict__ v_w, const float *__restrict__ proj_wc) {
-  const int b = blockIdx.x / CTX_BLOCKS, cblk = blockIdx.x % CTX_BLOCKS;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int T = d.T;
-  const int step = d.ctl[0] + i;
-  if (step >= d.nframes[b]) return;  // (the step limits change in the prenet kernel only: all 8 blocks of a chunk agree)
-  constexpr int C4 = CTX_COLS / 4, TG = 256 / C4;  // 16 float4 columns x 16 time groups
-  constexpr int CTX_PF = 7;
-  __shared__ __attribute__((aligned(16))) float s_e[T_MAX], s_eg[4][T_MAX], s_part[TG][CTX_COLS], s_ctx[CTX_COLS];
-  // ---- loads in the order they are needed (vmcnt retires in issue order) ----
-  const int gq = 4 * cblk + wave;  // this wave's group of four attention dims
-  float4 hv[4], wq[4][4];
-  {
+__device__ __forceinline__ void granule_store(u64 *slot, unsigned tag, float v) {
+  __hip_atomic_store(slot, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// N granules at base[idx + k * stride], polled together until every tag equals `want`; a timed-out slot reads as 0.0f
+template <int N>
+__device__ __forceinline__ void granule_gather(const u64 *base, size_t idx, size_t stride, unsigned want, float (&out)[N], int *err) {
+  unsigned pending = (1u << N) - 1u, spins = 0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) out[k] = 0.f;
+  while (pending) {
+    u64 g[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+      if (pending >> k & 1u) g[k] = __hip_atomic_load(base + idx + (size_t)k * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+      if ((pending >> k & 1u) && (unsigned)(g[k] >> 32) == want) {
+        out[k] = __uint_as_float((unsigned)g[k]);
+        pending &= ~(1u << k);
+      }
+    if (pending) {
+      if (++spins > AB_SPIN_LIMIT || ((spins & 127u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+        atomicExch(err, 1);
+        return;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+}
+
+// Every global load of the attention phase that does not depend on this step's attention-LSTM output, issued in the
+// order the values are needed (vmcnt retires in issue order).
+struct AttentionLoads {
+  float4 hv[4], wq[4][4], l4[2], p4[2], v4, wc[8], pf[7];
+  float awc_pre;
+  int nv;
+};
+template <int NT, bool HG>
+__device__ __forceinline__ void attention_loads(AttentionLoads &L, const DecoderBufs &d, int i, int cur, int b, int part,
+                                                const float4 *__restrict__ Wq, const float *__restrict__ v_w,
+                                                const float *__restrict__ proj_wc) {
+  constexpr int NWV = NT / 64, NB = ATT_DIM / (4 * NWV), COLS = EMB / NB, C4 = COLS / 4, TG = NT / C4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, T = d.T;
+  const int gq = NWV * part + wave;  // this wave's group of four attention dims
+  if (!HG) {
     const float *h = d.att_h[cur ^ 1] + (size_t)b * ATT_RNN;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) hv[k] = *reinterpret_cast<const float4 *>(h + 256 * k + 4 * lane);
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) wq[r][k] = Wq[(size_t)(4 * gq + r) * (ATT_RNN / 4) + lane + 64 * k];
+    for (int k = 0; k < 4; ++k) L.hv[k] = *reinterpret_cast<const float4 *>(h + 256 * k + 4 * lane);
   }
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) L.wq[r][k] = Wq[(size_t)(4 * gq + r) * (ATT_RNN / 4) + lane + 64 * k];
   const float *locg = d.loc + ((size_t)b * (ATT_DIM / 4) + gq) * T * 4, *pmg = d.pmem_t + ((size_t)b * (ATT_DIM / 4) + gq) * T * 4;
-  float4 l4[2], p4[2];
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int t = lane + 64 * u < T ? lane + 64 * u : 0;
-    l4[u] = *reinterpret_cast<const float4 *>(locg + 4 * t);
-    p4[u] = *reinterpret_cast<const float4 *>(pmg + 4 * t);
+    L.l4[u] = *reinterpret_cast<const float4 *>(locg + 4 * t);
+    L.p4[u] = *reinterpret_cast<const float4 *>(pmg + 4 * t);
   }
-  const float4 v4 = *reinterpret_cast<const float4 *>(v_w + 4 * gq);
-  const float *awc_in = (i & 1) ? d.awc2 : d.awc;
-  float *awc_out = (i & 1) ? d.awc : d.awc2;
-  const int nv = d.n_valid[b];
-  const float awc_pre = tid < T ? awc_in[b * T + tid] : 0.f;
+  L.v4 = *reinterpret_cast<const float4 *>(v_w + 4 * gq);
+  L.nv = d.n_valid[b];
+  L.awc_pre = tid < T ? ((i & 1) ? d.awc2 : d.awc)[b * T + tid] : 0.f;
   asm volatile("" ::: "memory");
-  const int pm_m = tid >> 1, pm_half = tid & 1;
-  float4 wc[8];
+  // projection rows of the 64-column block cblk: thread (m, half) of each 256-thread group holds 32 columns of row m
+  const int csub = tid >> 8, pm_m = (tid & 255) >> 1, pm_half = tid & 1, cblk = (COLS / CTX_COLS) * part + csub;
 #pragma unroll
   for (int k = 0; k < 8; ++k)
-    wc[k] = pm_m <= N_MEL ? reinterpret_cast<const float4 *>(proj_wc + ((size_t)cblk * (N_MEL + 1) + pm_m) * CTX_COLS + 32 * pm_half)[k]
-                          : make_float4(0.f, 0.f, 0.f, 0.f);
+    L.wc[k] = pm_m <= N_MEL ? reinterpret_cast<const float4 *>(proj_wc + ((size_t)cblk * (N_MEL + 1) + pm_m) * CTX_COLS + 32 * pm_half)[k]
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
   const int c4 = tid % C4, tg = tid / C4;
-  const float4 *mem = reinterpret_cast<const float4 *>(d.memory + (size_t)b * T * EMB) + cblk * C4;
-  float4 pf[CTX_PF];
+  const float4 *mem = reinterpret_cast<const float4 *>(d.memory + (size_t)b * T * EMB) + part * C4;
 #pragma unroll
-  for (int u = 0; u < CTX_PF; ++u) {
+  for (int u = 0; u < 7; ++u) {
     const int t = tg + TG * u;
-    pf[u] = t < T ? mem[(size_t)t * (EMB / 4) + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    L.pf[u] = t < T ? mem[(size_t)t * (EMB / 4) + c4] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   asm volatile("" ::: "memory");
+}
+
+// lds: T_MAX + (NT / 64) T_MAX + 17 (512 / NB) + 1024 floats.  HG: the attention-LSTM output of this step
+// arrives as granules d.hg[b][1024] (published by the LSTM phase of the same launch) instead of the row-major vector.
+template <int NT, bool HG>
+__device__ __forceinline__ void attention_chunk(const DecoderBufs &d, int i, int step, int b, int part, float *lds, AttentionLoads &L,
+                                                const float *__restrict__ proj_wc) {
+  constexpr int NWV = NT / 64, NB = ATT_DIM / (4 * NWV);       // a wave takes four attention dims
+  constexpr int COLS = EMB / NB, C4 = COLS / 4, TG = NT / C4;  // context columns of this block; 16 time groups
+  constexpr int CTX_PF = 7;
+  static_assert(TG == 16 && COLS % CTX_COLS == 0 && NB <= ATT_EXCHANGE_BLOCKS && ATT_RNN % NT == 0, "block shape");
+  float *s_e = lds, *s_eg = s_e + T_MAX, *s_part = s_eg + NWV * T_MAX, *s_ctx = s_part + TG * COLS, *s_hv = s_ctx + COLS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int T = d.T;
+  const unsigned want = (unsigned)step + 1u;
+#ifdef XDTTS_LSTM_PROBE
+  unsigned long long ap[8];
+  ap[0] = wall_clock64();
+#define APROBE(i) ap[i] = wall_clock64()
+#else
+#define APROBE(i) do { } while (0)
+#endif
+  const int gq = NWV * part + wave;
+  const float *locg = d.loc + ((size_t)b * (ATT_DIM / 4) + gq) * T * 4, *pmg = d.pmem_t + ((size_t)b * (ATT_DIM / 4) + gq) * T * 4;
+  float4 (&hv)[4] = L.hv;
+  const float4 (&wq)[4][4] = L.wq;
+  const float4 (&l4)[2] = L.l4, (&p4)[2] = L.p4, (&wc)[8] = L.wc, (&pf)[7] = L.pf;
+  const float4 v4 = L.v4;
+  const float *awc_in = (i & 1) ? d.awc2 : d.awc;
+  float *awc_out = (i & 1) ? d.awc : d.awc2;
+  const int nv = L.nv;
+  const float awc_pre = L.awc_pre;
+  const int csub = tid >> 8, pm_m = (tid & 255) >> 1, pm_half = tid & 1, cblk = (COLS / CTX_COLS) * part + csub;
+  const int c4 = tid % C4, tg = tid / C4;
+  const float4 *mem = reinterpret_cast<const float4 *>(d.memory + (size_t)b * T * EMB) + part * C4;
+  APROBE(1);
+  if (HG) {  // the 256 LSTM blocks of this launch each publish four units of every chunk
+    constexpr int NG = ATT_RNN / NT;
+    float g[NG];
+    granule_gather<NG>(d.hg, (size_t)b * ATT_RNN + tid, NT, want, g, d.att_err);
+#pragma unroll
+    for (int k = 0; k < NG; ++k) s_hv[tid + NT * k] = g[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) hv[k] = *reinterpret_cast<const float4 *>(s_hv + 256 * k + 4 * lane);
+  }
+  APROBE(2);
   // ---- processed query: the four rows of this wave's dims, no LDS (wave_sum leaves the total in every lane) ----
   float4 q4;
   {
@@ -1116,47 +1206,29 @@ __global__ __launch_bounds__(256) void k_attention_b(DecoderBufs d, int i, int c
   };
 #pragma unroll
   for (int u = 0; u < 2; ++u)
-    if (lane + 64 * u < T) s_eg[wave][lane + 64 * u] = energy(l4[u], p4[u]);
+    if (lane + 64 * u < T) s_eg[wave * T_MAX + lane + 64 * u] = energy(l4[u], p4[u]);
   for (int t = lane + 128; t < T; t += 64)
-    s_eg[wave][t] = energy(*reinterpret_cast<const float4 *>(locg + 4 * t), *reinterpret_cast<const float4 *>(pmg + 4 * t));
+    s_eg[wave * T_MAX + t] = energy(*reinterpret_cast<const float4 *>(locg + 4 * t), *reinterpret_cast<const float4 *>(pmg + 4 * t));
   __syncthreads();
-  // ---- exchange: publish this block's 16-dim partial, collect the chunk's eight ----
-  const unsigned want = (unsigned)step + 1u;
-  u64 *slots = d.ep_g + (size_t)b * CTX_BLOCKS * T;
-  for (int t = tid; t < T; t += 256) {
-    const float e = (s_eg[0][t] + s_eg[1][t]) + (s_eg[2][t] + s_eg[3][t]);
-    __hip_atomic_store(slots + (size_t)cblk * T + t, ((u64)want << 32) | (u64)__float_as_uint(e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  APROBE(3);
+  // ---- exchange: publish this block's partial, collect the chunk's NB ----
+  u64 *slots = d.ep_g + (size_t)b * ATT_EXCHANGE_BLOCKS * T;
+  for (int t = tid; t < T; t += NT) {
+    float e = 0.f;
+#pragma unroll
+    for (int k = 0; k < NWV; k += 4) e += (s_eg[k * T_MAX + t] + s_eg[(k + 1) * T_MAX + t]) + (s_eg[(k + 2) * T_MAX + t] + s_eg[(k + 3) * T_MAX + t]);
+    granule_store(slots + (size_t)part * T + t, want, e);
   }
-  for (int t = tid; t < T; t += 256) {
-    float part[CTX_BLOCKS];
-    unsigned pending = (1u << CTX_BLOCKS) - 1u, spins = 0;
+  for (int t = tid; t < T; t += NT) {
+    float pe[NB];
+    granule_gather<NB>(slots, t, T, want, pe, d.att_err);
+    float e = pe[0];
 #pragma unroll
-    for (int k = 0; k < CTX_BLOCKS; ++k) part[k] = 0.f;
-    while (pending) {
-      u64 g[CTX_BLOCKS];
-#pragma unroll
-      for (int k = 0; k < CTX_BLOCKS; ++k)
-        if (pending >> k & 1u) g[k] = __hip_atomic_load(slots + (size_t)k * T + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-      for (int k = 0; k < CTX_BLOCKS; ++k)
-        if ((pending >> k & 1u) && (unsigned)(g[k] >> 32) == want) {
-          part[k] = __uint_as_float((unsigned)g[k]);
-          pending &= ~(1u << k);
-        }
-      if (pending) {
-        if (++spins > AB_SPIN_LIMIT || ((spins & 127u) == 0 && __hip_atomic_load(d.att_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-          atomicExch(d.att_err, 1);
-          break;
-        }
-        __builtin_amdgcn_s_sleep(1);
-      }
-    }
-    float e = part[0];
-#pragma unroll
-    for (int k = 1; k < CTX_BLOCKS; ++k) e += part[k];
+    for (int k = 1; k < NB; ++k) e += pe[k];
     s_e[t] = t >= nv ? -INFINITY : e;
   }
   __syncthreads();
+  APROBE(4);
   // ---- softmax (every block of the chunk computes the same one), new weights, context slice, partial mel:
   //      as k_softmax_ctx ----
   if (wave == 0) {
@@ -1173,8 +1245,9 @@ __global__ __launch_bounds__(256) void k_attention_b(DecoderBufs d, int i, int c
     for (int t = lane; t < T; t += 64) s_e[t] = s_e[t] / sum;
   }
   __syncthreads();
-  if (cblk == 0)
-    for (int t = tid; t < T; t += 256) {
+  APROBE(5);
+  if (part == 0)
+    for (int t = tid; t < T; t += NT) {
       const float wv = s_e[t];
       d.aw[b * T + t] = wv;
       awc_out[b * T + t] = (t == tid ? awc_pre : awc_in[b * T + t]) + wv;
@@ -1194,14 +1267,14 @@ __global__ __launch_bounds__(256) void k_attention_b(DecoderBufs d, int i, int c
     }
     ++k;
   }
-  *reinterpret_cast<float4 *>(&s_part[tg][4 * c4]) = acc;
+  *reinterpret_cast<float4 *>(&s_part[tg * COLS + 4 * c4]) = acc;
   __syncthreads();
-  if (tid < CTX_COLS) {
+  if (tid < COLS) {
     float v = 0.f;
 #pragma unroll
-    for (int g = 0; g < TG; ++g) v += s_part[g][tid];
+    for (int g = 0; g < TG; ++g) v += s_part[g * COLS + tid];
     s_ctx[tid] = v;
-    const int j = cblk * CTX_COLS + tid;
+    const int j = part * COLS + tid;
     d.ctx[b * EMB + j] = v;
     d.ctxf[((size_t)(j >> 2) * d.Bpad + b) * 4 + (j & 3)] = v;
   }
@@ -1209,10 +1282,69 @@ __global__ __launch_bounds__(256) void k_attention_b(DecoderBufs d, int i, int c
   {
     float pv = 0.f;
 #pragma unroll
-    for (int k2 = 0; k2 < 8; ++k2) pv = dot4(wc[k2], *reinterpret_cast<const float4 *>(&s_ctx[32 * pm_half + 4 * k2]), pv);
+    for (int k2 = 0; k2 < 8; ++k2) pv = dot4(wc[k2], *reinterpret_cast<const float4 *>(&s_ctx[CTX_COLS * csub + 32 * pm_half + 4 * k2]), pv);
     pv += dpp_move<0xB1, 0xf>(0.f, pv);  // lanes 2j, 2j+1 hold the two halves of row m
     if (pm_half == 0 && pm_m <= N_MEL) d.pmel[((size_t)b * PM_ROWS + cblk) * MEL_LD + pm_m] = pv;
   }
+#ifdef XDTTS_LSTM_PROBE
+  APROBE(6);
+  if (tid == 0 && (step == 100 || step == 101) && (b == 0 || b == 17 || b == 40) && part == 0)
+    printf("probe attention NT %d chunk %d step %d: loads issued %llu  h gathered %llu  energies %llu  e gathered %llu  softmax %llu  ctx+pmel %llu (x10ns)\n", NT, b, step,
+           ap[1] - ap[0], ap[2] - ap[1], ap[3] - ap[2], ap[4] - ap[3], ap[5] - ap[4], ap[6] - ap[5]);
+#endif
+}
+
+constexpr int attention_lds_floats(int nt) { return T_MAX + nt / 64 * T_MAX + 17 * (EMB / (ATT_DIM / (nt / 16))) + ATT_RNN; }
+
+__global__ __launch_bounds__(256) void k_attention_b(DecoderBufs d, int i, int cur, const float4 *__restrict__ Wq,
+                                                     const float *__restrict__ v_w, const float *__restrict__ proj_wc) {
+  static_assert(CTX_BLOCKS == ATT_EXCHANGE_BLOCKS, "eight blocks per chunk");
+  const int b = blockIdx.x / CTX_BLOCKS;
+  const int step = d.ctl[0] + i;
+  if (step >= d.nframes[b]) return;  // (the step limits change in the prenet kernel only: all blocks of a chunk agree)
+  __shared__ __attribute__((aligned(16))) float lds[attention_lds_floats(256)];
+  AttentionLoads L;
+  attention_loads<256, false>(L, d, i, cur, b, blockIdx.x % CTX_BLOCKS, Wq, v_w, proj_wc);
+  attention_chunk<256, false>(d, i, step, b, blockIdx.x % CTX_BLOCKS, lds, L, proj_wc);
+}
+
+// D2 + D3 for batches of up to 64 chunks in ONE launch: the 256 blocks run the attention-LSTM pass and publish their
+// four hidden units of every chunk as granules (next to the B-operand copy the decoder LSTM reads after the grid
+// boundary); blocks 4 b .. 4 b + 3 then turn into the attention blocks of chunk b.  All 256 blocks must be resident
+// together (one per CU), as for the persistent engine; the same bounded spin covers a grid that is not.
+__global__ __launch_bounds__(64 * MFMA_WAVES) void k_att_lstm_attention(DecoderBufs d, int i, int cur, const float4 *__restrict__ Wm,
+                                                                        const float *__restrict__ bias, const float4 *__restrict__ Wq,
+                                                                        const float *__restrict__ v_w, const float *__restrict__ proj_wc) {
+  constexpr int NW = MFMA_WAVES, KW = ATT_COLS / NW, JJ = KW / 16;
+  static_assert(NW == 8 && attention_lds_floats(512) <= NW * 4 * 64 * 4, "the attention phase reuses the accumulator exchange area");
+  const int blk = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fg = lane >> 4;
+  const float4 *wsrc = Wm + ((size_t)(blk * NW + wave) * JJ) * 64 + lane;
+  const int step = d.ctl[0] + i;
+  const bool a = lane < d.B && step < d.nframes[min(lane, d.B - 1)];
+  const unsigned long long m = __ballot(a);
+  const int nta = m ? (63 - __clzll((long long)m)) / 16 + 1 : 0;
+  const float4 bz = *reinterpret_cast<const float4 *>(bias + (blk * 4 + fg) * 4);
+  const float4 we = make_float4(0.f, 0.f, 0.f, 0.f);
+  __shared__ __attribute__((aligned(16))) float s_acc[NW * 4 * 64 * 4];
+  __shared__ __attribute__((aligned(16))) float s_h[64 * 4];
+  // blocks 4 b .. 4 b + 3 are the attention blocks of chunk b; their loads for that phase go out as soon as the wave has
+  // issued the last load of its LSTM pass, and arrive while it waits for the other waves and the other blocks
+  const int b = blk >> 2, part = blk & 3;
+  const bool attn = b < d.B && step < d.nframes[min(b, d.B - 1)];
+  AttentionLoads L;
+  auto hook = [&]() {
+    if (attn) attention_loads<512, true>(L, d, i, cur, b, part, Wq, v_w, proj_wc);
+  };
+  switch (nta) {
+    case 1: lstm_mfma_pass<ATT_COLS, 0, 1>(d, 0, cur, step, blk, wsrc, bz, we, s_acc, s_h, m, 0, hook); break;
+    case 2: lstm_mfma_pass<ATT_COLS, 0, 2>(d, 0, cur, step, blk, wsrc, bz, we, s_acc, s_h, m, 0, hook); break;
+    case 3: lstm_mfma_pass<ATT_COLS, 0, 3>(d, 0, cur, step, blk, wsrc, bz, we, s_acc, s_h, m, 0, hook); break;
+    case 4: lstm_mfma_pass<ATT_COLS, 0, 4>(d, 0, cur, step, blk, wsrc, bz, we, s_acc, s_h, m, 0, hook); break;
+    default: return;  // (no chunk is active: nothing to attend to either)
+  }
+  if (!attn) return;
+  attention_chunk<512, true>(d, i, step, b, part, s_acc, L, proj_wc);
 }
 
 }  // namespace
@@ -1244,6 +1376,7 @@ void launch_decoder_init(const DecoderBufs &d, const int *limits_dev, hipStream_
   // must read as zero
   HIP_CHECK(hipMemsetAsync(d.pmel, 0, decoder_pmel_floats(d.B) * sizeof(float), s));
   if (d.ep_g) HIP_CHECK(hipMemsetAsync(d.ep_g, 0, sizeof(unsigned long long) * (size_t)d.B * CTX_BLOCKS * d.T, s));  // step tags restart at 1
+  if (d.hg) HIP_CHECK(hipMemsetAsync(d.hg, 0, sizeof(unsigned long long) * (size_t)d.B * ATT_RNN, s));
   hipLaunchKernelGGL(k_decoder_init, dim3(d.B), dim3(256), 0, s, d, limits_dev);
   HIP_CHECK(hipGetLastError());
 }
@@ -1263,6 +1396,7 @@ void launch_decoder_steps(const DecoderBufs &d, const DeviceWeights &w, int nste
   const std::string order = mix ? mix : "paqsd";
   const bool batched = d.B >= BATCH_MFMA_MIN && w.att_wm.p && w.dec_wm.p && d.xf;  // LSTMs as MFMA GEMMs
   const float4 *att_wm = reinterpret_cast<const float4 *>(w.att_wm.p), *dec_wm = reinterpret_cast<const float4 *>(w.dec_wm.p);
+  const bool fuse_aq = batched && d.ep_g && d.hg && d.B <= 64;
   for (int i = 0; i < nsteps; ++i) {
     const int cur = i & 1;
     for (char k : order) {
@@ -1276,13 +1410,17 @@ void launch_decoder_steps(const DecoderBufs &d, const DeviceWeights &w, int nste
                                w.proj_b.p);
           break;
         case 'a':
-          if (batched)
+          if (fuse_aq)  // attention LSTM + energies + softmax + context ('q' and 's' are then no-ops)
+            hipLaunchKernelGGL(k_att_lstm_attention, dim3(NBLK), dim3(64 * MFMA_WAVES), 0, s, d, i, cur, att_wm, w.att_b.p,
+                               reinterpret_cast<const float4 *>(w.q_w.p), w.v_w.p, w.proj_wc.p);
+          else if (batched)
             hipLaunchKernelGGL((k_lstm_mfma<ATT_COLS, 0>), dim3(NBLK, (d.B + 63) / 64), dim3(64 * MFMA_WAVES), 0, s, d, i, cur, att_wm, w.att_b.p, q4);
           else
             hipLaunchKernelGGL((k_lstm<ATT_COLS, 0>), dim3(NBLK), dim3(256), 0, s, d, i, cur, att_w, w.att_b.p, q4,
                                w.loc_conv.p, w.loc_denseT.p);
           break;
         case 'q':
+          if (fuse_aq) break;
           if (batched && d.ep_g) {  // energies + softmax + context in one launch ('s' is then a no-op)
             hipLaunchKernelGGL(k_attention_b, dim3(CTX_BLOCKS * d.B), dim3(256), 0, s, d, i, cur, reinterpret_cast<const float4 *>(w.q_w.p),
                                w.v_w.p, w.proj_wc.p);

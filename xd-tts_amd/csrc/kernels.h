@@ -49,6 +49,9 @@ struct DecoderBufs {
   // whose bounded spin ran out.
   unsigned long long *ep_g;
   int *att_err;
+  // ... and the attention LSTM in the same launch (k_att_lstm_attention, B <= 64): its output as granules [B][1024]
+  // in place of the row-major att_h; null = separate launches
+  unsigned long long *hg;
 };
 constexpr int ATT_EXCHANGE_BLOCKS = 8;  // granule rows per chunk (CTX_BLOCKS in decoder.hip)
 // [B][T][128] -> [B][32][T][4]
