@@ -143,9 +143,12 @@ xdtts_status xdtts_tacotron2_decoder_step(xdtts_tacotron2 *h, const float *memor
 
 /* Engine state of a handle: 1 = the persistent decoder / cooperative encoder is in use, 0 = the handle was
  * demoted to the launch-per-stage / single-workgroup engine after a timed-out exchange (it probes the fast
- * engine again by itself every 64 calls), -1 = not probed yet.  _reset puts a demoted handle back at once. */
+ * engine again by itself every 64 calls), -1 = not probed yet.  batched_attention (lock-step batches of 5 or more
+ * chunks): 2 = attention LSTM, energies, softmax and context in one launch whose blocks exchange tagged granules,
+ * 1 = the attention alone in one such launch (also: batches beyond 64 chunks), 0 = separate kernels (after a
+ * timed-out exchange).  Any of the three pointers may be null.  _reset puts a demoted handle back at once. */
 xdtts_status xdtts_tacotron2_engine_state(const xdtts_tacotron2 *h, int32_t *decoder_persistent,
-                                          int32_t *encoder_cooperative);
+                                          int32_t *encoder_cooperative, int32_t *batched_attention);
 xdtts_status xdtts_tacotron2_engine_reset(xdtts_tacotron2 *h);
 
 /* postnet.onnx (mod.rs:345-355): frames (F x 80) -> mel_outputs_postnet (80 x F). */

@@ -200,7 +200,7 @@ def test_engine_state_and_reset(pkg, orc, blob):
     m = pkg.Tacotron2.from_blob(blob)
     assert m.engine_state()["decoder_persistent"] == -1
     m.decoder(mem, pm, 21, pkg.default_opts(fixed_steps=6, dropout_seed=3))
-    assert m.engine_state() == {"decoder_persistent": 1, "encoder_cooperative": 1}
+    assert m.engine_state() == {"decoder_persistent": 1, "encoder_cooperative": 1, "batched_attention": 2}
     os.environ["XDTTS_PERSIST_FAULT"] = "201"
     os.environ["XDTTS_PERSIST_SPINS"] = "20000"
     try:

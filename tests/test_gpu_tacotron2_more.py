@@ -277,6 +277,65 @@ def test_batched_path_with_a_larger_window(pkg, model, orc, blob):
         assert mels[b].shape == (80, st) and rms(mels[b], ref) <= 1e-5, b
 
 
+def _batch_case(n=12):
+    ids_list = [synth_ids(18 + 5 * i, seed=500 + i) for i in range(n)]
+    steps = [5 + (3 * i) % 7 for i in range(n)]
+    return ids_list, steps
+
+
+def test_batched_attention_forms_agree(pkg, orc, blob):
+    """Lock-step batches run the attention LSTM, the energies, the softmax and the context as ONE launch whose blocks
+    exchange tagged granules (k_att_lstm_attention), as the LSTM plus a one-launch attention (k_attention_b; also what
+    batches beyond 64 chunks use), or as three kernels with grid boundaries in between.  The three forms differ only
+    in how the 32 partial energies of a time step are grouped before they are summed: each within 1e-5 of the oracle,
+    and of each other."""
+    ids_list, steps = _batch_case()
+    out = {}
+    for form in ("2", "1", "0"):
+        os.environ["XDTTS_ATT_FUSED"] = form
+        try:
+            m = pkg.Tacotron2.from_blob(blob)
+        finally:
+            del os.environ["XDTTS_ATT_FUSED"]
+        out[form] = m.infer_batch(ids_list, opts=pkg.default_opts(dropout_seed=31), fixed_steps=steps)
+        assert m.engine_state()["batched_attention"] == int(form)
+        m.close()
+    for b, (ids, st) in enumerate(zip(ids_list, steps)):
+        ref = orc.infer_chunk(blob, ids, orc.default_opts(fixed_steps=st, dropout_seed=31, item=b))
+        for form in out:
+            assert out[form][b].shape == (80, st) and rms(out[form][b], ref) <= 1e-5, (form, b)
+        assert rms(out["2"][b], out["0"][b]) <= 1e-5 and rms(out["1"][b], out["0"][b]) <= 1e-5
+
+
+@pytest.mark.parametrize("form", ["2", "1"])
+def test_lost_attention_block_falls_back(pkg, orc, blob, capfd, form):
+    """The blocks of a chunk wait for each other's partial energies inside one launch.  With one block never
+    publishing (test hook) the bounded spins run out, the error word is set, and the handle decodes the request
+    again with separate kernels: correct frames, a message on stderr, no hang; engine_reset restores the fast form."""
+    ids_list, steps = _batch_case(8)
+    os.environ["XDTTS_ATT_FUSED"] = form
+    os.environ["XDTTS_ATT_FAULT"] = "3"     # block 2 = chunk 0's third attention block in either form
+    os.environ["XDTTS_ATT_SPINS"] = "20000"
+    try:
+        m = pkg.Tacotron2.from_blob(blob)
+        mels = m.infer_batch(ids_list, opts=pkg.default_opts(dropout_seed=31), fixed_steps=steps)
+        assert "batched attention exchange timed out" in capfd.readouterr().err
+    finally:
+        del os.environ["XDTTS_ATT_FAULT"], os.environ["XDTTS_ATT_SPINS"]
+    assert m.engine_state()["batched_attention"] == 0
+    for b, (ids, st) in enumerate(zip(ids_list, steps)):
+        ref = orc.infer_chunk(blob, ids, orc.default_opts(fixed_steps=st, dropout_seed=31, item=b))
+        assert rms(mels[b], ref) <= 1e-5, b
+    try:
+        m.engine_reset()
+    finally:
+        del os.environ["XDTTS_ATT_FUSED"]
+    assert m.engine_state()["batched_attention"] == int(form)
+    again = m.infer_batch(ids_list, opts=pkg.default_opts(dropout_seed=31), fixed_steps=steps)
+    assert all(rms(a, b) <= 1e-5 for a, b in zip(again, mels))
+    m.close()
+
+
 def test_gemm_tile_shapes_give_identical_results(tmp_path):
     """k_gemm_nt picks 32x32 tiles for the single-utterance shapes and 64x64 once a grid fills the chip twice;
     both accumulate every output element's K products in ascending order, so a batch decoded with either

@@ -79,7 +79,7 @@ SYMBOLS = {
     "xdtts_tacotron2_encoder": (_I32, [_VP, _VP, _I32, _VP, _VP]),
     "xdtts_tacotron2_decoder": (_I32, [_VP, _VP, _VP, _I32, _I32, C.POINTER(InferOpts), _VP, _VP, C.POINTER(_SZ)]),
     "xdtts_tacotron2_decoder_step": (_I32, [_VP, _VP, _VP, _I32, _I32, C.POINTER(InferOpts), _U32] + [_VP] * 10),
-    "xdtts_tacotron2_engine_state": (_I32, [_VP, C.POINTER(_I32), C.POINTER(_I32)]),
+    "xdtts_tacotron2_engine_state": (_I32, [_VP, C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32)]),
     "xdtts_tacotron2_engine_reset": (_I32, [_VP]),
     "xdtts_tacotron2_postnet": (_I32, [_VP, _VP, _I32, _VP]),
     "xdtts_tacotron2_last_timings": (_I32, [_VP, C.POINTER(C.c_float * 4), C.POINTER(_I32)]),
@@ -404,9 +404,9 @@ class Tacotron2:
         return out, float(gate[0]), st
 
     def engine_state(self):
-        a, b = C.c_int32(), C.c_int32()
-        _check(lib.xdtts_tacotron2_engine_state(self._h, C.byref(a), C.byref(b)))
-        return {"decoder_persistent": a.value, "encoder_cooperative": b.value}
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        _check(lib.xdtts_tacotron2_engine_state(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"decoder_persistent": a.value, "encoder_cooperative": b.value, "batched_attention": c.value}
 
     def engine_reset(self):
         _check(lib.xdtts_tacotron2_engine_reset(self._h))

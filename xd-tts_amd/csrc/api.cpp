@@ -171,7 +171,11 @@ struct xdtts_tacotron2 {
   DevBuf<unsigned long long> att_exchange;
   // batched mode: energies, softmax and context in one launch (XDTTS_ATT_FUSED=0: the two-kernel form; also after
   // an exchange of that launch timed out)
-  int att_fused = []() { const char *e = getenv("XDTTS_ATT_FUSED"); return e ? atoi(e) : 2; }();  // 2: with the attention LSTM
+  static int att_fused_default() {
+    const char *e = getenv("XDTTS_ATT_FUSED");
+    return e ? atoi(e) : 2;
+  }
+  int att_fused = att_fused_default();  // 2: with the attention LSTM in the same launch, 1: attention alone, 0: two kernels
   int persist_state = -1;                   // -1 unknown, 0 unavailable on this device / demoted, 1 usable
   bool persist_probe_ok = false;            // the device can host the persistent grid (occupancy probe)
   bool coop_ok = true;                      // cooperative encoder BiLSTM usable (cleared after a timed-out exchange)
@@ -351,6 +355,8 @@ struct xdtts_tacotron2 {
         d.ep_g = att_exchange.p;
         d.att_err = dec_err.p;
         if (att_fused > 1 && B <= 64) d.hg = att_exchange.p + ne;  // ... and the attention LSTM in the same launch
+        if (const char *sp = getenv("XDTTS_ATT_SPINS")) d.att_spins = atoi(sp);  // test hooks for the
+        if (const char *ft = getenv("XDTTS_ATT_FAULT")) d.att_fault = atoi(ft);  // lost-block path
       }
     }
     return d;
@@ -1435,11 +1441,13 @@ xdtts_status xdtts_tacotron2_decoder_step(xdtts_tacotron2 *h, const float *memor
 
 // Which engines this handle currently uses (1 = the persistent / cooperative one, 0 = demoted to the
 // launch-per-stage / single-workgroup one after a timed-out exchange, -1 = not probed yet).
-xdtts_status xdtts_tacotron2_engine_state(const xdtts_tacotron2 *h, int32_t *decoder_persistent, int32_t *encoder_cooperative) {
+xdtts_status xdtts_tacotron2_engine_state(const xdtts_tacotron2 *h, int32_t *decoder_persistent, int32_t *encoder_cooperative,
+                                          int32_t *batched_attention) {
   return guard([&] {
     if (!h) fail(XDTTS_ERR_BAD_ARG, "null handle");
     if (decoder_persistent) *decoder_persistent = h->persist_state;
     if (encoder_cooperative) *encoder_cooperative = h->coop_ok ? 1 : 0;
+    if (batched_attention) *batched_attention = h->att_fused;
   });
 }
 
@@ -1451,6 +1459,7 @@ xdtts_status xdtts_tacotron2_engine_reset(xdtts_tacotron2 *h) {
     h->persist_state = -1;
     h->coop_ok = true;
     h->demoted_calls = 0;
+    h->att_fused = xdtts_tacotron2::att_fused_default();
   });
 }
 

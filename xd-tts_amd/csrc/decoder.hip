@@ -1064,7 +1064,8 @@ __device__ __forceinline__ void granule_store(u64 *slot, unsigned tag, float v) 
 }
 // N granules at base[idx + k * stride], polled together until every tag equals `want`; a timed-out slot reads as 0.0f
 template <int N>
-__device__ __forceinline__ void granule_gather(const u64 *base, size_t idx, size_t stride, unsigned want, float (&out)[N], int *err) {
+__device__ __forceinline__ void granule_gather(const u64 *base, size_t idx, size_t stride, unsigned want, float (&out)[N], int *err,
+                                               unsigned limit) {
   unsigned pending = (1u << N) - 1u, spins = 0;
 #pragma unroll
   for (int k = 0; k < N; ++k) out[k] = 0.f;
@@ -1080,7 +1081,7 @@ __device__ __forceinline__ void granule_gather(const u64 *base, size_t idx, size
         pending &= ~(1u << k);
       }
     if (pending) {
-      if (++spins > AB_SPIN_LIMIT || ((spins & 127u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+      if (++spins > limit || ((spins & 127u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
         atomicExch(err, 1);
         return;
       }
@@ -1151,7 +1152,7 @@ __device__ __forceinline__ void attention_chunk(const DecoderBufs &d, int i, int
   float *s_e = lds, *s_eg = s_e + T_MAX, *s_part = s_eg + NWV * T_MAX, *s_ctx = s_part + TG * COLS, *s_hv = s_ctx + COLS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int T = d.T;
-  const unsigned want = (unsigned)step + 1u;
+  const unsigned want = (unsigned)step + 1u, spin_limit = d.att_spins > 0 ? (unsigned)d.att_spins : AB_SPIN_LIMIT;
 #ifdef XDTTS_LSTM_PROBE
   unsigned long long ap[8];
   ap[0] = wall_clock64();
@@ -1176,7 +1177,7 @@ __device__ __forceinline__ void attention_chunk(const DecoderBufs &d, int i, int
   if (HG) {  // the 256 LSTM blocks of this launch each publish four units of every chunk
     constexpr int NG = ATT_RNN / NT;
     float g[NG];
-    granule_gather<NG>(d.hg, (size_t)b * ATT_RNN + tid, NT, want, g, d.att_err);
+    granule_gather<NG>(d.hg, (size_t)b * ATT_RNN + tid, NT, want, g, d.att_err, spin_limit);
 #pragma unroll
     for (int k = 0; k < NG; ++k) s_hv[tid + NT * k] = g[k];
     __syncthreads();
@@ -1217,11 +1218,11 @@ __device__ __forceinline__ void attention_chunk(const DecoderBufs &d, int i, int
     float e = 0.f;
 #pragma unroll
     for (int k = 0; k < NWV; k += 4) e += (s_eg[k * T_MAX + t] + s_eg[(k + 1) * T_MAX + t]) + (s_eg[(k + 2) * T_MAX + t] + s_eg[(k + 3) * T_MAX + t]);
-    granule_store(slots + (size_t)part * T + t, want, e);
+    if (!(d.att_fault && (int)blockIdx.x == d.att_fault - 1)) granule_store(slots + (size_t)part * T + t, want, e);
   }
   for (int t = tid; t < T; t += NT) {
     float pe[NB];
-    granule_gather<NB>(slots, t, T, want, pe, d.att_err);
+    granule_gather<NB>(slots, t, T, want, pe, d.att_err, spin_limit);
     float e = pe[0];
 #pragma unroll
     for (int k = 1; k < NB; ++k) e += pe[k];

@@ -52,6 +52,7 @@ struct DecoderBufs {
   // ... and the attention LSTM in the same launch (k_att_lstm_attention, B <= 64): its output as granules [B][1024]
   // in place of the row-major att_h; null = separate launches
   unsigned long long *hg;
+  int att_spins, att_fault;  // test hooks: poll limit (0 = default) and a block (index + 1) that never publishes its energies
 };
 constexpr int ATT_EXCHANGE_BLOCKS = 8;  // granule rows per chunk (CTX_BLOCKS in decoder.hip)
 // [B][T][128] -> [B][32][T][4]
