@@ -399,7 +399,7 @@ struct xdtts_tacotron2 {
   // when its 256-workgroup grid can be co-resident; XDTTS_DECODER=launch forces the
   // launch-per-stage path (developer comparison aid).
   bool use_persistent(const DecoderBufs &d) {
-    if (d.B > 2 * PERSIST_B_MAX || d.T > PERSIST_T_MAX) return false;  // 3..4 chunks: two launches of <= 2
+    if (d.xf || d.B > 2 * PERSIST_B_MAX || d.T > PERSIST_T_MAX) return false;  // 3..4 chunks: two launches of <= 2
     const char *e = getenv("XDTTS_DECODER");
     if (e && std::string(e) == "launch") return false;
     if (persist_state < 0) {

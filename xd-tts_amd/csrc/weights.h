@@ -40,7 +40,10 @@ struct ConvGemm {
 #define XDTTS_MFMA_WAVES 8  // (52 chunks: 46.9 us per iteration with 8, 47.2 with 16, 49.7 with 4)
 #endif
 constexpr int MFMA_WAVES = XDTTS_MFMA_WAVES;     // waves per block of the batched LSTM kernel: each takes 1/8 of K
-constexpr int BATCH_MFMA_MIN = 5;  // chunks in lock-step from which the LSTMs run as MFMA GEMMs (measured: 38 us per iteration at 5..8 chunks against 41..49 us for the GEMV kernels)
+#ifndef XDTTS_BATCH_MFMA_MIN
+#define XDTTS_BATCH_MFMA_MIN 5
+#endif
+constexpr int BATCH_MFMA_MIN = XDTTS_BATCH_MFMA_MIN;  // chunks in lock-step from which the LSTMs run as MFMA GEMMs (measured: 38 us per iteration at 5..8 chunks against 41..49 us for the GEMV kernels)
 
 struct DeviceWeights {
   DevBuf<float> emb;                         // [148][512]
