@@ -22,15 +22,15 @@ print("BASELINE configs[2]: 32 utterances -> 52 chunks in one lock-step batch (t
 print("rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes); averages per dispatch; gfx950 correction: fetch x 2 (MI355X_MICROARCH.md)")
 print("%-28s %8s %14s %14s %16s" % ("kernel", "calls", "fetch KB", "write KB", "traffic MB (corr.)"))
 tot = 0.0
-STEP = ("k_lstm_mfma", "k_softmax_ctx", "k_prenet_b", "k_qenergy")
+STEP = ("k_lstm_mfma", "k_att_lstm_attention", "k_attention_b", "k_softmax_ctx", "k_prenet_b", "k_qenergy")
 for k in sorted(f, key=lambda k: -(2 * f[k][1] + w.get(k, (0, 0.0))[1]) * f[k][0]):
     n, fe = f[k]
     wr = w.get(k, (0, 0.0))[1]
     tr = (2 * fe + wr) * 1024 / 1e6
     if k.startswith(STEP): tot += tr * n
     print("%-28s %8d %14.1f %14.1f %16.2f" % (k, n, fe, wr, tr))
-it = f.get("k_qenergy", (1, 0))[0]
-print("the five kernels of a decoder step: %.1f MB per lock-step iteration (%d iterations) against 73 MB algorithmic (71.3 MB of LSTM weights + per-chunk state)" % (tot / max(it, 1), it))
+it = f.get("k_prenet_b", (1, 0))[0] - 1  # (one more prenet launch: the flush)
+print("the kernels of a decoder step: %.1f MB per lock-step iteration (%d iterations) against 73 MB algorithmic (71.3 MB of LSTM weights + per-chunk state)" % (tot / max(it, 1), it))
 print("(FETCH_SIZE counts what leaves the L2s, Infinity-Cache hits included: the LSTM weights are re-read every step, the 0.4 - 0.65 MB activation operand once per XCD;")
 print(" the small kernels' traffic is the partial-mel rows, the encoder memory and the location / energy arrays)")
 PY
