@@ -175,6 +175,8 @@ struct xdtts_tacotron2 {
     const char *e = getenv("XDTTS_ATT_FUSED");
     return e ? atoi(e) : 2;
   }
+  bool att_demoted = false;
+  int att_demoted_calls = 0;
   int att_fused = att_fused_default();  // 2: with the attention LSTM in the same launch, 1: attention alone, 0: two kernels
   int persist_state = -1;                   // -1 unknown, 0 unavailable on this device / demoted, 1 usable
   bool persist_probe_ok = false;            // the device can host the persistent grid (occupancy probe)
@@ -349,6 +351,11 @@ struct xdtts_tacotron2 {
       pmem_t.alloc((size_t)B * T * ATT_DIM);
       launch_dimgroup_transpose(pm, pmem_t.p, B, T, stream);
       d.pmem_t = pmem_t.p;
+      // a timed-out exchange demoted the handle to separate kernels; the cause may be transient: try again after PROBE_AFTER batches
+      if (att_demoted && ++att_demoted_calls >= PROBE_AFTER) {
+        att_demoted = false;
+        att_fused = att_fused_default();
+      }
       if (att_fused > 0 && T <= T_MAX) {  // one-launch attention: partial energies cross as tagged granules
         const size_t ne = (size_t)B * ATT_EXCHANGE_BLOCKS * T;
         att_exchange.alloc(ne + (size_t)B * ATT_RNN);
@@ -568,8 +575,10 @@ struct xdtts_tacotron2 {
       if (e) {  // a block of the one-launch attention never saw its neighbours' energies: not silent, not fatal
         HIP_CHECK(hipMemsetAsync(dec_err.p, 0, sizeof(int), stream));
         att_fused = 0;
+        att_demoted = true;
+        att_demoted_calls = 0;
         std::fprintf(stderr, "libxdtts_hip: batched attention exchange timed out; this handle now uses the "
-                             "separate attention kernels\n");
+                             "separate attention kernels (probed again after %d batches)\n", PROBE_AFTER);
         DecoderBufs d2 = d;
         d2.ep_g = nullptr;
         d2.hg = nullptr;
@@ -1460,6 +1469,7 @@ xdtts_status xdtts_tacotron2_engine_reset(xdtts_tacotron2 *h) {
     h->coop_ok = true;
     h->demoted_calls = 0;
     h->att_fused = xdtts_tacotron2::att_fused_default();
+    h->att_demoted = false;
   });
 }
 
