@@ -300,7 +300,7 @@ def main():
             "ms": {"encoder": tm["encoder_ms"], "decoder_loop": tm["decoder_ms"], "postnet": tm["postnet_ms"], "wall_mel_gen": t_mel * 1e3},
             "us_per_lockstep_iteration": tm["decoder_ms"] * 1e3 / it,
             "roofline": {
-                "kernel": "the decoder iteration of the batched path (k_lstm_mfma x2 + prenet/energies/context/location kernels)",
+                "kernel": "the decoder iteration of the batched path (three launches: k_prenet_b with the location blocks, k_att_lstm_attention, k_lstm_mfma<DEC>)",
                 "bound": "mfma",
                 "achieved": c3_flops / dsec / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": c3_flops / dsec / 1e12 / MFMA_F32_PEAK_TF,
                 "hbm_achieved_GBs": c3_bytes / dsec / 1e9, "hbm_frac": c3_bytes / dsec / 1e9 / HBM_PEAK_GBS,
