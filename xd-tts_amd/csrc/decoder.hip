@@ -1,7 +1,8 @@
 // decoder.hip -- the Tacotron2 autoregressive decoder step as a chain of HIP kernels for gfx950:
 // the launch-per-stage engine.  Small lock-step batches (1-4 chunks, T <= 128) run the persistent
 // weight-stationary kernel of decoder_persistent.hip instead (api.cpp: run_decoder); this file serves
-// 5-7 chunks, the batched MFMA form for >= 8 chunks, longer encoder memories, and is the second
+// the batched MFMA form for >= 5 chunks (three launches per step: k_prenet_b, k_att_lstm_attention,
+// k_lstm_mfma<DEC>, see the comments at those kernels), longer encoder memories, and is the second
 // implementation the parity tests compare the persistent kernel with.
 //
 // Replaces the per-frame `self.decoder.run(inputs)` of the reference (src/tacotron2/mod.rs:304,
