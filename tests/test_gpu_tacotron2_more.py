@@ -223,6 +223,21 @@ def test_batch_beyond_one_mfma_pass(pkg, model, orc, blob):
         assert rms(mels[b], ref) <= 1e-5, b
 
 
+@pytest.mark.parametrize("n", [5, 64])
+def test_one_launch_attention_at_the_batch_size_limits(pkg, model, orc, blob, n):
+    """5 chunks is the smallest lock-step batch of the MFMA path (20 of the 256 blocks of k_att_lstm_attention turn
+    into attention blocks), 64 the largest that keeps the attention LSTM and the attention in one launch (all 256 do)."""
+    rng = np.random.Generator(np.random.PCG64(40 + n))
+    ids_list = [synth_ids(int(x), seed=700 + i) for i, x in enumerate(rng.integers(4, 90, size=n))]
+    steps = [int(x) for x in rng.integers(3, 10, size=n)]
+    mels = model.infer_batch(ids_list, opts=pkg.default_opts(dropout_seed=37), fixed_steps=steps)
+    assert model.engine_state()["batched_attention"] == 2
+    assert [m.shape for m in mels] == [(80, s) for s in steps]
+    for b in sorted({0, 1, n // 2, n - 2, n - 1}):
+        ref = orc.infer_chunk(blob, ids_list[b], orc.default_opts(fixed_steps=steps[b], dropout_seed=37, item=b))
+        assert rms(mels[b], ref) <= 1e-5, b
+
+
 def test_onnx_export_converts_and_loads(pkg, model, blob, tmp_path):
     """ONNX graphs (synthetic, written the way torch.onnx.export names/packs the
     parameters) -> tools/onnx_to_xdtw.py -> Tacotron2::load(dir) gives the same mel as the blob."""
