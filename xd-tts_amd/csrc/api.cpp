@@ -175,6 +175,7 @@ struct xdtts_tacotron2 {
     const char *e = getenv("XDTTS_ATT_FUSED");
     return e ? atoi(e) : 2;
   }
+  int n_cu = 0;
   bool att_demoted = false;
   int att_demoted_calls = 0;
   int att_fused = att_fused_default();  // 2: with the attention LSTM in the same launch, 1: attention alone, 0: two kernels
@@ -213,6 +214,7 @@ struct xdtts_tacotron2 {
     int cus = 0;
     HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     coop_group = cus / 8 < 1 ? 1 : cus / 8;
+    n_cu = cus;
     enc_err.alloc(1);
     HIP_CHECK(hipMemsetAsync(enc_err.p, 0, sizeof(int), stream));
     dec_err.alloc(1);
@@ -361,7 +363,8 @@ struct xdtts_tacotron2 {
         att_exchange.alloc(ne + (size_t)B * ATT_RNN);
         d.ep_g = att_exchange.p;
         d.att_err = dec_err.p;
-        if (att_fused > 1 && B <= 64) d.hg = att_exchange.p + ne;  // ... and the attention LSTM in the same launch
+        // ... and the attention LSTM in the same launch: its 256 blocks of 512 threads must be resident together, one per CU
+        if (att_fused > 1 && B <= 64 && n_cu >= ATT_RNN / 4) d.hg = att_exchange.p + ne;
         if (const char *sp = getenv("XDTTS_ATT_SPINS")) d.att_spins = atoi(sp);  // test hooks for the
         if (const char *ft = getenv("XDTTS_ATT_FAULT")) d.att_fault = atoi(ft);  // lost-block path
       }
