@@ -431,6 +431,13 @@ __global__ __launch_bounds__(PRENET_BT) void k_prenet_b(DecoderBufs d, int i, in
       location_blocks(d, i, (int)blockIdx.x - PRENET_SPLIT * d.B, loc_convT, loc_denseT);
     return;
   }
+#ifdef XDTTS_LSTM_PROBE
+  unsigned long long pp[8];
+  pp[0] = wall_clock64();
+#define PPROBE(i) pp[i] = wall_clock64()
+#else
+#define PPROBE(i) do { } while (0)
+#endif
   constexpr int HALF = PRENET / PRENET_SPLIT;          // layer-2 columns of this block
   constexpr int NPART = PRENET_BT / 32;                // 32 row groups of the partial-mel reduction
   constexpr int ROWS = (PM_ROWS + NPART - 1) / NPART;  // 9 rows per group
@@ -461,6 +468,7 @@ __global__ __launch_bounds__(PRENET_BT) void k_prenet_b(DecoderBufs d, int i, in
   const int step = d.ctl[0] + i;
   const int nf = d.nframes[b];
   const uint32_t item = d.item_base + (uint32_t)(d.item_perm ? d.item_perm[b] : b);
+  PPROBE(1);
   // ---- projection of the previous step: sum of the 264 partial rows in a fixed order ----
   {
     float4 r = rv[0];
@@ -474,6 +482,7 @@ __global__ __launch_bounds__(PRENET_BT) void k_prenet_b(DecoderBufs d, int i, in
     if (m4 < MEL_LD / 4) *reinterpret_cast<float4 *>(&s_red[part][4 * m4]) = r;
   }
   __syncthreads();
+  PPROBE(2);
   const bool have_prev = step >= 1 && step - 1 < nf;  // the chunk was active at the previous step
   if (tid < MEL_LD) {
     float v = 0.f;
@@ -495,6 +504,7 @@ __global__ __launch_bounds__(PRENET_BT) void k_prenet_b(DecoderBufs d, int i, in
     }
   }
   if (flush || fired || step >= nf) return;
+  PPROBE(3);
   // ---- prenet layer 1 (every block, all 256 outputs) ----
   {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -519,6 +529,7 @@ __global__ __launch_bounds__(PRENET_BT) void k_prenet_b(DecoderBufs d, int i, in
     s_x1[tid] = v;
   }
   __syncthreads();
+  PPROBE(4);
   // ---- prenet layer 2, this block's HALF columns ----
   {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -544,6 +555,12 @@ __global__ __launch_bounds__(PRENET_BT) void k_prenet_b(DecoderBufs d, int i, in
     d.x[b * PRENET + j] = o;
     d.xf[((size_t)(j >> 2) * d.Bpad + b) * 4 + (j & 3)] = o;
   }
+#ifdef XDTTS_LSTM_PROBE
+  PPROBE(5);
+  if (tid == 0 && (step == 100 || step == 101) && (b == 1 || b == 30) && half == 0)
+    printf("probe prenet_b chunk %d step %d: loads issued %llu  rows summed+sync %llu  mel+sync %llu  layer 1 %llu  layer 2 + store %llu (x10ns)\n", b, step,
+           pp[1] - pp[0], pp[2] - pp[1], pp[3] - pp[2], pp[4] - pp[3], pp[5] - pp[4]);
+#endif
 }
 
 // D2 / D4: LSTM cell as a weight-streaming GEMV with the cell update fused.  One wave owns one
