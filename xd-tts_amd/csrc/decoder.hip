@@ -1117,9 +1117,8 @@ struct AttentionLoads {
 };
 template <int NT, bool HG>
 __device__ __forceinline__ void attention_loads(AttentionLoads &L, const DecoderBufs &d, int i, int cur, int b, int part,
-                                                const float4 *__restrict__ Wq, const float *__restrict__ v_w,
-                                                const float *__restrict__ proj_wc) {
-  constexpr int NWV = NT / 64, NB = ATT_DIM / (4 * NWV), COLS = EMB / NB, C4 = COLS / 4, TG = NT / C4;
+                                                const float4 *__restrict__ Wq, const float *__restrict__ v_w) {
+  constexpr int NWV = NT / 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, T = d.T;
   const int gq = NWV * part + wave;  // this wave's group of four attention dims
   if (!HG) {
@@ -1142,6 +1141,12 @@ __device__ __forceinline__ void attention_loads(AttentionLoads &L, const Decoder
   L.nv = d.n_valid[b];
   L.awc_pre = tid < T ? ((i & 1) ? d.awc2 : d.awc)[b * T + tid] : 0.f;
   asm volatile("" ::: "memory");
+}
+// ... and those the stages after the softmax consume (projection rows, this block's slice of the encoder memory)
+template <int NT>
+__device__ __forceinline__ void attention_loads_late(AttentionLoads &L, const DecoderBufs &d, int b, int part, const float *__restrict__ proj_wc) {
+  constexpr int NWV = NT / 64, NB = ATT_DIM / (4 * NWV), COLS = EMB / NB, C4 = COLS / 4, TG = NT / C4;
+  const int tid = threadIdx.x, T = d.T;
   // projection rows of the 64-column block cblk: thread (m, half) of each 256-thread group holds 32 columns of row m
   const int csub = tid >> 8, pm_m = (tid & 255) >> 1, pm_half = tid & 1, cblk = (COLS / CTX_COLS) * part + csub;
 #pragma unroll
@@ -1191,6 +1196,7 @@ __device__ __forceinline__ void attention_chunk(const DecoderBufs &d, int i, int
   const int csub = tid >> 8, pm_m = (tid & 255) >> 1, pm_half = tid & 1, cblk = (COLS / CTX_COLS) * part + csub;
   const int c4 = tid % C4, tg = tid / C4;
   const float4 *mem = reinterpret_cast<const float4 *>(d.memory + (size_t)b * T * EMB) + part * C4;
+  if (HG) attention_loads_late<NT>(L, d, b, part, proj_wc);  // behind this block's own publish of h, ahead of the wait for everyone else's
   APROBE(1);
   if (HG) {  // the 256 LSTM blocks of this launch each publish four units of every chunk
     constexpr int NG = ATT_RNN / NT;
@@ -1323,7 +1329,8 @@ __global__ __launch_bounds__(256) void k_attention_b(DecoderBufs d, int i, int c
   if (step >= d.nframes[b]) return;  // (the step limits change in the prenet kernel only: all blocks of a chunk agree)
   __shared__ __attribute__((aligned(16))) float lds[attention_lds_floats(256)];
   AttentionLoads L;
-  attention_loads<256, false>(L, d, i, cur, b, blockIdx.x % CTX_BLOCKS, Wq, v_w, proj_wc);
+  attention_loads<256, false>(L, d, i, cur, b, blockIdx.x % CTX_BLOCKS, Wq, v_w);
+  attention_loads_late<256>(L, d, b, blockIdx.x % CTX_BLOCKS, proj_wc);
   attention_chunk<256, false>(d, i, step, b, blockIdx.x % CTX_BLOCKS, lds, L, proj_wc);
 }
 
@@ -1353,7 +1360,7 @@ __global__ __launch_bounds__(64 * MFMA_WAVES) void k_att_lstm_attention(DecoderB
   const bool attn = b < d.B && step < d.nframes[min(b, d.B - 1)];
   AttentionLoads L;
   auto hook = [&]() {
-    if (attn) attention_loads<512, true>(L, d, i, cur, b, part, Wq, v_w, proj_wc);
+    if (attn) attention_loads<512, true>(L, d, i, cur, b, part, Wq, v_w);  // (the late group follows the publish of h: attention_chunk)
   };
   switch (nta) {
     case 1: lstm_mfma_pass<ATT_COLS, 0, 1>(d, 0, cur, step, blk, wsrc, bz, we, s_acc, s_h, m, 0, hook); break;
