@@ -690,7 +690,7 @@ __device__ __forceinline__ void lstm_mfma_pass(const DecoderBufs &d, int n0, int
                                                unsigned long long d_probe_entry = 0, Hook after_loop = Hook()) {  // active: bit j = chunk n0 + j still runs at this step
   constexpr int NW = MFMA_WAVES, KW = NCOLS / NW, JJ = KW / 16;
   constexpr int N0 = KIND == 0 ? PRENET : ATT_RNN, N1 = EMB;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fi = lane & 15, fg = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fi = lane & 15, fg = lane >> 4;  // (wave index as a scalar: the segment choice in src() below is then scalar code, not exec-masked branches)
   const float4 *seg0 = reinterpret_cast<const float4 *>(KIND == 0 ? d.xf : d.att_hf[cur ^ 1]);
   const float4 *seg1 = reinterpret_cast<const float4 *>(d.ctxf);
   const float4 *seg2 = reinterpret_cast<const float4 *>(KIND == 0 ? d.att_hf[cur] : d.dec_hf[cur]);
@@ -833,7 +833,7 @@ __global__ __launch_bounds__(64 * MFMA_WAVES) void k_lstm_mfma(DecoderBufs d, in
   const unsigned long long t_entry = 0;
 #endif
   const int blk = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fg = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fg = lane >> 4;
   const float4 *wsrc = Wm + ((size_t)(blk * NW + wave) * JJ) * 64 + lane;
   const int n0 = 64 * blockIdx.y;  // 64 chunks (four MFMA tiles) per block row; B > 64 adds rows that stream the weights again
   const int step = d.ctl[0] + i;
@@ -1344,7 +1344,7 @@ __global__ __launch_bounds__(64 * MFMA_WAVES) void k_att_lstm_attention(DecoderB
   constexpr int NW = MFMA_WAVES, KW = ATT_COLS / NW, JJ = KW / 16;
   static_assert(NW == 8 && attention_lds_floats(512) <= NW * 4 * 64 * 4, "the attention phase reuses the accumulator exchange area");
   const int blk = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fg = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fg = lane >> 4;
   const float4 *wsrc = Wm + ((size_t)(blk * NW + wave) * JJ) * 64 + lane;
   const int step = d.ctl[0] + i;
   const bool a = lane < d.B && step < d.nframes[min(lane, d.B - 1)];
