@@ -363,7 +363,7 @@ __device__ __forceinline__ void location_chunk_mfma(const DecoderBufs &d, int i,
   constexpr int PADK = (LOC_K - 1) / 2, KC = 64;  // conv contraction: 2 x 31 taps, padded to 64
   const int T = d.T, MT = (T + 15) / 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fi = lane & 15, fg = lane >> 4;
-  __shared__ __attribute__((aligned(16))) float s_aw[2][LOC_MFMA_T + 2 * PADK + 2], s_cw[KC][LOC_F + 1], s_wd[LOC_F][ATT_DIM], s_lc[LOC_MFMA_T][LOC_F + 1];  // (+1: fragment reads walk the rows)
+  __shared__ __attribute__((aligned(16))) float s_aw[2][LOC_MFMA_T + 2 * PADK + 2], s_lc[LOC_MFMA_T][LOC_F + 1];  // (+1: fragment reads walk the rows)
   const int step = d.ctl[0] + i;
   const bool act = step < d.nframes[b];
   const float *aw = d.aw + b * T, *awc = ((i & 1) ? d.awc2 : d.awc) + b * T;  // weights of step s-1 (cumulative: ping-pong by parity)
@@ -372,8 +372,20 @@ __device__ __forceinline__ void location_chunk_mfma(const DecoderBufs &d, int i,
     const int c = k / SZ, t = k % SZ - PADK;
     s_aw[c][t + PADK] = (t >= 0 && t < T) ? (c ? awc[t] : aw[t]) : 0.f;  // zero-padded: channel 0 = previous weights, 1 = cumulative
   }
-  for (int k = tid; k < KC * LOC_F; k += PRENET_BT) s_cw[k / LOC_F][k % LOC_F] = k < 2 * LOC_K * LOC_F ? loc_convT[k] : 0.f;  // [c][k][f]; rows 62, 63 zero
-  for (int k = tid; k < LOC_F * ATT_DIM; k += PRENET_BT) s_wd[0][k] = loc_denseT[k];                             // [f][a]
+  // the weights go straight from global memory into B fragments (conv [c][k][f], rows 62 and 63 zero; dense [f][a]): one round trip,
+  // in flight together with the attention weights above, no LDS copy in between
+  float cwf[KC / 4], bw[LOC_F / 4];
+  {
+    const int nt = wave & 1;
+#pragma unroll
+    for (int ks = 0; ks < KC / 4; ++ks) {
+      const int kk = 4 * ks + fg;
+      cwf[ks] = (wave < 8 && kk < 2 * LOC_K) ? loc_convT[kk * LOC_F + 16 * nt + fi] : 0.f;
+    }
+    const int dt = wave & 7;
+#pragma unroll
+    for (int ks = 0; ks < LOC_F / 4; ++ks) bw[ks] = loc_denseT[(4 * ks + fg) * ATT_DIM + 16 * dt + fi];
+  }
   __syncthreads();
   if (!act) return;  // (block-uniform)
   // ---- conv: (time tile mt, filter tile nt) per wave ----
@@ -385,9 +397,8 @@ __device__ __forceinline__ void location_chunk_mfma(const DecoderBufs &d, int i,
     for (int ks = 0; ks < KC / 4; ++ks) {
       const int kk = 4 * ks + fg, c = kk >= LOC_K, k = kk - (c ? LOC_K : 0);  // (kk = 62, 63: c = 1, k = 31, 32 -- weight rows are zero)
       const float av = s_aw[c][16 * mt + fi + k];
-      const float bv = s_cw[kk][16 * nt + fi];
-      if (ks & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc1, 0, 0, 0);
-      else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc0, 0, 0, 0);
+      if (ks & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, cwf[ks], acc1, 0, 0, 0);
+      else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, cwf[ks], acc0, 0, 0, 0);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) s_lc[16 * mt + 4 * fg + r][16 * nt + fi] = acc0[r] + acc1[r];
@@ -396,9 +407,6 @@ __device__ __forceinline__ void location_chunk_mfma(const DecoderBufs &d, int i,
   // ---- dense: (time tile mt, dim tile nt = wave % 8) per wave; the wave's eight B fragments stay in registers ----
   {
     const int nt = wave & 7;
-    float bw[LOC_F / 4];
-#pragma unroll
-    for (int ks = 0; ks < LOC_F / 4; ++ks) bw[ks] = s_wd[4 * ks + fg][16 * nt + fi];
     // its two time tiles mt = 4 half + wave / 8 + 2 j side by side: independent accumulator chains
     constexpr int NJ = 2;
     f32x4 acc[NJ];
