@@ -694,7 +694,7 @@ struct NoHook {
 // attention-LSTM launch puts the loads of its attention phase there, behind nothing the LSTM pass still waits for
 template <int NCOLS, int KIND, int NTA, class Hook = NoHook>
 __device__ __forceinline__ void lstm_mfma_pass(const DecoderBufs &d, int n0, int cur, int step, int blk, const float4 *__restrict__ wsrc,
-                                               const float4 bz, const float4 we, float *s_acc, float *s_h, unsigned long long active,
+                                               const float4 bz, const float (&wa)[6], float *s_acc, unsigned long long active,
                                                unsigned long long d_probe_entry = 0, Hook after_loop = Hook()) {  // active: bit j = chunk n0 + j still runs at this step
   constexpr int NW = MFMA_WAVES, KW = NCOLS / NW, JJ = KW / 16;
   constexpr int N0 = KIND == 0 ? PRENET : ATT_RNN, N1 = EMB;
@@ -806,22 +806,21 @@ __device__ __forceinline__ void lstm_mfma_pass(const DecoderBufs &d, int n0, int
         hf_out[((size_t)blk * d.Bpad + n) * 4 + fg] = hn;
       }
     }
-    s_h[(16 * wave + fi) * 4 + fg] = hn;
+    if (KIND == 1) {
+      // Partial mel of this block's four hidden units, pm[m][chunk] = sum_u W_p[m][4 blk + u] h[chunk][u], on the matrix cores: the lane
+      // that has just produced h of (chunk fi, unit fg) holds exactly the B fragment of a 16x16x4 MFMA (k = unit, column = chunk); the A
+      // fragments -- W_p[16 rt + fi][4 blk + fg], six 16-row tiles -- were fetched at kernel entry.  D register r of the lane is mel row
+      // 16 rt + 4 fg + r of chunk fi: one 16-byte store.  (It was a pass of all waves over an LDS copy of h behind a barrier: ~1 us.)
+      const bool on = n < d.B && ((active >> (16 * wave + fi)) & 1ull);
+      float *prow = d.pmel + ((size_t)min(n, d.B - 1) * PM_ROWS + CTX_BLOCKS + blk) * MEL_LD + 4 * fg;
+#pragma unroll
+      for (int rt = 0; rt < 6; ++rt) {
+        const f32x4 pm = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[rt], hn, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        if (on && 16 * rt + 4 * fg < MEL_LD) *reinterpret_cast<f32x4 *>(prow + 16 * rt) = pm;
+      }
+    }
   }
   PROBE(3);
-  if (KIND == 1) {  // partial mel of this block's four hidden units, for every chunk of the active tiles
-    __syncthreads();
-    const int nb = min(16 * NTA, d.B - n0);
-    // thread -> mel row m = tid % 84 (its four weights were fetched at kernel entry), chunks tid / 84 + 12 j
-    const int m = tid % MEL_LD;
-    if (tid < MEL_LD * (64 * NW / MEL_LD))
-      for (int bl = tid / MEL_LD; bl < nb; bl += 64 * NW / MEL_LD) {
-        const float4 h4 = *reinterpret_cast<const float4 *>(s_h + 4 * bl);
-        if ((active >> bl) & 1ull)  // (no step-limit load inside this loop: it ran once per chunk pass on the kernel's tail)
-          d.pmel[((size_t)(n0 + bl) * PM_ROWS + CTX_BLOCKS + blk) * MEL_LD + m] =
-              fmaf(we.w, h4.w, fmaf(we.z, h4.z, fmaf(we.y, h4.y, we.x * h4.x)));
-      }
-  }
   __syncthreads();
   PROBE(4);
 #ifdef XDTTS_LSTM_PROBE
@@ -850,14 +849,18 @@ __global__ __launch_bounds__(64 * MFMA_WAVES) void k_lstm_mfma(DecoderBufs d, in
   const unsigned long long m = __ballot(a);
   const int nta = m ? (63 - __clzll((long long)m)) / 16 + 1 : 0;
   const float4 bz = *reinterpret_cast<const float4 *>(bias + (blk * 4 + fg) * 4);  // unit fg's i,f,g,o biases
-  const float4 we = (KIND == 1 && tid < MEL_LD * (64 * NW / MEL_LD)) ? Wepi[(size_t)blk * MEL_LD + tid % MEL_LD] : make_float4(0.f, 0.f, 0.f, 0.f);
+  float wa[6];  // KIND 1: A fragments of the partial-mel product (lstm_mfma_pass), rows past the 81 are zero
+#pragma unroll
+  for (int rt = 0; rt < 6; ++rt) {
+    const int mrow = 16 * rt + (lane & 15);
+    wa[rt] = (KIND == 1 && wave < 4 && mrow < MEL_LD) ? reinterpret_cast<const float *>(Wepi)[((size_t)blk * MEL_LD + mrow) * 4 + fg] : 0.f;
+  }
   __shared__ __attribute__((aligned(16))) float s_acc[NW * 4 * 64 * 4];  // [K-slice][tile][lane][gate]
-  __shared__ __attribute__((aligned(16))) float s_h[64 * 4];             // [chunk in super-tile][unit]
   switch (nta) {
-    case 1: lstm_mfma_pass<NCOLS, KIND, 1>(d, n0, cur, step, blk, wsrc, bz, we, s_acc, s_h, m, t_entry); break;
-    case 2: lstm_mfma_pass<NCOLS, KIND, 2>(d, n0, cur, step, blk, wsrc, bz, we, s_acc, s_h, m, t_entry); break;
-    case 3: lstm_mfma_pass<NCOLS, KIND, 3>(d, n0, cur, step, blk, wsrc, bz, we, s_acc, s_h, m, t_entry); break;
-    case 4: lstm_mfma_pass<NCOLS, KIND, 4>(d, n0, cur, step, blk, wsrc, bz, we, s_acc, s_h, m, t_entry); break;
+    case 1: lstm_mfma_pass<NCOLS, KIND, 1>(d, n0, cur, step, blk, wsrc, bz, wa, s_acc, m, t_entry); break;
+    case 2: lstm_mfma_pass<NCOLS, KIND, 2>(d, n0, cur, step, blk, wsrc, bz, wa, s_acc, m, t_entry); break;
+    case 3: lstm_mfma_pass<NCOLS, KIND, 3>(d, n0, cur, step, blk, wsrc, bz, wa, s_acc, m, t_entry); break;
+    case 4: lstm_mfma_pass<NCOLS, KIND, 4>(d, n0, cur, step, blk, wsrc, bz, wa, s_acc, m, t_entry); break;
     default: break;
   }
 }
@@ -1359,9 +1362,8 @@ __global__ __launch_bounds__(64 * MFMA_WAVES) void k_att_lstm_attention(DecoderB
   const unsigned long long m = __ballot(a);
   const int nta = m ? (63 - __clzll((long long)m)) / 16 + 1 : 0;
   const float4 bz = *reinterpret_cast<const float4 *>(bias + (blk * 4 + fg) * 4);
-  const float4 we = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float wa[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   __shared__ __attribute__((aligned(16))) float s_acc[NW * 4 * 64 * 4];
-  __shared__ __attribute__((aligned(16))) float s_h[64 * 4];
   // blocks 4 b .. 4 b + 3 are the attention blocks of chunk b; their loads for that phase go out as soon as the wave has
   // issued the last load of its LSTM pass, and arrive while it waits for the other waves and the other blocks
   const int b = blk >> 2, part = blk & 3;
@@ -1371,10 +1373,10 @@ __global__ __launch_bounds__(64 * MFMA_WAVES) void k_att_lstm_attention(DecoderB
     if (attn) attention_loads<512, true>(L, d, i, cur, b, part, Wq, v_w);  // (the late group follows the publish of h: attention_chunk)
   };
   switch (nta) {
-    case 1: lstm_mfma_pass<ATT_COLS, 0, 1>(d, 0, cur, step, blk, wsrc, bz, we, s_acc, s_h, m, 0, hook); break;
-    case 2: lstm_mfma_pass<ATT_COLS, 0, 2>(d, 0, cur, step, blk, wsrc, bz, we, s_acc, s_h, m, 0, hook); break;
-    case 3: lstm_mfma_pass<ATT_COLS, 0, 3>(d, 0, cur, step, blk, wsrc, bz, we, s_acc, s_h, m, 0, hook); break;
-    case 4: lstm_mfma_pass<ATT_COLS, 0, 4>(d, 0, cur, step, blk, wsrc, bz, we, s_acc, s_h, m, 0, hook); break;
+    case 1: lstm_mfma_pass<ATT_COLS, 0, 1>(d, 0, cur, step, blk, wsrc, bz, wa, s_acc, m, 0, hook); break;
+    case 2: lstm_mfma_pass<ATT_COLS, 0, 2>(d, 0, cur, step, blk, wsrc, bz, wa, s_acc, m, 0, hook); break;
+    case 3: lstm_mfma_pass<ATT_COLS, 0, 3>(d, 0, cur, step, blk, wsrc, bz, wa, s_acc, m, 0, hook); break;
+    case 4: lstm_mfma_pass<ATT_COLS, 0, 4>(d, 0, cur, step, blk, wsrc, bz, wa, s_acc, m, 0, hook); break;
     default: return;  // (no chunk is active: nothing to attend to either)
   }
   if (!attn) return;
