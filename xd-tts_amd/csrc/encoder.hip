@@ -12,6 +12,7 @@
 // Two granule slots per value (step parity) make overwriting impossible: a block can only write
 // step s+2 after every peer consumed its step-s value.  Every spin is bounded; a timeout raises
 // an error word that the host turns into XDTTS_ERR_HIP.
+#include "device_utils.h"
 #include "kernels.h"
 
 namespace xdtts {
@@ -21,7 +22,6 @@ namespace {
 typedef unsigned long long u64;
 typedef __attribute__((address_space(1))) u64 gu64;
 
-__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 constexpr int CO_BLOCKS = 4, CO_UNITS = ENC_H / CO_BLOCKS;  // 64 hidden units per block
 constexpr unsigned SPIN_LIMIT = 1u << 22;
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(1024) void k_bilstm_coop(const float *__restrict__ 
   float w[64];
 #pragma unroll
   for (int j = 0; j < 64; ++j) w[j] = whhT[(size_t)(64 * q + j) * (4 * ENC_H) + row];
-  __shared__ float h[ENC_H], part[4][256], gl[256];
+  __shared__ float h[ENC_H], part[4][256];
   __shared__ int dead;
   const float *xp = xproj + ((size_t)dir * Btot + b0 + b) * T * (4 * ENC_H);
   gu64 *ex = (gu64 *)(exchange + ((size_t)dir * B + b) * 2 * ENC_H);
@@ -60,15 +60,18 @@ __global__ __launch_bounds__(1024) void k_bilstm_coop(const float *__restrict__ 
       a2 = fmaf(w[j + 2], h[64 * q + j + 2], a2);
       a3 = fmaf(w[j + 3], h[64 * q + j + 3], a3);
     }
-    part[q][rl] = (a0 + a1) + (a2 + a3);
-    __syncthreads();
-    if (tid < 256) gl[tid] = ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid])) + xin;
+    part[q][rl] = ((a0 + a1) + (a2 + a3)) + xin;  // (xin: the input projection, held by the q = 0 quarter, 0 elsewhere)
     __syncthreads();
     if (tid < CO_UNITS) {
-      const float ig = sigm(gl[tid]), fg = sigm(gl[64 + tid]);
-      const float gg = tanhf(gl[128 + tid]), og = sigm(gl[192 + tid]);
+      // the four column quarters of the unit's four gate rows meet here (one barrier, no staging pass); hardware exp2 / rcp
+      // forms as in the decoder engines
+      float gs[4];
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi) gs[gi] = (part[0][64 * gi + tid] + part[1][64 * gi + tid]) + (part[2][64 * gi + tid] + part[3][64 * gi + tid]);
+      const float ig = fast_sigmoid(gs[0]), fg = fast_sigmoid(gs[1]);
+      const float gg = fast_tanh(gs[2]), og = fast_sigmoid(gs[3]);
       c = fmaf(fg, c, ig * gg);
-      const float hn = og * tanhf(c);
+      const float hn = og * fast_tanh(c);
       const int u = CO_UNITS * k + tid;
       h[u] = hn;
       memory[((size_t)(b0 + b) * T + t) * EMB + dir * ENC_H + u] = hn;
