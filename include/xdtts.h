@@ -248,6 +248,23 @@ xdtts_status xdtts_synthesize_ids(xdtts_tacotron2 *h, xdtts_griffinlim *g, const
                                   const xdtts_infer_opts *opts, float **mel, size_t *n_frames,
                                   float **audio, size_t *n_samples);
 
+/* XdTts::infer (src/lib.rs:110-159) for n_utt utterances in one call -- the "batched / parallel
+ * sentences" the author notes at src/phonemes.rs:677-680, BASELINE.json configs[3].  The chunks of
+ * all utterances are given as in xdtts_tacotron2_infer_batch (ids [B][t_stride], lens[B], optional
+ * per-chunk fixed step counts); utt_chunks[u] = number of CONSECUTIVE chunks that form utterance u
+ * (they sum to B; find_splits + the trailing split, src/tacotron2/mod.rs:399,412-414).  All chunks
+ * decode in one lock-step batch, each utterance's chunk mels are concatenated on the time axis
+ * (mod.rs:430) where the post-net writes them, and the vocoder batch reads that mel in HBM.
+ * Results equal xdtts_tacotron2_infer_batch followed by xdtts_griffinlim_infer_batch bit for bit.
+ * n_frames[u] / mels[u] (80 x n_frames[u]; mels may be NULL) and n_samples[u] / audios[u] are
+ * per utterance; buffers are released with xdtts_free. */
+xdtts_status xdtts_synthesize_batch(xdtts_tacotron2 *h, xdtts_griffinlim *g, const int64_t *ids,
+                                    const int32_t *lens, int32_t B, int32_t t_stride,
+                                    const int32_t *utt_chunks, int32_t n_utt,
+                                    const xdtts_infer_opts *opts,
+                                    const int32_t *fixed_steps_per_item, float **mels,
+                                    size_t *n_frames, float **audios, size_t *n_samples);
+
 /* ---- host-side front of Tacotron2::infer (stays on the CPU side of the FFI) ---------------- */
 /* generate_id_list -- src/tacotron2/mod.rs:90-122: 148 symbols; token text of an id. */
 int32_t xdtts_symbol_count(void);

@@ -148,3 +148,41 @@ def test_config2_full_size_audio(pkg, model, orc, orc64, blob):
     # phases to an ulp, so the two audios stay within the same noise amplification
     assert rms(audio, gpu) <= 5.0 * ef, (rms(audio, gpu), ef)
     voc.close()
+
+
+def test_synthesize_batch_equals_the_two_batch_calls(pkg, model, orc, blob):
+    """xdtts_synthesize_batch (XdTts::infer for several utterances, the mel kept in HBM) against
+    xdtts_tacotron2_infer_batch + xdtts_griffinlim_infer_batch on the same utterances: bit-identical
+    mels and audios; one utterance's mel against the per-chunk oracle."""
+    rng = np.random.default_rng(11)
+    utts = [wl.synth_ids(int(n), seed=40 + i) for i, n in enumerate((130, 45, 100, 171, 60, 12, 200))]
+    groups = [wl.chunk_utterance(pkg, u) for u in utts]
+    gsteps = [[int(np.floor(wl.FRAMES_PER_ID_BATCH * len(c) + 0.5)) for c in g] for g in groups]
+    voc = pkg.create_griffin_lim(iters=30, seed=3)
+    o = pkg.default_opts(dropout_seed=5, item_base=0)
+    mels, audios = pkg.synthesize_batch(model, voc, groups, opts=o, fixed_steps=gsteps)
+    flat = [c for g in groups for c in g]
+    fsteps = [s for g in gsteps for s in g]
+    cm = model.infer_batch(flat, opts=o, fixed_steps=fsteps)
+    k = 0
+    umels = []
+    for g in groups:
+        umels.append(np.concatenate(cm[k:k + len(g)], axis=1))
+        k += len(g)
+    ua = voc.infer_batch(umels)
+    for u in range(len(utts)):
+        assert mels[u].shape == umels[u].shape == (80, sum(gsteps[u]))
+        assert np.array_equal(mels[u], umels[u]), u
+        assert audios[u].shape == ua[u].shape == (256 * (sum(gsteps[u]) - 1),)
+        assert np.array_equal(audios[u], ua[u]), u
+    # utterance 3 (171 ids -> two chunks, batch slots 5 and 6) against the oracle, chunk by chunk
+    b0 = sum(len(g) for g in groups[:3])
+    ref = np.concatenate([orc.infer_chunk(blob, c, orc.default_opts(fixed_steps=s, dropout_seed=5, item=b0 + i)) for i, (c, s) in enumerate(zip(groups[3], gsteps[3]))], axis=1)
+    assert rms(mels[3], ref) <= 1e-4
+    # without the mels: same audio
+    m2, a2 = pkg.synthesize_batch(model, voc, groups, opts=o, fixed_steps=gsteps, want_mels=False)
+    assert m2 is None and all(np.array_equal(x, y) for x, y in zip(a2, audios))
+    # argument errors come back as status codes, not crashes
+    with pytest.raises(pkg.XdttsError):
+        pkg.synthesize_batch(model, voc, [[np.zeros(101, dtype=np.int64)]], opts=o)
+    voc.close()

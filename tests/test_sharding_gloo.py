@@ -88,6 +88,18 @@ def _share_worker(rank, world, port, out_dir):
     for u in share:  # chunks of an utterance stay in order and cover it exactly
         ok = ok and np.array_equal(np.concatenate([c for c, o in zip(chunks, owner) if o == u]), utts[u])
         ok = ok and res["audio"][u].size == 256 * (sum(s for s, o in zip(steps, owner) if o == u) - 1)
+    # the one-call form bench.py times (fused = the package's synthesize_batch): same counters from the same plan
+    def fused(model, vocoder, groups, opts=None, fixed_steps=None):
+        flat = [c for g in groups for c in g]
+        ms = model.infer_batch(flat, opts=opts, fixed_steps=[s for g in fixed_steps for s in g])
+        um, k = [], 0
+        for g in groups:
+            um.append(np.concatenate(ms[k:k + len(g)], axis=1))
+            k += len(g)
+        return um, [vocoder.infer(m) for m in um]
+    res_f = shard.run_share(_StubModel(), _StubVocoder(), share, chunks, steps, owner, None, fused=fused)
+    ok = ok and res_f["frames"] == res["frames"] and res_f["samples"] == res["samples"] and sorted(res_f["audio"]) == sorted(res["audio"])
+    ok = ok and all(res_f["audio"][u].size == res["audio"][u].size for u in share)
     totals, max_s, per_rank = shard.gather_counters(res, dist)
     np.save(os.path.join(out_dir, "s%d.npy" % rank), np.array([int(ok), len(share), len(chunks), res["frames"], res["samples"]]))
     if rank == 0:

@@ -10,7 +10,7 @@ wl = importlib.import_module("xd-tts_amd.workloads")
 m = pkg.Tacotron2.synthetic()
 steps = 200
 print("%4s %14s %16s %12s" % ("B", "us/iteration", "mel-frames/s", "engine"))
-for B in (1, 2, 3, 4, 5, 6, 7, 8, 12, 16, 17, 24, 32, 48, 52, 64, 96):
+for B in ([int(a) for a in sys.argv[1:]] or (1, 2, 3, 4, 5, 6, 7, 8, 12, 16, 17, 24, 32, 48, 52, 64, 96)):  # optional: the batch sizes as arguments
     chunks = [wl.synth_ids(60 + (7 * b) % 40, seed=10 + b) for b in range(B)]
     o = pkg.default_opts(dropout_seed=1)
     for _ in range(2):

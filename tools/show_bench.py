@@ -8,7 +8,7 @@ e = d.get("extra") or {}
 if "config3" in e:
     c = e["config3"]; print("config3: %.0f frames/s mel-gen, %.1f us/iteration, ms %s, mfma frac %.3f hbm frac %.3f" % (c["mel_frames_per_s_mel_gen"], c["us_per_lockstep_iteration"], {k: round(v, 2) for k, v in c["ms"].items()}, c["roofline"]["frac"], c["roofline"]["hbm_frac"]))
 if "config4" in e:
-    c = e["config4"]; print("config4: %.1f utt/s, %.0f frames/s, rtf %.5f, vocoder ms %.1f" % (c["utterances_per_s"], c["mel_frames_per_s"], c["rtf"], c["vocoder_ms_this_rank"]))
+    c = e["config4"]; print("config4: %.1f utt/s, %.0f frames/s, rtf %.5f, vocoder ms %.1f" % (c["utterances_per_s"], c["mel_frames_per_s"], c["rtf"], c["vocoder_ms_this_rank"]), c.get("device_ms_this_rank"), (c.get("two_call_form") or {}).get("seconds_this_rank"))
 if "config5" in e:
     print("config5:", [(x["iterations"], round(x["us_per_iteration"], 2), round(x["roofline"]["frac"], 3)) for x in e["config5"]["runs"]])
 cb = d.get("cpu_baseline")

@@ -99,6 +99,7 @@ SYMBOLS = {
     "xdtts_griffinlim_last_timings": (_I32, [_VP, C.POINTER(C.c_float * 3)]),
     "xdtts_griffinlim_free": (None, [_VP]),
     "xdtts_synthesize_ids": (_I32, [_VP, _VP, _VP, _SZ, _VP, _SZ, C.POINTER(InferOpts), C.POINTER(_PF), C.POINTER(_SZ), C.POINTER(_PF), C.POINTER(_SZ)]),
+    "xdtts_synthesize_batch": (_I32, [_VP, _VP, _VP, _VP, _I32, _I32, _VP, _I32, C.POINTER(InferOpts), _VP, _VP, _VP, _VP, _VP]),
     "xdtts_symbol_count": (_I32, []),
     "xdtts_symbol_token": (C.c_char_p, [_I32]),
     "xdtts_unit_id": (C.c_int64, [C.c_char_p, _I32]),
@@ -534,3 +535,30 @@ def synthesize(tacotron2, vocoder, ids, splits=None, opts=None):
         )
     )
     return _take(mel, N_MEL * nf.value, (N_MEL, nf.value)), _take(audio, ns.value, (ns.value,))
+
+
+def synthesize_batch(tacotron2, vocoder, utterance_chunks, opts=None, fixed_steps=None, want_mels=True):
+    """XdTts::infer (src/lib.rs:110-159) for several utterances in one call: `utterance_chunks[u]` is the
+    list of <=window-id chunks of utterance u (find_splits + the trailing split, mod.rs:399,412-414);
+    `fixed_steps`, if given, holds one frame count per chunk in the same nested shape.  All chunks decode
+    in one lock-step batch and the vocoder batch reads the concatenated mel in HBM.  Returns
+    (mels or None, audios), one entry per utterance."""
+    chunks = [c for u in utterance_chunks for c in u]
+    B, n_utt = len(chunks), len(utterance_chunks)
+    lens = np.array([len(x) for x in chunks], dtype=np.int32)
+    stride = int(lens.max()) if B else 1
+    ids = np.zeros((B, stride), dtype=np.int64)
+    for b, x in enumerate(chunks):
+        ids[b, : len(x)] = x
+    uc = np.array([len(u) for u in utterance_chunks], dtype=np.int32)
+    fs = None if fixed_steps is None else np.ascontiguousarray([s for u in fixed_steps for s in u], dtype=np.int32)
+    mels = (_PF * n_utt)() if want_mels else None
+    audios = (_PF * n_utt)()
+    nf, ns = (C.c_size_t * n_utt)(), (C.c_size_t * n_utt)()
+    _check(
+        lib.xdtts_synthesize_batch(
+            tacotron2._h, vocoder._h, _ptr(ids), _ptr(lens), B, stride, _ptr(uc), n_utt, C.byref(opts) if opts else None, None if fs is None else _ptr(fs), mels, nf, audios, ns
+        )
+    )
+    out_m = [_take(mels[u], N_MEL * nf[u], (N_MEL, nf[u])) for u in range(n_utt)] if want_mels else None
+    return out_m, [_take(audios[u], ns[u], (ns[u],)) for u in range(n_utt)]

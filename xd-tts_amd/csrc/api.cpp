@@ -1660,50 +1660,38 @@ xdtts_status xdtts_griffinlim_infer(xdtts_griffinlim *g, const float *mel, size_
   });
 }
 
-// GriffinLim::infer for several utterances at once (the vocoder half of a batch, BASELINE.json configs[3]):
-// the utterances' frames are concatenated, mel -> linear is one GEMM over all of them, and the persistent
-// kernel takes as many utterances per launch as fit one workgroup per CU (a workgroup never spans two
-// utterances and exchanges overlaps only inside its own).  Every utterance's audio is bit-identical to what
-// xdtts_griffinlim_infer returns for it alone.
-xdtts_status xdtts_griffinlim_infer_batch(xdtts_griffinlim *g, const float *const *mels, size_t n_mels, const size_t *n_frames,
-                                          int32_t n_utt, float **audios, size_t *n_samples) {
-  return guard([&] {
-    if (!g || !mels || !n_frames || !audios || !n_samples || n_utt <= 0) fail(XDTTS_ERR_BAD_ARG, "bad argument");
-    if ((int)n_mels != g->n_mels) fail(XDTTS_ERR_BAD_ARG, "mel has %zu rows, basis has %d", n_mels, g->n_mels);
-    std::vector<int> fbase(n_utt), abase(n_utt), Fu(n_utt);
+// The vocoder half of a batch from a mel that is already in HBM (on g's device): [n_mels][sum Fu], utterance u at columns
+// fbase[u] .. fbase[u] + Fu[u].  mel -> linear is one GEMM over all frames, and the persistent kernel takes as many
+// utterances per launch as fit one workgroup per CU (a workgroup never spans two utterances and exchanges overlaps only
+// inside its own).  Caller holds g->mu.  The reads of the mel are enqueued on g->stream: the caller orders them behind
+// the mel's producer (a stream sync or an event wait on g->stream).
+static void gl_batch_from_device(xdtts_griffinlim *g, const float *mel_dev_all, const std::vector<int> &Fu, float **audios,
+                                 size_t *n_samples) {
+  {
+    const int n_utt = (int)Fu.size();
+    std::vector<int> fbase(n_utt), abase(n_utt);
     size_t Ftot = 0, Ntot = 0;
     for (int u = 0; u < n_utt; ++u) {
-      audios[u] = nullptr;
-      n_samples[u] = 0;
-      if (!mels[u] || n_frames[u] < 2) fail(XDTTS_ERR_BAD_ARG, "utterance %d: need at least 2 frames", u);
       fbase[u] = (int)Ftot;
       abase[u] = (int)Ntot;
-      Fu[u] = (int)n_frames[u];
-      Ftot += n_frames[u];
-      Ntot += (size_t)g->hop * (n_frames[u] - 1);
+      Ftot += (size_t)Fu[u];
+      Ntot += (size_t)g->hop * (size_t)(Fu[u] - 1);
       if (Ftot > (1u << 24)) fail(XDTTS_ERR_BAD_ARG, "batch too large");
     }
-    std::lock_guard<std::mutex> lk(g->mu);
     HIP_CHECK(hipSetDevice(g->device));
     hipStream_t st = g->stream;
-    // mel of all utterances side by side: [n_mels][Ftot], staged in pinned memory (one fast upload)
-    PinnedGuard mel_all((size_t)n_mels * Ftot);
     std::vector<int> fl(Ftot);
-    for (int u = 0; u < n_utt; ++u) {
-      for (size_t m = 0; m < n_mels; ++m)
-        std::memcpy(mel_all.p + m * Ftot + fbase[u], mels[u] + m * n_frames[u], sizeof(float) * n_frames[u]);
+    for (int u = 0; u < n_utt; ++u)
       for (int f = 0; f < Fu[u]; ++f) fl[(size_t)fbase[u] + f] = f;
-    }
-    g->mel_in.upload(mel_all.p, (size_t)n_mels * Ftot, st);
     g->frame_local.upload(fl.data(), fl.size(), st);
     GlBufs all = g->bufs((int)Ftot);
     g->audio.alloc(std::max<size_t>(Ntot, 1));
-    HIP_CHECK(hipStreamSynchronize(st));  // the two host vectors above
+    HIP_CHECK(hipStreamSynchronize(st));  // the host vector above
     const float alpha = g->momentum / (1.0f + g->momentum);
     std::lock_guard<std::recursive_mutex> chip(chip_mutex(g->device));
     for (int attempt = 0;; ++attempt) {
       HIP_CHECK(hipEventRecord(g->ev.e[0], st));
-      g->mel_to_linear(g->mel_in.p, (int)Ftot);
+      g->mel_to_linear(mel_dev_all, (int)Ftot);
       HIP_CHECK(hipEventRecord(g->ev.e[1], st));
       launch_gl_phase_init_batch(all, g->seed, g->frame_local.p, st);
       // pack consecutive utterances into persistent launches of <= one workgroup per CU.  A workgroup owns up to
@@ -1855,6 +1843,39 @@ xdtts_status xdtts_griffinlim_infer_batch(xdtts_griffinlim *g, const float *cons
       }
       return;
     }
+  }
+}
+
+// GriffinLim::infer for several utterances at once (the vocoder half of a batch, BASELINE.json configs[3]):
+// the utterances' frames are concatenated, mel -> linear is one GEMM over all of them, and the persistent
+// kernel takes as many utterances per launch as fit one workgroup per CU.  Every utterance's audio is bit-identical to what
+// xdtts_griffinlim_infer returns for it alone.
+xdtts_status xdtts_griffinlim_infer_batch(xdtts_griffinlim *g, const float *const *mels, size_t n_mels, const size_t *n_frames,
+                                          int32_t n_utt, float **audios, size_t *n_samples) {
+  return guard([&] {
+    if (!g || !mels || !n_frames || !audios || !n_samples || n_utt <= 0) fail(XDTTS_ERR_BAD_ARG, "bad argument");
+    if ((int)n_mels != g->n_mels) fail(XDTTS_ERR_BAD_ARG, "mel has %zu rows, basis has %d", n_mels, g->n_mels);
+    std::vector<int> fbase(n_utt), Fu(n_utt);
+    size_t Ftot = 0;
+    for (int u = 0; u < n_utt; ++u) {
+      audios[u] = nullptr;
+      n_samples[u] = 0;
+      if (!mels[u] || n_frames[u] < 2) fail(XDTTS_ERR_BAD_ARG, "utterance %d: need at least 2 frames", u);
+      fbase[u] = (int)Ftot;
+      Fu[u] = (int)n_frames[u];
+      Ftot += n_frames[u];
+      if (Ftot > (1u << 24)) fail(XDTTS_ERR_BAD_ARG, "batch too large");
+    }
+    std::lock_guard<std::mutex> lk(g->mu);
+    HIP_CHECK(hipSetDevice(g->device));
+    // mel of all utterances side by side: [n_mels][Ftot], staged in pinned memory (one fast upload)
+    PinnedGuard mel_all((size_t)n_mels * Ftot);
+    for (int u = 0; u < n_utt; ++u)
+      for (size_t m = 0; m < n_mels; ++m)
+        std::memcpy(mel_all.p + m * Ftot + fbase[u], mels[u] + m * n_frames[u], sizeof(float) * n_frames[u]);
+    g->mel_in.upload(mel_all.p, (size_t)n_mels * Ftot, g->stream);
+    HIP_CHECK(hipStreamSynchronize(g->stream));  // the staging buffer goes back to the pool
+    gl_batch_from_device(g, g->mel_in.p, Fu, audios, n_samples);
   });
 }
 
@@ -1985,6 +2006,72 @@ xdtts_status xdtts_synthesize_ids(xdtts_tacotron2 *h, xdtts_griffinlim *g, const
     gl_run_from_device_mel(g, h->mel_dev.p, total, audio, n_samples);
     *mel = mel_host.release();
     *n_frames = (size_t)total;
+  });
+}
+
+// XdTts::infer for several utterances in one call (BASELINE.json configs[3]; the author's "batched / parallel
+// sentences" note, src/phonemes.rs:677-680): all chunks through one lock-step mel-gen batch (chunks are independent,
+// src/tacotron2/mod.rs:422-434), the post-net writes every utterance's chunks side by side on the time axis
+// (mod.rs:430), and the vocoder batch reads that mel where it lies in HBM -- no copy to the host and back, no
+// re-staging between the two halves.  The per-utterance mels leave for the host while the vocoder runs.
+xdtts_status xdtts_synthesize_batch(xdtts_tacotron2 *h, xdtts_griffinlim *g, const int64_t *ids, const int32_t *lens, int32_t B,
+                                    int32_t t_stride, const int32_t *utt_chunks, int32_t n_utt, const xdtts_infer_opts *opts,
+                                    const int32_t *fixed_steps_per_item, float **mels, size_t *n_frames, float **audios,
+                                    size_t *n_samples) {
+  return guard([&] {
+    if (!h || !g || !ids || !lens || !utt_chunks || !n_frames || !audios || !n_samples) fail(XDTTS_ERR_BAD_ARG, "null argument");
+    if (h->device != g->device) fail(XDTTS_ERR_BAD_ARG, "tacotron2 and griffin-lim handles live on different devices");
+    if (B <= 0 || n_utt <= 0 || t_stride <= 0) fail(XDTTS_ERR_BAD_ARG, "batch %d / utterances %d / stride %d out of range", B, n_utt, t_stride);
+    long nchunks = 0;
+    for (int u = 0; u < n_utt; ++u) {
+      if (utt_chunks[u] <= 0) fail(XDTTS_ERR_BAD_ARG, "utterance %d has no chunk", u);
+      nchunks += utt_chunks[u];
+      audios[u] = nullptr;
+      n_frames[u] = n_samples[u] = 0;
+      if (mels) mels[u] = nullptr;
+    }
+    if (nchunks != B) fail(XDTTS_ERR_BAD_ARG, "utt_chunks sum to %ld, the batch has %d chunks", nchunks, B);
+    std::lock_guard<std::mutex> lk(h->mu);
+    std::lock_guard<std::mutex> lk2(g->mu);
+    const xdtts_infer_opts o = resolve_opts(opts);
+    const int T = o.max_chunk;
+    std::vector<int64_t> padded((size_t)B * T, 0);
+    for (int b = 0; b < B; ++b) {
+      if (lens[b] > T) fail(XDTTS_ERR_TOO_LONG, "chunk %d has %d ids, window is %d", b, lens[b], T);
+      if (lens[b] > t_stride || lens[b] <= 0) fail(XDTTS_ERR_BAD_ARG, "chunk %d: bad length %d", b, lens[b]);
+      std::copy(ids + (size_t)b * t_stride, ids + (size_t)b * t_stride + lens[b], padded.begin() + (size_t)b * T);
+    }
+    int total = 0;
+    const std::vector<int> F = h->infer_batch_device(padded.data(), lens, B, T, o, fixed_steps_per_item, &total);
+    std::vector<int> Fu(n_utt, 0), col0(n_utt, 0);
+    for (int u = 0, b = 0, off = 0; u < n_utt; ++u) {
+      col0[u] = off;
+      for (int k = 0; k < utt_chunks[u]; ++k) Fu[u] += F[b++];
+      off += Fu[u];
+      if (Fu[u] < 2) fail(XDTTS_ERR_BAD_ARG, "utterance %d has %d mel frame(s); the vocoder needs at least 2", u, Fu[u]);
+    }
+    // the vocoder stream reads the mel behind the post-net (event 3 of infer_batch_device); the host copies of the
+    // mel follow on the mel-gen stream and overlap the vocoder
+    HIP_CHECK(hipStreamWaitEvent(g->stream, h->ev.e[3], 0));
+    std::vector<PinnedGuard> mel_out;
+    struct Drain {  // no mel buffer goes back to the pool while a copy into it may be in flight
+      hipStream_t s;
+      ~Drain() { (void)hipStreamSynchronize(s); }
+    } drain{h->stream};
+    if (mels) {
+      mel_out.reserve((size_t)n_utt);
+      for (int u = 0; u < n_utt; ++u) {
+        mel_out.emplace_back((size_t)N_MEL * Fu[u]);
+        HIP_CHECK(hipMemcpy2DAsync(mel_out[(size_t)u].p, sizeof(float) * (size_t)Fu[u], h->mel_dev.p + col0[u], sizeof(float) * (size_t)total,
+                                   sizeof(float) * (size_t)Fu[u], N_MEL, hipMemcpyDeviceToHost, h->stream));
+      }
+    }
+    gl_batch_from_device(g, h->mel_dev.p, Fu, audios, n_samples);
+    h->finish_timings();  // (stream sync: the mel copies have landed)
+    for (int u = 0; u < n_utt; ++u) {
+      n_frames[u] = (size_t)Fu[u];
+      if (mels) mels[u] = mel_out[(size_t)u].release();
+    }
   });
 }
 

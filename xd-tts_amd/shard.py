@@ -52,14 +52,30 @@ def plan_share(chunker, utterances, rank, world, frames_per_id):
     return share, chunks, steps, owner
 
 
-def run_share(model, vocoder, share, chunks, steps, owner, opts):
+def run_share(model, vocoder, share, chunks, steps, owner, opts, fused=None):
     """XdTts::infer (src/lib.rs:110-159) for every utterance of a rank's share: all chunks through ONE
     batched mel-gen call (chunks are independent, src/tacotron2/mod.rs:422-434), then per utterance the
-    chunk mels concatenated on the time axis (mod.rs:430) and the vocoder (lib.rs:141).  Returns the
-    counters gather_counters() takes plus the mel-gen / vocoder split."""
+    chunk mels concatenated on the time axis (mod.rs:430) and the vocoder (lib.rs:141).  `fused` is the
+    one-call form of the same (xdtts_synthesize_batch through the package's synthesize_batch: the mel
+    stays in HBM between the halves); None = the two batch entry points with the mel crossing the host.
+    Returns the counters gather_counters() takes plus the mel-gen / vocoder split."""
     import time
 
     t0 = time.perf_counter()
+    if fused is not None:
+        groups, gsteps = [], []
+        for u in share:
+            idx = [i for i in range(len(chunks)) if owner[i] == u]
+            assert idx == list(range(idx[0], idx[0] + len(idx))), "an utterance's chunks are consecutive"
+            groups.append([chunks[i] for i in idx])
+            gsteps.append([steps[i] for i in idx])
+        umels, outs = fused(model, vocoder, groups, opts=opts, fixed_steps=gsteps)
+        t2 = time.perf_counter()
+        timings = model.last_timings()
+        mel_s = min(timings.get("total_ms", 0.0) * 1e-3, t2 - t0)  # device time of the mel-gen half (HIP events)
+        audio = dict(zip(share, outs))
+        return {"frames": int(sum(m.shape[1] for m in umels)), "samples": int(sum(a.size for a in outs)), "seconds": t2 - t0,
+                "mel_gen_seconds": mel_s, "vocoder_seconds": (t2 - t0) - mel_s, "timings": timings, "mels": umels, "audio": audio}
     mels = model.infer_batch(chunks, opts=opts, fixed_steps=steps)
     timings = model.last_timings()
     t1 = time.perf_counter()
