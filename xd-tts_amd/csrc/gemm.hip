@@ -20,7 +20,6 @@
 namespace xdtts {
 
 namespace {
-
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Output tile per 256-thread block: 2 x 2 waves, each MT x NT MFMA tiles of 16x16.
@@ -34,12 +33,28 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // the slab is staged (the zero fill happens there).  Every output element accumulates its K products in
 // ascending order in both shapes, so they give identical results.
 constexpr int BK = 32, LDS_LD = 36;  // 144-byte rows: 16-B aligned float4 reads
+template <bool C, class T>
+__device__ __forceinline__ T &pick(T &a, T &b) {  // one of two named register sets, chosen at compile time
+  if constexpr (C) return a;
+  else return b;
+}
+#define P3_OR(a, b) pick<P3>(a, b)
+// Issue order of a pipelined step: one memory instruction behind each MFMA (a dependent v_mfma_f32_16x16x4_f32 issues ~44
+// cycles after its predecessor, the wave is otherwise idle in between) -- the LDS stores and the global loads first, the
+// fragment reads of the next slab last.  Post-net at F = 800: 157 -> 142 us over its five launches; with the stage / fetch
+// group fenced off ahead of the MFMAs (sched_barrier) the two phases of a wave ran back to back.
+#define GEMM_SG(m) __builtin_amdgcn_sched_group_barrier(m, 1, 0)
+#define GEMM_INTERLEAVE                                                                                                   \
+  GEMM_SG(0x008); GEMM_SG(0x200); GEMM_SG(0x008); GEMM_SG(0x200); GEMM_SG(0x008); GEMM_SG(0x020); GEMM_SG(0x008); GEMM_SG(0x020); \
+  GEMM_SG(0x008); GEMM_SG(0x100); GEMM_SG(0x008); GEMM_SG(0x100); GEMM_SG(0x008); GEMM_SG(0x100); GEMM_SG(0x008); GEMM_SG(0x100)
 
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs g) {
   constexpr int MT = BM / 32, NT = BN / 32;  // MFMA tiles per wave; also: float4 loads per thread and slab
-  __shared__ __attribute__((aligned(16))) float As[2][BM * LDS_LD];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDS_LD];
+  constexpr bool P3 = BM == 32;              // three-stage software pipeline (below) or the two-buffer form
+  constexpr int NBUF = P3 ? 3 : 2;           // LDS slabs (P3: one being read into fragments, one staged, one in between)
+  __shared__ __attribute__((aligned(16))) float As[NBUF][BM * LDS_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[NBUF][BN * LDS_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN, z = blockIdx.z;
@@ -73,66 +88,146 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs g) {
   struct Slab {
     float4 a[MT], b[NT];
   };
+  struct Frag {  // a slab's MFMA operands of this lane: [16-column group][tile]
+    float4 a[BK / 16][MT], b[BK / 16][NT];
+  };
 
+  // Software pipeline over the K-slabs, three stages deep (a wave has the CU's matrix pipe to itself at the
+  // single-utterance sizes -- 1-2 blocks per CU --, so whatever it waits for is idle MFMA time: with the fragments read
+  // from LDS right before their MFMAs and the next slab staged after them, a slab took 0.48 us for 0.11 us of MFMA):
+  //   step s:  slab s + 2 goes from its prefetch registers into LDS buffer (s + 2) % 3 and that register slot is refilled
+  //            from global memory (slab s + 6: four slabs ahead of the staging point);
+  //            the fragments of slab s + 1 are read from buffer (s + 1) % 3 into the second fragment set;
+  //            the MFMAs of slab s run on the set read during step s - 1;  one barrier.
+  // Buffer (s + 2) % 3 held slab s - 1, whose fragments every wave read before the barrier that ended step s - 2.
 #define GEMM_FETCH(SLAB, Q)                                                                 \
   do {                                                                                      \
     const int k0_ = ((SLAB) < nslab && (SLAB) * BK + lc < g.K) ? (SLAB) * BK : 0;           \
     _Pragma("unroll") for (int r_ = 0; r_ < MT; ++r_) Q.a[r_] = *reinterpret_cast<const float4 *>(a_src[r_] + k0_); \
     _Pragma("unroll") for (int r_ = 0; r_ < NT; ++r_) Q.b[r_] = *reinterpret_cast<const float4 *>(b_src[r_] + k0_); \
   } while (0)
-#define GEMM_STAGE(SLAB, Q)                                                                 \
+#define GEMM_STAGE(SLAB, BUF, Q)                                                            \
   do {                                                                                      \
     const bool kok_ = (SLAB) * BK + lc < g.K; /* K is a multiple of 16, not always of 32 */ \
     /* no `cond ? Q : zero4` on the vector class: it selects between ADDRESSES and sends the  \
        prefetch registers to scratch */                                                      \
     _Pragma("unroll") for (int r_ = 0; r_ < MT; ++r_) {                                     \
       const float ma_ = (kok_ && a_ok[r_]) ? 1.f : 0.f;                                     \
-      *reinterpret_cast<float4 *>(&As[(SLAB) & 1][(lr + 32 * r_) * LDS_LD + lc]) =         \
+      *reinterpret_cast<float4 *>(&As[BUF][(lr + 32 * r_) * LDS_LD + lc]) =                 \
           make_float4(ma_ != 0.f ? Q.a[r_].x : 0.f, ma_ != 0.f ? Q.a[r_].y : 0.f, ma_ != 0.f ? Q.a[r_].z : 0.f, ma_ != 0.f ? Q.a[r_].w : 0.f); \
     }                                                                                       \
     _Pragma("unroll") for (int r_ = 0; r_ < NT; ++r_) {                                     \
       const float mb_ = (kok_ && b_ok[r_]) ? 1.f : 0.f;                                     \
-      *reinterpret_cast<float4 *>(&Bs[(SLAB) & 1][(lr + 32 * r_) * LDS_LD + lc]) =         \
+      *reinterpret_cast<float4 *>(&Bs[BUF][(lr + 32 * r_) * LDS_LD + lc]) =                 \
           make_float4(mb_ != 0.f ? Q.b[r_].x : 0.f, mb_ != 0.f ? Q.b[r_].y : 0.f, mb_ != 0.f ? Q.b[r_].z : 0.f, mb_ != 0.f ? Q.b[r_].w : 0.f); \
     }                                                                                       \
   } while (0)
-#define GEMM_STEP(J, Q, NQ)                                                                 \
-  if (s0 + (J) < nslab) {                                                                   \
-    GEMM_FETCH(s0 + (J) + 4, Q); /* slot J was staged for this slab already: refill */      \
-    __builtin_amdgcn_sched_barrier(0); /* or the scheduler sinks the loads to their use */  \
+#define GEMM_READ(BUF, F)                                                                   \
+  do {                                                                                      \
     _Pragma("unroll") for (int kg = 0; kg < BK / 16; ++kg) {                                \
-      float4 af[MT], bf[NT];                                                                \
       _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_)                                     \
-        af[i_] = *reinterpret_cast<const float4 *>(&As[(J) & 1][(wm * 16 * MT + 16 * i_ + fi) * LDS_LD + kg * 16 + fg * 4]); \
+        F.a[kg][i_] = *reinterpret_cast<const float4 *>(&As[BUF][(wm * 16 * MT + 16 * i_ + fi) * LDS_LD + kg * 16 + fg * 4]); \
       _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_)                                     \
-        bf[j_] = *reinterpret_cast<const float4 *>(&Bs[(J) & 1][(wn * 16 * NT + 16 * j_ + fi) * LDS_LD + kg * 16 + fg * 4]); \
-      _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_)                                     \
-        _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i_].x, bf[j_].x, acc[i_][j_], 0, 0, 0); \
-      _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_)                                     \
-        _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i_].y, bf[j_].y, acc[i_][j_], 0, 0, 0); \
-      _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_)                                     \
-        _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i_].z, bf[j_].z, acc[i_][j_], 0, 0, 0); \
-      _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_)                                     \
-        _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i_].w, bf[j_].w, acc[i_][j_], 0, 0, 0); \
+        F.b[kg][j_] = *reinterpret_cast<const float4 *>(&Bs[BUF][(wn * 16 * NT + 16 * j_ + fi) * LDS_LD + kg * 16 + fg * 4]); \
     }                                                                                       \
-    if (s0 + (J) + 1 < nslab) GEMM_STAGE(s0 + (J) + 1, NQ); /* buffer last read before the previous barrier */ \
+  } while (0)
+#define GEMM_MMA(F)                                                                         \
+  do {                                                                                      \
+    _Pragma("unroll") for (int kg = 0; kg < BK / 16; ++kg) {                                \
+      _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_)                                     \
+        _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x4f32(F.a[kg][i_].x, F.b[kg][j_].x, acc[i_][j_], 0, 0, 0); \
+      _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_)                                     \
+        _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x4f32(F.a[kg][i_].y, F.b[kg][j_].y, acc[i_][j_], 0, 0, 0); \
+      _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_)                                     \
+        _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x4f32(F.a[kg][i_].z, F.b[kg][j_].z, acc[i_][j_], 0, 0, 0); \
+      _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_)                                     \
+        _Pragma("unroll") for (int j_ = 0; j_ < NT; ++j_) acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x4f32(F.a[kg][i_].w, F.b[kg][j_].w, acc[i_][j_], 0, 0, 0); \
+    }                                                                                       \
+  } while (0)
+  // step J of a round of 12 (register slots, LDS buffers and fragment sets are all literals then).
+  // Full rounds run WITHOUT the per-step bounds checks: a conditional step is a control-flow join, and at a join the
+  // compiler's waitcnt pass no longer knows how many younger loads are in flight -- it then waits for vmcnt(1)/(0)
+  // before staging, i.e. for the loads it has just issued (seen in the ISA of the round-1 kernel: the four-slab
+  // prefetch was lost in most steps and a slab cost an L2 round trip).  Straight-line rounds get vmcnt(6..9).
+  //   P3 (32x32 tile): the three-stage form above -- slot (J + 2) % 4, buffers (J + 1) % 3 / (J + 2) % 3, fragment sets by parity;
+  //   else (64x64 tile, four independent MFMA chains per wave, 2-4 blocks per CU): two LDS buffers, the fragments read right
+  //   before their MFMAs -- slot (J + 1) % 4, buffers J % 2 / (J + 1) % 2 -- which keeps 37 KB of LDS per block.
+#define GEMM_STEP_U(J, QA, QB, FC, FN)                                                      \
+  if constexpr (P3) {                                                                       \
+    GEMM_STAGE(s0 + (J) + 2, ((J) + 2) % NBUF, QA);                                         \
+    GEMM_FETCH(s0 + (J) + 6, QA); /* the slot just staged: refill */                        \
+    GEMM_READ(((J) + 1) % NBUF, FN);                                                        \
+    GEMM_MMA(FC);                                                                           \
+    GEMM_INTERLEAVE;                                                                        \
+    __syncthreads();                                                                        \
+  } else {                                                                                  \
+    GEMM_FETCH(s0 + (J) + 4, QB); /* slot J % 4 was staged for this slab already: refill */ \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    GEMM_READ((J) % NBUF, f0);                                                              \
+    GEMM_MMA(f0);                                                                           \
+    GEMM_STAGE(s0 + (J) + 1, ((J) + 1) % NBUF, QA); /* buffer last read before the previous barrier */ \
     __syncthreads();                                                                        \
   }
+#define GEMM_STEP(J, QA, QB, FC, FN)                                                        \
+  if (s0 + (J) < nslab) {                                                                   \
+    if constexpr (P3) {                                                                     \
+      if (s0 + (J) + 2 < nslab) GEMM_STAGE(s0 + (J) + 2, ((J) + 2) % NBUF, QA);             \
+      GEMM_FETCH(s0 + (J) + 6, QA);                                                         \
+      __builtin_amdgcn_sched_barrier(0);                                                    \
+      if (s0 + (J) + 1 < nslab) GEMM_READ(((J) + 1) % NBUF, FN);                            \
+      GEMM_MMA(FC);                                                                         \
+    } else {                                                                                \
+      GEMM_FETCH(s0 + (J) + 4, QB);                                                         \
+      __builtin_amdgcn_sched_barrier(0);                                                    \
+      GEMM_READ((J) % NBUF, f0);                                                            \
+      GEMM_MMA(f0);                                                                         \
+      if (s0 + (J) + 1 < nslab) GEMM_STAGE(s0 + (J) + 1, ((J) + 1) % NBUF, QA);             \
+    }                                                                                       \
+    __syncthreads();                                                                        \
+  }
+  // (QA, QB) of step J: P3 stages slot (J + 2) % 4; the two-buffer form refills slot J % 4 = QB and stages slot (J + 1) % 4 = QA
+#define GEMM_ROUND(STEP)                                                                    \
+  STEP(0, P3_OR(q2, q1), q0, f0, f1)                                                        \
+  STEP(1, P3_OR(q3, q2), q1, f1, f0)                                                        \
+  STEP(2, P3_OR(q0, q3), q2, f0, f1)                                                        \
+  STEP(3, P3_OR(q1, q0), q3, f1, f0)                                                        \
+  STEP(4, P3_OR(q2, q1), q0, f0, f1)                                                        \
+  STEP(5, P3_OR(q3, q2), q1, f1, f0)                                                        \
+  STEP(6, P3_OR(q0, q3), q2, f0, f1)                                                        \
+  STEP(7, P3_OR(q1, q0), q3, f1, f0)                                                        \
+  STEP(8, P3_OR(q2, q1), q0, f0, f1)                                                        \
+  STEP(9, P3_OR(q3, q2), q1, f1, f0)                                                        \
+  STEP(10, P3_OR(q0, q3), q2, f0, f1)                                                       \
+  STEP(11, P3_OR(q1, q0), q3, f1, f0)
 
   Slab q0, q1, q2, q3;
+  Frag f0, f1;
   GEMM_FETCH(0, q0);
   GEMM_FETCH(1, q1);
   GEMM_FETCH(2, q2);
   GEMM_FETCH(3, q3);
-  GEMM_STAGE(0, q0);
-  __syncthreads();
-  for (int s0 = 0; s0 < nslab; s0 += 4) {  // slab parity == J parity
-    GEMM_STEP(0, q0, q1)
-    GEMM_STEP(1, q1, q2)
-    GEMM_STEP(2, q2, q3)
-    GEMM_STEP(3, q3, q0)
+  GEMM_STAGE(0, 0, q0);
+  if constexpr (P3) {
+    if (1 < nslab) GEMM_STAGE(1, 1, q1);
+    GEMM_FETCH(4, q0);
+    GEMM_FETCH(5, q1);
+    __syncthreads();
+    GEMM_READ(0, f0);
+  } else {
+    __syncthreads();
   }
+  int s0 = 0;
+  for (; s0 + 14 <= nslab; s0 += 12) {  // every slab this round stages (up to s0 + 13) exists
+    GEMM_ROUND(GEMM_STEP_U)
+  }
+  for (; s0 < nslab; s0 += 12) {  // the last 2..13 slabs
+    GEMM_ROUND(GEMM_STEP)
+  }
+#undef GEMM_ROUND
+#undef GEMM_STEP_U
 #undef GEMM_STEP
+#undef GEMM_MMA
+#undef GEMM_READ
 #undef GEMM_STAGE
 #undef GEMM_FETCH
   // epilogue: D register r of lane l holds row (l>>4)*4 + r, column l&15 of its 16x16 tile
