@@ -143,6 +143,59 @@ inline GriffinLim create_griffin_lim(int device_id = 0) {
   return GriffinLim(mel_basis, 1024 - 256, 1.7f, 30, 0.99f, device_id);
 }
 
+// XdTts::infer (src/lib.rs:110-159) for several utterances in one call (xdtts_synthesize_batch): units -> ids
+// (units with no id are dropped, mod.rs:403-406), find_splits per utterance (mod.rs:399,412-414), all chunks in one
+// lock-step batch, the mel kept in HBM between mel-gen and vocoder.  Returns (mel, audio) per utterance.
+inline std::vector<std::pair<Array2, std::vector<float>>> infer_many(const Tacotron2 &model, const GriffinLim &vocoder,
+                                                                       const std::vector<std::vector<Unit>> &texts,
+                                                                       const xdtts_infer_opts *opts = nullptr) {
+  xdtts_infer_opts o;
+  xdtts_infer_opts_default(&o);
+  if (opts) o = *opts;
+  const size_t T = (size_t)o.max_chunk;
+  std::vector<int64_t> ids;      // [B][T], zero-padded
+  std::vector<int32_t> lens, utt_chunks;
+  for (const std::vector<Unit> &units : texts) {
+    std::vector<int64_t> u;
+    for (const Unit &x : units) {
+      const int64_t id = xdtts_unit_id(x.token.c_str(), x.is_character ? 1 : 0);
+      if (id >= 0) u.push_back(id);
+    }
+    std::vector<size_t> splits(u.size() + 2);
+    size_t n_splits = 0;
+    check(xdtts_find_splits(u.data(), u.size(), T, splits.data(), splits.size(), &n_splits));
+    splits.resize(n_splits);
+    if (splits.empty() || splits.back() != u.size()) splits.push_back(u.size());  // the trailing split (mod.rs:412-414)
+    int32_t n = 0;
+    size_t a = 0;
+    for (size_t e : splits) {
+      if (e <= a) continue;
+      if (e - a > T) throw std::runtime_error("xdtts: a chunk exceeds the encoder window");
+      ids.resize(ids.size() + T, 0);
+      std::copy(u.begin() + (long)a, u.begin() + (long)e, ids.end() - (long)T);
+      lens.push_back((int32_t)(e - a));
+      a = e;
+      ++n;
+    }
+    utt_chunks.push_back(n);
+  }
+  const size_t n_utt = texts.size();
+  std::vector<float *> mels(n_utt, nullptr), audios(n_utt, nullptr);
+  std::vector<size_t> nf(n_utt, 0), ns(n_utt, 0);
+  check(xdtts_synthesize_batch(model.raw(), vocoder.raw(), ids.data(), lens.data(), (int32_t)lens.size(), (int32_t)T, utt_chunks.data(),
+                               (int32_t)n_utt, &o, nullptr, mels.data(), nf.data(), audios.data(), ns.data()));
+  std::vector<std::pair<Array2, std::vector<float>>> out(n_utt);
+  for (size_t i = 0; i < n_utt; ++i) {
+    out[i].first.rows = 80;
+    out[i].first.cols = nf[i];
+    out[i].first.data.assign(mels[i], mels[i] + 80 * nf[i]);
+    out[i].second.assign(audios[i], audios[i] + ns[i]);
+    xdtts_free(mels[i]);
+    xdtts_free(audios[i]);
+  }
+  return out;
+}
+
 // XdTts::infer's output stage (src/lib.rs:145-157): RTF, `(sample * i16::MAX as f32) as i16`,
 // mono 22050 Hz 16-bit WAV (WAV_SPEC, src/lib.rs:25-30).
 inline std::vector<int16_t> to_i16(const std::vector<float> &audio) {

@@ -22,6 +22,12 @@ int main() {
     std::printf("spec %zu x %zu\n", spec.rows, spec.cols);
     xdtts::GriffinLim voc = xdtts::create_griffin_lim();
     std::printf("audio %zu\n", voc.infer(spec).size());
+    // XdTts::infer for two texts in one call (xdtts_synthesize_batch)
+    const std::vector<std::vector<xdtts::Unit>> texts = {{{"a", true}, {"b", true}}, {{"HH", false}, {"AH0", false}, {" ", false}, {"L", false}}};
+    const auto many = xdtts::infer_many(model, voc, texts, &o);
+    std::printf("many %zu:", many.size());
+    for (const auto &m : many) std::printf(" %zu/%zu", m.first.cols, m.second.size());
+    std::printf("\n");
   } else {
     try {
       xdtts::Tacotron2::synthetic();

@@ -189,6 +189,11 @@ def test_cpp_host_mirror_sanity_on_gpu(pkg, tmp_path):
     rows, _x, cols = lines[1].split()[1:]
     assert int(rows) == 80 and int(cols) > 0
     assert int(lines[2].split()[1]) == 256 * (int(cols) - 1)
+    many = lines[3].split()
+    assert many[:2] == ["many", "2:"] and len(many) == 4
+    for pair in many[2:]:   # (frames, samples) per utterance: max_steps = 5 frames -> 256 * 4 samples
+        f, n = (int(x) for x in pair.split("/"))
+        assert f > 0 and n == 256 * (f - 1)
 
 
 # ---- output stage (src/lib.rs:25-30,125-176): host-side, runs without a GPU ------------------------
