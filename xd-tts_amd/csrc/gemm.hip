@@ -57,7 +57,26 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) float Bs[NBUF][BN * LDS_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN, z = blockIdx.z;
+  // Workgroups go to the 8 XCDs round-robin in dispatch order (x fastest), so with a grid whose x extent is a multiple of 8 an
+  // XCD sees a fixed set of column tiles and EVERY row tile: A crosses into all eight L2s.  That is the cheap way round for the
+  // single-utterance shapes (A 1.6 MB, W 5.2 MB), and the expensive one for a batch (52-chunk post-net: A 51 MB, W 5.2 MB --
+  // the counters showed 412 MB fetched per launch).  g.xcd_rows turns the mapping round: of 8 consecutive dispatch slots each
+  // takes another row tile and keeps it for gridDim.x consecutive visits, i.e. the column tiles of one row tile share an XCD
+  // (the row tiles of all items of a batch are numbered through, so the XCDs get equal shares whatever the items' lengths).
+  int bx = blockIdx.x, by = blockIdx.y, z = blockIdx.z;
+  if (g.xcd_rows) {  // grid (column tiles, row tiles of ALL items rounded up to 8, 1): row tile G of the batch -> XCD G % 8
+    const int nx = gridDim.x, L = bx + nx * by, j = L % (8 * nx);
+    int G = (L / (8 * nx)) * 8 + (j & 7);
+    bx = j >> 3;
+    for (z = 0; z < g.batch; ++z) {  // (scalar: at most 64 items)
+      const int t = ((g.ragged ? g.Mz[z] : g.M) + BM - 1) / BM;
+      if (G < t) break;
+      G -= t;
+    }
+    if (z == g.batch) return;  // padding of the last group of 8
+    by = G;
+  }
+  const int m0 = by * BM, n0 = bx * BN;
   const int M = g.ragged ? g.Mz[z] : g.M;
   if (m0 >= M) return;  // ragged batch: this item has fewer rows than the longest
   const float *A = g.A + (size_t)z * g.strideA;
@@ -397,10 +416,25 @@ void launch_gemm_nt(const GemmArgs &g, hipStream_t s) {
   static const int forced = getenv("XDTTS_GEMM_TILE") ? atoi(getenv("XDTTS_GEMM_TILE")) : 0;
   const long tiles64 = (long)((g.N + 63) / 64) * ((g.M + 63) / 64) * g.batch;
   const bool big = forced ? forced == 64 : (g.N >= 64 && tiles64 >= 512);
+  // row tiles per XCD when A (unique bytes: rows x lda) outweighs W -- the batches; XDTTS_GEMM_XCD=0|1 forces it (comparison aid)
+  static const int forced_x = getenv("XDTTS_GEMM_XCD") ? atoi(getenv("XDTTS_GEMM_XCD")) : -1;
+  long rows = 0;
+  for (int z = 0; z < g.batch; ++z) rows += g.ragged ? g.Mz[z] : g.M;
+  GemmArgs a = g;
+  a.xcd_rows = forced_x >= 0 ? forced_x : (rows * g.lda > (long)g.N * g.K ? 1 : 0);
+  const int tb = big ? 64 : 32;
+  const int nx = (g.N + tb - 1) / tb;
+  int ny = (g.M + tb - 1) / tb, nz = g.batch;
+  if (a.xcd_rows) {
+    long tiles = 0;
+    for (int z = 0; z < g.batch; ++z) tiles += ((g.ragged ? g.Mz[z] : g.M) + tb - 1) / tb;
+    ny = (int)((tiles + 7) / 8 * 8);
+    nz = 1;
+  }
   if (big)
-    hipLaunchKernelGGL((k_gemm_nt<64, 64>), dim3((g.N + 63) / 64, (g.M + 63) / 64, g.batch), dim3(256), 0, s, g);
+    hipLaunchKernelGGL((k_gemm_nt<64, 64>), dim3(nx, ny, nz), dim3(256), 0, s, a);
   else
-    hipLaunchKernelGGL((k_gemm_nt<32, 32>), dim3((g.N + 31) / 32, (g.M + 31) / 32, g.batch), dim3(256), 0, s, g);
+    hipLaunchKernelGGL((k_gemm_nt<32, 32>), dim3(nx, ny, nz), dim3(256), 0, s, a);
   HIP_CHECK(hipGetLastError());
 }
 

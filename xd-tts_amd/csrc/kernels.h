@@ -118,6 +118,7 @@ struct GemmArgs {
   // (0 in alpha / beta means 1: zero-initialised args keep the plain form)
   float alpha, beta;
   int r_before_act;
+  int xcd_rows;       // set by launch_gemm_nt: block -> tile mapping that keeps a row tile's column tiles on one XCD (gemm.hip)
 };
 constexpr int GEMM_RAGGED_MAX = 64;  // (the argument block stays under 1 KB)
 void launch_gemm_nt(const GemmArgs &g, hipStream_t s);
