@@ -192,7 +192,8 @@ struct xdtts_tacotron2 {
   int demoted_calls = 0;    // decoder calls since a demotion (the fast engines are probed again after PROBE_AFTER)
   static constexpr int PROBE_AFTER = 64;
   DevBuf<float> ppA, ppB, mel_dev;
-  int *host_ctl = nullptr;  // pinned: [0..1] ctl, [2..] nframes
+  int *host_ctl = nullptr;  // pinned: [0..1] ctl, [2..] nframes, [HOST_ENC_ERR] the encoder's error word
+  static constexpr int HOST_ENC_ERR = 2 + 4096;
 
   // cached hipGraph of GRAPH_STEPS decoder steps for the current (B, T, buffers)
   static constexpr int GRAPH_STEPS = 20;
@@ -210,7 +211,7 @@ struct xdtts_tacotron2 {
     select_device(dev);
     HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     ev.create();
-    HIP_CHECK(hipHostMalloc((void **)&host_ctl, sizeof(int) * (2 + 4096), hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc((void **)&host_ctl, sizeof(int) * (2 + 4096 + 1), hipHostMallocDefault));
     int cus = 0;
     HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     coop_group = cus / 8 < 1 ? 1 : cus / 8;
@@ -697,16 +698,20 @@ struct xdtts_tacotron2 {
     ids.upload(ids_host, (size_t)B * T, stream);
     n_valid.upload(lens, B, stream);
     if (B >= BATCH_MFMA_MIN) item_perm.upload(order.data(), B, stream);
-    HIP_CHECK(hipStreamSynchronize(stream));  // ids_host may be a caller temporary
+    // (no sync here: the three sources are locals of this function -- the sorted copies -- and outlive the stream work,
+    // which run_decoder drains before it returns; a pageable source is staged before hipMemcpyAsync returns anyway)
     std::lock_guard<std::recursive_mutex> chip(chip_mutex(device));  // released after run_decoder's final sync
     run_encoder(B, T);
     HIP_CHECK(hipEventRecord(ev.e[1], stream));
+    // the cooperative BiLSTM's error word comes back with the decoder's own final fetch (one stream sync less per call)
+    HIP_CHECK(hipMemcpyAsync(host_ctl + HOST_ENC_ERR, enc_err.p, sizeof(int), hipMemcpyDeviceToHost, stream));
     if (B >= BATCH_MFMA_MIN) w.ensure_batched_layout(blob, stream);
     DecoderBufs d = decoder_bufs(B, T, memory.p, pmem.p, o);
     if (B >= BATCH_MFMA_MIN) d.item_perm = item_perm.p;
     if (fixed_per_item || o.fixed_frames_per_id > 0.f) d.use_gate = 0;
-    last_steps = run_decoder(d, lim);
-    if (encoder_exchange_failed()) {
+    last_steps = run_decoder(d, lim);  // (ends with a stream sync)
+    if (host_ctl[HOST_ENC_ERR] != 0) {
+      HIP_CHECK(hipMemsetAsync(enc_err.p, 0, sizeof(int), stream));
       // the 4-CU cooperative BiLSTM needs its workgroups co-resident too: same policy as the decoder --
       // say so, use the single-workgroup recurrence from now on, and run the request again
       coop_ok = false;
@@ -2001,9 +2006,16 @@ xdtts_status xdtts_synthesize_ids(xdtts_tacotron2 *h, xdtts_griffinlim *g, const
     h->infer_batch_device(padded.data(), lens.data(), (int)lens.size(), o.max_chunk, o, nullptr, &total);
     if (total < 2) fail(XDTTS_ERR_BAD_ARG, "mel has %d frame(s); the vocoder needs at least 2", total);
     PinnedGuard mel_host((size_t)N_MEL * total);
+    // the vocoder stream reads the mel behind the post-net (event 3 of infer_batch_device); the mel's copy to the host
+    // follows on the mel-gen stream and overlaps the vocoder
+    HIP_CHECK(hipStreamWaitEvent(g->stream, h->ev.e[3], 0));
     HIP_CHECK(hipMemcpyAsync(mel_host.p, h->mel_dev.p, (size_t)N_MEL * total * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-    h->finish_timings();  // stream sync: the mel is complete in HBM before the vocoder stream reads it
+    struct Drain {  // the pinned buffer does not go back to the pool with the copy in flight
+      hipStream_t s;
+      ~Drain() { (void)hipStreamSynchronize(s); }
+    } drain{h->stream};
     gl_run_from_device_mel(g, h->mel_dev.p, total, audio, n_samples);
+    h->finish_timings();  // (stream sync: the mel has landed)
     *mel = mel_host.release();
     *n_frames = (size_t)total;
   });
