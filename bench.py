@@ -38,6 +38,7 @@ SAMPLE_RATE = 22050.0
 GL_ITERS = 60                 # BASELINE.json configs[1]
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak
+POSTNET_FLOP_PER_FRAME = 8683520.0  # 5 x conv1d k5 (80->512->512->512->512->80), 2 flops per MAC
 
 # Algorithmic work of one decoder step: the fp32 decoder_iter parameters are
 # streamed once per lock-step iteration, plus per ACTIVE chunk the encoder memory + processed memory
@@ -236,6 +237,9 @@ def main():
             "mel_to_linear": m2l_ms / K,
             "griffinlim_iterations": gl_ms / K,
         },
+        "postnet_roofline": {"kernel": "k_gemm_nt<32,32> x 5 (implicit-GEMM conv1d k5 over the utterance's %d frames)" % frames, "bound": "mfma",
+                             "achieved": POSTNET_FLOP_PER_FRAME * frames / (post_ms / K * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                             "frac": POSTNET_FLOP_PER_FRAME * frames / (post_ms / K * 1e-3) / 1e12 / MFMA_F32_PEAK_TF},
         "roofline": {
             "kernel": "k_decoder_persistent (<2> for the %d steps both chunks run, then <1>: %d lock-step decoder steps per utterance in two launches)" % (min(chunk_steps), int(steps_per_utt)),
             "bound": "hbm",
@@ -314,6 +318,9 @@ def main():
             % (len(share), len(chunks), fr, it),
             "mel_frames_per_s_mel_gen": fr / t_mel,
             "ms": {"encoder": tm["encoder_ms"], "decoder_loop": tm["decoder_ms"], "postnet": tm["postnet_ms"], "wall_mel_gen": t_mel * 1e3},
+            "postnet_roofline": {"kernel": "k_gemm_nt<64,64> x 5 (implicit-GEMM conv1d k5, SURVEY 8d: 8 683 520 FLOP per frame)", "bound": "mfma",
+                                 "achieved": POSTNET_FLOP_PER_FRAME * fr / (tm["postnet_ms"] * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                                 "frac": POSTNET_FLOP_PER_FRAME * fr / (tm["postnet_ms"] * 1e-3) / 1e12 / MFMA_F32_PEAK_TF},
             "us_per_lockstep_iteration": tm["decoder_ms"] * 1e3 / it,
             "roofline": {
                 "kernel": "the decoder iteration of the batched path (three launches: k_prenet_b with the location blocks, k_att_lstm_attention, k_lstm_mfma<DEC>)",
