@@ -457,37 +457,52 @@ __global__ __launch_bounds__(PRENET_BT) void k_prenet_b(DecoderBufs d, int i, in
   // ---- every global load of the kernel, issued before anything is waited for ----
   const int m4 = tid & 31, part = tid >> 5;
   const float4 *pm = reinterpret_cast<const float4 *>(d.pmel + (size_t)b * PM_ROWS * MEL_LD);
+  // (the small loads first: vmcnt retires in issue order, so a value loaded behind the weight blocks could not be used before them)
+  // and the compiler must not look at them before the last big load has been issued: it would scalarise the three block-uniform
+  // ones on the spot (v_readfirstlane behind s_waitcnt vmcnt(0): one exposed L2 round trip ahead of everything else) -- they are
+  // handed to it through the asm below
+  float bias_raw = proj_b[tid < N_MEL + 1 ? tid : N_MEL];
+  int step_v = d.ctl[0], nf_v = d.nframes[b];
+  int perm_v = *(d.item_perm ? d.item_perm + b : d.nframes + b);  // (unconditional load; the value is dropped without a permutation)
+  asm volatile("" ::: "memory");
+  // Every load below is UNCONDITIONAL (addresses clamped, values masked where they are consumed): a load under a condition is a
+  // control-flow join, after which the compiler's waitcnt pass no longer knows how many younger loads are in flight and waits
+  // for vmcnt(0) -- the row sum then sat behind W0 and W1 as well, i.e. behind all 296 KB of the block (seen in the ISA; in-kernel
+  // clocks: 1.7 us between the last load's issue and the summed rows).  Straight-line, the rows are waited for with vmcnt(13),
+  // layer 1 with vmcnt(8), and the two weight blocks arrive while the mel is summed, stored and judged by the stop rule.
   float4 rv[ROWS];
+  const bool col_ok = m4 < MEL_LD / 4;
 #pragma unroll
   for (int k = 0; k < ROWS; ++k) {
     const int row = part + NPART * k;
-    rv[k] = (m4 < MEL_LD / 4 && row < PM_ROWS) ? pm[(size_t)row * (MEL_LD / 4) + m4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    rv[k] = pm[(size_t)(row < PM_ROWS ? row : PM_ROWS - 1) * (MEL_LD / 4) + (col_ok ? m4 : 0)];
   }
+  asm volatile("" ::: "memory");
   const int o4 = tid & 63, kg1 = tid >> 6;       // layer 1: outputs 4 o4 .. +3, inputs IN1 kg1 .. +IN1
   const int c4 = tid % (HALF / 4), kg2 = tid / (HALF / 4);  // layer 2: columns HALF half + 4 c4 .. +3, inputs IN2 kg2 .. +IN2
   float4 w0[IN1], w1[IN2];
-  if (!flush) {
 #pragma unroll
-    for (int k = 0; k < IN1; ++k) w0[k] = reinterpret_cast<const float4 *>(W0T)[(size_t)(kg1 * IN1 + k) * (PRENET / 4) + o4];
+  for (int k = 0; k < IN1; ++k) w0[k] = reinterpret_cast<const float4 *>(W0T)[(size_t)(kg1 * IN1 + k) * (PRENET / 4) + o4];
+  asm volatile("" ::: "memory");
 #pragma unroll
-    for (int k = 0; k < IN2; ++k) w1[k] = reinterpret_cast<const float4 *>(W1T)[((size_t)(kg2 * IN2 + k) * PRENET + HALF * half) / 4 + c4];
-  }
-  const float bias = tid < N_MEL + 1 ? proj_b[tid] : 0.f;
-  const int step = d.ctl[0] + i;
-  const int nf = d.nframes[b];
-  const uint32_t item = d.item_base + (uint32_t)(d.item_perm ? d.item_perm[b] : b);
+  for (int k = 0; k < IN2; ++k) w1[k] = reinterpret_cast<const float4 *>(W1T)[((size_t)(kg2 * IN2 + k) * PRENET + HALF * half) / 4 + c4];
+  asm volatile("" : "+v"(bias_raw), "+v"(step_v), "+v"(nf_v), "+v"(perm_v) : : "memory");
+  const int step = step_v + i;
+  const int nf = nf_v;
+  const uint32_t item = d.item_base + (uint32_t)(d.item_perm ? perm_v : b);
   PPROBE(1);
   // ---- projection of the previous step: sum of the 264 partial rows in a fixed order ----
   {
-    float4 r = rv[0];
+    float4 r = rv[0];  // (row `part` < NPART <= PM_ROWS always exists)
 #pragma unroll
     for (int k = 1; k < ROWS; ++k) {
-      r.x += rv[k].x;
-      r.y += rv[k].y;
-      r.z += rv[k].z;
-      r.w += rv[k].w;
+      const bool ok = part + NPART * k < PM_ROWS;  // (the clamped duplicate of the last row otherwise)
+      r.x += ok ? rv[k].x : 0.f;
+      r.y += ok ? rv[k].y : 0.f;
+      r.z += ok ? rv[k].z : 0.f;
+      r.w += ok ? rv[k].w : 0.f;
     }
-    if (m4 < MEL_LD / 4) *reinterpret_cast<float4 *>(&s_red[part][4 * m4]) = r;
+    if (col_ok) *reinterpret_cast<float4 *>(&s_red[part][4 * m4]) = r;
   }
   __syncthreads();
   PPROBE(2);
@@ -495,7 +510,7 @@ __global__ __launch_bounds__(PRENET_BT) void k_prenet_b(DecoderBufs d, int i, in
   if (tid < MEL_LD) {
     float v = 0.f;
     if (have_prev && tid < N_MEL + 1) {
-      v = bias;
+      v = bias_raw;
 #pragma unroll
       for (int k = 0; k < NPART; ++k) v += s_red[k][tid];
     }
@@ -723,13 +738,22 @@ __device__ __forceinline__ void lstm_mfma_pass(const DecoderBufs &d, int n0, int
   // i.e. for the whole 42 MB HBM stream, and the MFMAs could not overlap it (measured: 5-12 us from kernel
   // entry to the first MFMA).  Both streams are issued in consumption order instead: weights three
   // k-steps ahead (HBM latency), activations two (L2).
-#ifndef XDTTS_LSTM_DW
-#define XDTTS_LSTM_DW 3  // (4 and 6 measured slower: every activation vector then queues behind more weight loads)
+  // Depth by the number of active tiles (measured with the k-steps fenced as below, all chunks active, us per iteration at
+  // 8 / 32 / 48 / 52 / 64 chunks): weights 3 + activations 2 ahead 29.6 / 32.6 / 39.0 / 44.8 / 45.7; 3 + 1: 30.5 / 33.8 / 39.4 / 44.1 / 44.8;
+  // 2 + 1: 30.3 / 33.4 / 38.5 / 43.7 / 44.6; 2 + 2: 29.6 / 32.8 / 38.7 / 44.6 / 45.5; 4 + 2: 29.9 / 32.9 / 40.1 / 44.7 / 45.5 -- with three or
+  // four tiles in flight per k-step every activation vector queues behind more loads, so they run one k-step shallower.
+  // (-DXDTTS_LSTM_DW / -DXDTTS_LSTM_DX override both cases.)
+#ifdef XDTTS_LSTM_DW
+  constexpr int DW = XDTTS_LSTM_DW;
+#else
+  constexpr int DW = NTA >= 3 ? 2 : 3;
 #endif
-#ifndef XDTTS_LSTM_DX
-#define XDTTS_LSTM_DX 2  // activations: 1 -> 41.0, 2 -> 38.5, 3 -> 38.5 (DW 3) / 38.8 (DW 4), 4 -> 39.1-39.7, 6 -> 41.2 us per 52-chunk iteration
+#ifdef XDTTS_LSTM_DX
+  constexpr int DX = XDTTS_LSTM_DX;
+#else
+  constexpr int DX = NTA >= 3 ? 1 : 2;
 #endif
-  constexpr int DW = XDTTS_LSTM_DW, DX = XDTTS_LSTM_DX, RX = DX + 1;
+  constexpr int RX = DX + 1;
   float4 ring[RX][NTA], wring[8];
 #pragma unroll
   for (int p = 0; p < (DW > DX ? DW : DX) && p < JJ; ++p) {
@@ -742,6 +766,12 @@ __device__ __forceinline__ void lstm_mfma_pass(const DecoderBufs &d, int n0, int
     }
     asm volatile("" ::: "memory");
   }
+  // batched cell state: [256 blocks][Bpad][4 units], one 256-byte run per tile.  Loaded here, behind the first operand
+  // loads, so that it is in its register long before the tail needs it (see the pin ahead of the hook below).
+  float *cst = KIND == 0 ? d.att_c : d.dec_c;
+  const size_t ci = ((size_t)blk * d.Bpad + n0 + 16 * (wave < NTA ? wave : 0) + fi) * 4 + fg;
+  float c_old = cst[wave < NTA && n0 + 16 * wave + fi < d.B ? ci : (size_t)blk * d.Bpad * 4];  // (unconditional: clamped to the block's first state)
+  asm volatile("" ::: "memory");
 #pragma unroll
   for (int jj = 0; jj < JJ; ++jj) {
     // (the activations of step jj + DX before the weights of step jj + DW: loads retire in issue order, and the other
@@ -754,6 +784,10 @@ __device__ __forceinline__ void lstm_mfma_pass(const DecoderBufs &d, int n0, int
     asm volatile("" ::: "memory");
     if (jj + DW < JJ) wring[(jj + DW) % 8] = wsrc[(size_t)(jj + DW) * 64];
     asm volatile("" ::: "memory");
+    // (the asm fences order memory operations only: the MFMAs of the NEXT k-step, whose operands are in flight already, are free
+    // to be hoisted above this k-step's loads, and then every load is waited for right behind its issue -- seen in the ISA after an
+    // unrelated edit: vmcnt(3)/(1)/(0) instead of (9)..(6), the decoder-LSTM launch 1.5-2.7 us slower.  Hence the scheduling fence.)
+    __builtin_amdgcn_sched_barrier(0);
     const float4 wv = wring[jj % 8];
     const float4(&xv)[NTA] = ring[jj % RX];
     // interleave the tiles so consecutive MFMAs hit different accumulators (40-cycle dependent latency)
@@ -769,12 +803,12 @@ __device__ __forceinline__ void lstm_mfma_pass(const DecoderBufs &d, int n0, int
   PROBE(1);
   float *h_out = KIND == 0 ? d.att_h[cur ^ 1] : d.dec_h[cur ^ 1];
   float *hf_out = KIND == 0 ? d.att_hf[cur ^ 1] : d.dec_hf[cur ^ 1];
-  float *cst = KIND == 0 ? d.att_c : d.dec_c;
-  // batched cell state: [256 blocks][Bpad][4 units], one 256-byte run per tile
-  const size_t ci = ((size_t)blk * d.Bpad + n0 + 16 * (wave < NTA ? wave : 0) + fi) * 4 + fg;
-  float c_old = 0.f;
-  if (wave < NTA && n0 + 16 * wave + fi < d.B) c_old = cst[ci];
-  asm volatile("" ::: "memory");
+  // Everything the tail still needs from memory (cell state, gate biases) is pinned in registers BEFORE the hook's loads go
+  // out: vmcnt counts in order, and behind the conditional hook the compiler waits for vmcnt(0) at the next use of any loaded
+  // value -- the cell update, and with it the publish of h, then sat behind the whole attention prefetch of the block
+  // (290 KB through the L1 port, ~2 us; seen in the ISA as s_waitcnt vmcnt(0) ahead of the accumulator exchange).
+  float4 bzp = bz;
+  asm volatile("" : "+v"(c_old), "+v"(bzp.x), "+v"(bzp.y), "+v"(bzp.z), "+v"(bzp.w));
   after_loop();
   // [K-slice][tile][lane][gate]
 #pragma unroll
@@ -790,8 +824,8 @@ __device__ __forceinline__ void lstm_mfma_pass(const DecoderBufs &d, int n0, int
     if (n < d.B) {
       // hardware exp2 / rcp forms (device_utils.h), as in the persistent engine: this tail runs on NTA of
       // the waves while the others wait
-      const float ig = fast_sigmoid(g[0] + bz.x), fgt = fast_sigmoid(g[1] + bz.y);
-      const float gg = fast_tanh(g[2] + bz.z), og = fast_sigmoid(g[3] + bz.w);
+      const float ig = fast_sigmoid(g[0] + bzp.x), fgt = fast_sigmoid(g[1] + bzp.y);
+      const float gg = fast_tanh(g[2] + bzp.z), og = fast_sigmoid(g[3] + bzp.w);
       const float cn = fmaf(fgt, c_old, ig * gg);
       hn = og * fast_tanh(cn);
       if ((active >> (16 * wave + fi)) & 1ull) {
