@@ -743,15 +743,21 @@ __device__ __forceinline__ void lstm_mfma_pass(const DecoderBufs &d, int n0, int
   // 2 + 1: 30.3 / 33.4 / 38.5 / 43.7 / 44.6; 2 + 2: 29.6 / 32.8 / 38.7 / 44.6 / 45.5; 4 + 2: 29.9 / 32.9 / 40.1 / 44.7 / 45.5 -- with three or
   // four tiles in flight per k-step every activation vector queues behind more loads, so they run one k-step shallower.
   // (-DXDTTS_LSTM_DW / -DXDTTS_LSTM_DX override both cases.)
+#ifndef XDTTS_HI_ATT
+#define XDTTS_HI_ATT 21  // weights / activations ahead (two digits) from three active tiles on: attention LSTM ...
+#endif
+#ifndef XDTTS_HI_DEC
+#define XDTTS_HI_DEC 21  // ... and decoder LSTM
+#endif
 #ifdef XDTTS_LSTM_DW
   constexpr int DW = XDTTS_LSTM_DW;
 #else
-  constexpr int DW = NTA >= 3 ? 2 : 3;
+  constexpr int DW = NTA >= 3 ? (KIND == 0 ? XDTTS_HI_ATT : XDTTS_HI_DEC) / 10 : 3;
 #endif
 #ifdef XDTTS_LSTM_DX
   constexpr int DX = XDTTS_LSTM_DX;
 #else
-  constexpr int DX = NTA >= 3 ? 1 : 2;
+  constexpr int DX = NTA >= 3 ? (KIND == 0 ? XDTTS_HI_ATT : XDTTS_HI_DEC) % 10 : 2;
 #endif
   constexpr int RX = DX + 1;
   float4 ring[RX][NTA], wring[8];
