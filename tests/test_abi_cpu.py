@@ -41,6 +41,16 @@ def test_no_gpu_means_error_not_fallback(pkg):
     assert e.value.status == pkg.XDTTS_ERR_NO_DEVICE
 
 
+def test_synthesize_batch_rejects_bad_arguments_without_touching_a_device(pkg):
+    """xdtts_synthesize_batch (XdTts::infer for several utterances): argument errors come back as status
+    codes with a message, before anything is launched -- so this runs without a GPU too."""
+    import ctypes as C
+    n = C.c_size_t()
+    st = pkg.lib.xdtts_synthesize_batch(None, None, None, None, 1, 1, None, 1, None, None, None, C.byref(n), None, None)
+    assert st == pkg.XDTTS_ERR_BAD_ARG
+    assert b"null" in pkg.lib.xdtts_last_error()
+
+
 def test_default_opts_are_the_reference_constants(pkg):
     o = pkg.default_opts()
     assert abs(o.gate_threshold - 0.6) < 1e-7 and o.max_steps == 1000  # mod.rs:279-280
