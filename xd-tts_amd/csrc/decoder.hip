@@ -447,15 +447,21 @@ __global__ __launch_bounds__(PRENET_BT) void k_prenet_b(DecoderBufs d, int i, in
 #define PPROBE(i) do { } while (0)
 #endif
   constexpr int HALF = PRENET / PRENET_SPLIT;          // layer-2 columns of this block
-  constexpr int NPART = PRENET_BT / 32;                // 32 row groups of the partial-mel reduction
-  constexpr int ROWS = (PM_ROWS + NPART - 1) / NPART;  // 9 rows per group
+  // The partial-mel rows are dense in memory (84 floats = 21 16-byte vectors each, no gap between rows), so the reduction reads
+  // them as one run of 264 x 21 vectors: thread (part = tid / 21, m4 = tid % 21) of the first 1008 takes vectors tid + 1008 k --
+  // the same column every time (1008 = 48 x 21), rows part + 48 k -- with fully used 1 KiB wave loads; 6 loads per thread, where a
+  // (32 columns, 21 used) x 32 row-group mapping needed 9 with a third of the lanes idle (the block is bound by the issue of its loads).
+  constexpr int C4 = MEL_LD / 4;                       // 21 vectors per row
+  constexpr int NPART = PRENET_BT / C4;                // 48 row groups of the partial-mel reduction
+  constexpr int ROWS = (PM_ROWS + NPART - 1) / NPART;  // 6 rows per group (the last one only for the first 24 groups)
+  static_assert(NPART * C4 <= PRENET_BT && PM_ROWS * MEL_LD % 4 == 0, "dense row mapping");
   constexpr int KG1 = PRENET_BT / 64, IN1 = N_MEL / KG1;       // layer 1: 16 input groups of 5
   constexpr int KG2 = PRENET_BT / (HALF / 4), IN2 = PRENET / KG2;  // layer 2: 32 input groups of 8
   const int tid = threadIdx.x;
   const int b = blockIdx.x / PRENET_SPLIT, half = blockIdx.x % PRENET_SPLIT;
   __shared__ __attribute__((aligned(16))) float s_red[NPART][MEL_LD], s_mel[MEL_LD], s_p1[KG1][PRENET], s_x1[PRENET], s_p2[KG2][HALF];
   // ---- every global load of the kernel, issued before anything is waited for ----
-  const int m4 = tid & 31, part = tid >> 5;
+  const int m4 = tid % C4, part = tid / C4;  // (part >= NPART: the 16 spare threads)
   const float4 *pm = reinterpret_cast<const float4 *>(d.pmel + (size_t)b * PM_ROWS * MEL_LD);
   // (the small loads first: vmcnt retires in issue order, so a value loaded behind the weight blocks could not be used before them)
   // and the compiler must not look at them before the last big load has been issued: it would scalarise the three block-uniform
@@ -471,11 +477,11 @@ __global__ __launch_bounds__(PRENET_BT) void k_prenet_b(DecoderBufs d, int i, in
   // clocks: 1.7 us between the last load's issue and the summed rows).  Straight-line, the rows are waited for with vmcnt(13),
   // layer 1 with vmcnt(8), and the two weight blocks arrive while the mel is summed, stored and judged by the stop rule.
   float4 rv[ROWS];
-  const bool col_ok = m4 < MEL_LD / 4;
+  const bool col_ok = part < NPART;
 #pragma unroll
   for (int k = 0; k < ROWS; ++k) {
     const int row = part + NPART * k;
-    rv[k] = pm[(size_t)(row < PM_ROWS ? row : PM_ROWS - 1) * (MEL_LD / 4) + (col_ok ? m4 : 0)];
+    rv[k] = pm[(size_t)(col_ok && row < PM_ROWS ? row : PM_ROWS - 1) * C4 + m4];
   }
   asm volatile("" ::: "memory");
   const int o4 = tid & 63, kg1 = tid >> 6;       // layer 1: outputs 4 o4 .. +3, inputs IN1 kg1 .. +IN1
@@ -493,7 +499,7 @@ __global__ __launch_bounds__(PRENET_BT) void k_prenet_b(DecoderBufs d, int i, in
   PPROBE(1);
   // ---- projection of the previous step: sum of the 264 partial rows in a fixed order ----
   {
-    float4 r = rv[0];  // (row `part` < NPART <= PM_ROWS always exists)
+    float4 r = rv[0];  // (row `part` < NPART <= PM_ROWS always exists; the spare threads' sums are dropped)
 #pragma unroll
     for (int k = 1; k < ROWS; ++k) {
       const bool ok = part + NPART * k < PM_ROWS;  // (the clamped duplicate of the last row otherwise)
