@@ -9,7 +9,8 @@
 //   * BiLSTM input projections, the attention memory layer, and the Griffin-Lim mel->linear
 //     product (pinv(mel_basis) . exp(mel)).
 // Tile: 32x32 or 64x64 per 256-thread block (one or 2x2 16x16 MFMA tiles per wave), K-slab 32 through
-// double-buffered LDS, global loads four slabs ahead.  Within a slab the contraction
+// LDS (three buffers and a three-stage software pipeline for the 32x32 form, two buffers for 64x64), global loads
+// four slabs ahead, block -> tile mapping chosen by XCD (below).  Within a slab the contraction
 // index is permuted (k = 4*(lane>>4) + kk) so each lane fetches its four K values of a tile row
 // with one ds_read_b128.
 #include <algorithm>
@@ -24,10 +25,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Output tile per 256-thread block: 2 x 2 waves, each MT x NT MFMA tiles of 16x16.
 //   32x32 (MT = NT = 1): the single-utterance shapes (M = 100..800 rows put only 1-2 blocks on a CU) -- measured
-//     the fastest there (64x64: post-net 0.49 / 0.79 ms against 0.38 ms);
+//     the fastest there (round 1: 64x64 post-net 0.49 / 0.79 ms against 0.38 ms; now 0.15 ms);
 //   64x64 (MT = NT = 2): batches whose grid fills the chip several times over (the 52-chunk post-net: M = 25 171
 //     rows in all): four times the MFMA work per staged slab and per barrier.
-// K-slab 32 through double-buffered LDS, one barrier per slab.  A slab's MFMAs take 0.1-0.4 us and an L2 round
+// K-slab 32 through LDS, one barrier per slab.  A slab's MFMAs take 0.1-0.4 us and an L2 round
 // trip ~0.7 us, so the global loads run FOUR slabs ahead in named registers (an indexed ring was demoted to
 // scratch by the compiler), unconditional and clamped into the operand so nothing depends on their data until
 // the slab is staged (the zero fill happens there).  Every output element accumulates its K products in
