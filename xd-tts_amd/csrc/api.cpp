@@ -550,9 +550,17 @@ struct xdtts_tacotron2 {
     std::unique_lock<std::recursive_mutex> chip;
     if (d.hg) chip = std::unique_lock<std::recursive_mutex>(chip_mutex(device));
     if (!d.use_gate) {  // deterministic work: every chunk runs to its cap
-      while (launched < max_lim) {
+      while (launched + GRAPH_STEPS <= max_lim) {
         replay_steps(d);
         launched += GRAPH_STEPS;
+      }
+      if (launched < max_lim) {
+        // the last < GRAPH_STEPS steps as plain launches of exactly that many (even) steps: a whole graph would run up to
+        // GRAPH_STEPS - 1 steps with no chunk active, three launches of ~3.5 us each (the 647-iteration batch of configs[2]: 13)
+        int r = max_lim - launched;
+        r += r & 1;
+        launch_decoder_steps(d, w, r, stream);
+        launched += r;
       }
       launch_decoder_flush(d, w, stream);
       fetch();
