@@ -271,9 +271,11 @@ struct xdtts_tacotron2 {
       launch_gemm_nt(g, stream);
     }
     if (coop_ok) {
-      // equal groups of at most coop_group chunks (52 chunks on 256 CUs: 26 + 26)
-      const int launches = (B + coop_group - 1) / coop_group, group = (B + launches - 1) / launches;
-      enc_exchange.alloc(bilstm_coop_exchange_words(group));
+      // groups of four workgroups per direction, at most coop_group of them per launch; from coop_group + 1 chunks on a group
+      // takes two chunks (52 chunks on 256 CUs: one launch of 26 two-chunk groups; it was 26 + 26 one-chunk groups)
+      const int slots = B > coop_group ? (B + 1) / 2 : B;  // groups needed
+      const int launches = (slots + coop_group - 1) / coop_group, group = B > coop_group ? coop_group : (B + launches - 1) / launches;
+      enc_exchange.alloc(bilstm_coop_exchange_words(2 * group));
       launch_bilstm_coop(xproj.p, w.enc_whhT[0].p, w.enc_whhT[1].p, memory.p, enc_exchange.p, enc_err.p, B, T, group,
                          stream);
     } else {
