@@ -815,12 +815,11 @@ __device__ __forceinline__ void lstm_mfma_pass(const DecoderBufs &d, int n0, int
   PROBE(1);
   float *h_out = KIND == 0 ? d.att_h[cur ^ 1] : d.dec_h[cur ^ 1];
   float *hf_out = KIND == 0 ? d.att_hf[cur ^ 1] : d.dec_hf[cur ^ 1];
-  // Everything the tail still needs from memory (cell state, gate biases) is pinned in registers BEFORE the hook's loads go
-  // out: vmcnt counts in order, and behind the conditional hook the compiler waits for vmcnt(0) at the next use of any loaded
-  // value -- the cell update, and with it the publish of h, then sat behind the whole attention prefetch of the block
-  // (290 KB through the L1 port, ~2 us; seen in the ISA as s_waitcnt vmcnt(0) ahead of the accumulator exchange).
-  float4 bzp = bz;
-  asm volatile("" : "+v"(c_old), "+v"(bzp.x), "+v"(bzp.y), "+v"(bzp.z), "+v"(bzp.w));
+  // (Cell state and gate biases are first used behind the conditional hook below, so the compiler waits for vmcnt(0) there --
+  // the whole attention prefetch of the block -- before the accumulator exchange.  Pinning both in registers ahead of the hook
+  // removes that wait and lets the block publish h ~2 us earlier, but measured 0.1 ms per 647-iteration batch SLOWER: the
+  // attention blocks wait for the slowest publisher of 256 either way, and their own prefetch then lands later.  Not pinned.)
+  const float4 bzp = bz;
   after_loop();
   // [K-slice][tile][lane][gate]
 #pragma unroll
