@@ -51,12 +51,21 @@ typedef struct {
   int32_t fixed_steps;   /* 0: stop on the gate (reference behaviour); >0: emit exactly this many
                             frames per chunk (deterministic work for benchmarks/parity) */
   int32_t dropout_mode;  /* 0 off; 1 seeded counter-based masks (the exported decoder graph keeps
-                            the prenet's p=0.5 dropout on at inference) */
+                            the prenet's p=0.5 dropout on at inference); 2 explicit: the caller's
+                            keep masks (dropout_masks below) */
   uint32_t dropout_seed;
   int32_t max_chunk;     /* encoder window; chunks are zero-padded to exactly this length */
   uint32_t item_base;    /* index of the first chunk in the dropout stream (batch sharding) */
   float fixed_frames_per_id; /* >0 (and fixed_steps == 0): chunk of n ids emits round(n * this)
                             frames -- deterministic work proportional to the chunk length */
+  /* dropout_mode 2 (SURVEY.md section 8(b) "explicit(mask ptr)"): keep bytes
+   * [chunk][dropout_mask_steps][2 prenet layers][256 units], non-zero = keep (the kept value is
+   * doubled, p = 0.5), chunk = index of the chunk within this call, step = frame index.  This is
+   * the hook for comparing with ONE recorded run of the real decoder_iter.onnx, whose in-graph
+   * RandomUniform draws (src/tacotron2/mod.rs:304) cannot be seeded from outside.  Every chunk's
+   * step limit must be <= dropout_mask_steps.  Host memory, read during the call only. */
+  const uint8_t *dropout_masks;
+  int32_t dropout_mask_steps;
 } xdtts_infer_opts;
 
 void xdtts_infer_opts_default(xdtts_infer_opts *opts);
@@ -67,13 +76,25 @@ void xdtts_infer_opts_default(xdtts_infer_opts *opts);
  * encoder.onnx, decoder_iter.onnx and postnet.onnx (mod.rs:246-259) are read directly (a minimal
  * protobuf reader pulls the weights out of the graphs; nothing of the graphs is executed), or, if
  * present, the flat container `tacotron2.xdtw` written by xdtts_tacotron2_save.  A git-LFS pointer
- * file in place of a graph gives XDTTS_ERR_IO with a message naming `git lfs pull`. */
+ * file in place of a graph gives XDTTS_ERR_IO with a message naming `git lfs pull`.
+ * What the reader expects of the graphs (torch.onnx.export of the NVIDIA model, csrc/onnx_load.cpp): attention_rnn,
+ * decoder_rnn and the encoder BiLSTM as ONNX `LSTM` nodes (the exporter script's LSTMCell -> LSTM form; an LSTMCell
+ * decomposed into Gemm/Sigmoid/Tanh is reported as "no LSTM node with input width 768"), convolutions as `Conv` with or
+ * without a following `BatchNormalization` (a folded conv is loaded with identity statistics), linear layers as MatMul / Gemm
+ * with a constant operand, and the graph input / output names the reference binds (xdtts_model_dir_describe). */
 xdtts_status xdtts_tacotron2_load(const char *dir, int32_t device_id, xdtts_tacotron2 **out);
 
 /* The host half of Tacotron2::load: reads `dir` (ONNX graphs or tacotron2.xdtw, as above) into a
  * caller-held flat fp32 blob in canonical tensor order (n_floats == xdtts_tensor_total()).  Needs no
  * device; xdtts_tacotron2_load(dir) == this + xdtts_tacotron2_load_blob. */
 xdtts_status xdtts_model_dir_read(const char *dir, float *blob, size_t n_floats);
+
+/* The graph inputs / outputs of the three ONNX files of `dir`, one line per file:
+ * "decoder_iter.onnx: inputs a,b,.. ; outputs x,y,..\n".  xdtts_tacotron2_load / xdtts_model_dir_read REQUIRE the names the
+ * reference binds: the 11 named inputs of src/tacotron2/mod.rs:284-296, the 9 named outputs of :306-307,332-339,
+ * `mel_outputs_postnet` (:349), 2 inputs / 3 outputs for the encoder (:379-385) -- XDTTS_ERR_IO otherwise.
+ * buf may be NULL with cap 0 to ask for the size (*needed, terminator included). */
+xdtts_status xdtts_model_dir_describe(const char *dir, char *buf, size_t cap, size_t *needed);
 
 /* Seeded synthetic weights with the checkpoint's exact shapes. */
 xdtts_status xdtts_tacotron2_load_synthetic(uint32_t seed, float rec_scale, int32_t device_id,
@@ -140,6 +161,27 @@ xdtts_status xdtts_tacotron2_decoder_step(xdtts_tacotron2 *h, const float *memor
                                           float *attention_weights, float *attention_weights_cum,
                                           float *attention_context, float *decoder_output,
                                           float *gate_prediction);
+
+/* The same hook through the frame-loop engine the caller names, for B chunks and n_steps >= 1 consecutive calls of
+ * decoder_iter.onnx, each fed the previous one's outputs as the reference's loop does (mod.rs:328-341):
+ *   engine 0  launch-per-stage GEMV kernels (what xdtts_tacotron2_decoder_step runs)
+ *   engine 1  the persistent weight-stationary kernel that serves 1..4-chunk requests -- the BASELINE configs[1]
+ *             engine (B <= 2 per launch, T <= 128).  It works from the attention WEIGHTS, so the incoming
+ *             attention_context must equal attention_weights . memory, as every state the graph itself produced does
+ *             (out_attention_context, mod.rs:332-339); anything else is XDTTS_ERR_BAD_ARG
+ *   engine 2  the batched MFMA kernels that serve lock-step batches of >= 5 chunks (configs[2] / [3]); B <= 64
+ * All arrays are [B][...] row-major: memory [B][T][512], processed_memory [B][T][128], n_valid [B], decoder_input
+ * [B][80], the seven state tensors [B][1024] x4, [B][T] x2, [B][512] (updated in place to the state after the last
+ * step); decoder_output [B][n_steps][80] and gate_prediction [B][n_steps] (logits; no stop rule is applied).
+ * step0 is the frame index of the first call (it selects the prenet-dropout draws), opts->item_base the first chunk's
+ * dropout-stream index.  n_steps > 1 from the zero state gives the engine's written-back state after a free run. */
+xdtts_status xdtts_tacotron2_decoder_steps(xdtts_tacotron2 *h, int32_t engine, int32_t B, const float *memory,
+                                           const float *processed_memory, int32_t T, const int32_t *n_valid,
+                                           const xdtts_infer_opts *opts, uint32_t step0, int32_t n_steps,
+                                           const float *decoder_input, float *attention_hidden, float *attention_cell,
+                                           float *decoder_hidden, float *decoder_cell, float *attention_weights,
+                                           float *attention_weights_cum, float *attention_context, float *decoder_output,
+                                           float *gate_prediction);
 
 /* Engine state of a handle: 1 = the persistent decoder / cooperative encoder is in use, 0 = the handle was
  * demoted to the launch-per-stage / single-workgroup engine after a timed-out exchange (it probes the fast

@@ -34,6 +34,8 @@ class DecoderOpts(C.Structure):
         ("dropout_mode", C.c_int32),
         ("dropout_seed", C.c_uint32),
         ("item", C.c_uint32),
+        ("masks", C.c_void_p),       # dropout_mode 2: [mask_steps][2][256] keep bytes of this chunk
+        ("mask_steps", C.c_int32),
     ]
 
 
@@ -124,8 +126,16 @@ class Oracle:
     def default_opts(self, **kw):
         o = DecoderOpts()
         self.lib.orc_decoder_opts_default(C.byref(o))
+        masks = kw.pop("masks", None)
         for k, v in kw.items():
             setattr(o, k, v)
+        if masks is not None:  # explicit prenet keep masks (steps, 2, 256) uint8 of this chunk: dropout_mode 2
+            m = np.ascontiguousarray(masks, dtype=np.uint8)
+            assert m.ndim == 3 and m.shape[1:] == (2, 256)
+            o._masks_keepalive = m
+            o.masks = m.ctypes.data
+            o.mask_steps = m.shape[0]
+            o.dropout_mode = 2
         return o
 
     def encoder(self, blob, ids):

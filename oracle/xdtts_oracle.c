@@ -342,6 +342,8 @@ void orc_decoder_opts_default(orc_decoder_opts *o) {
   o->dropout_mode = 1; /* the exported graph keeps the prenet dropout on at inference */
   o->dropout_seed = 0;
   o->item = 0;
+  o->masks = NULL;
+  o->mask_steps = 0;
 }
 
 /* DecoderState::new, src/tacotron2/mod.rs:202-233: everything zero. */
@@ -349,6 +351,14 @@ void orc_decoder_state_init(orc_decoder_state *s) { memset(s, 0, sizeof(*s)); }
 
 int orc_dropout_keep(uint32_t seed, uint32_t item, uint32_t step, int layer, int j) {
   return (orc_rng_u32(seed, 0x1000u + (uint32_t)layer + 2u * item, step * 256u + (uint32_t)j) >> 31) == 0;
+}
+
+/* dropout_mode 1: the seeded counter stream; 2: the caller's keep bytes [step][layer][unit] -- what the exported
+ * graph's RandomUniform would have drawn in one recorded run of decoder_iter.onnx (hard part i) */
+static int prenet_keep(const orc_decoder_opts *o, uint32_t step, int layer, int j) {
+  if (o->dropout_mode == 2)
+    return o->masks && (int64_t)step < o->mask_steps ? o->masks[((size_t)step * 2 + (size_t)layer) * ORC_PRENET + (size_t)j] != 0 : 1;
+  return orc_dropout_keep(o->dropout_seed, o->item, step, layer, j);
 }
 
 /* One decoder_iter.onnx call, src/tacotron2/mod.rs:304 with I/O names at :285-295,:306-307,
@@ -363,13 +373,13 @@ void orc_decoder_step(const float *blob, const real *memory, const real *pmem, i
   for (int j = 0; j < ORC_PRENET; ++j) {
     real v = dotw(p0 + (size_t)j * ORC_N_MEL, s->dec_in, ORC_N_MEL);
     v = v > 0 ? v : 0;
-    if (o->dropout_mode) v = orc_dropout_keep(o->dropout_seed, o->item, step, 0, j) ? v * 2 : 0;
+    if (o->dropout_mode) v = prenet_keep(o, step, 0, j) ? v * 2 : 0;
     x1[j] = v;
   }
   for (int j = 0; j < ORC_PRENET; ++j) {
     real v = dotw(p1 + (size_t)j * ORC_PRENET, x1, ORC_PRENET);
     v = v > 0 ? v : 0;
-    if (o->dropout_mode) v = orc_dropout_keep(o->dropout_seed, o->item, step, 1, j) ? v * 2 : 0;
+    if (o->dropout_mode) v = prenet_keep(o, step, 1, j) ? v * 2 : 0;
     cell_in[j] = v;
   }
   /* D2 attention LSTM on [prenet ; previous context] */

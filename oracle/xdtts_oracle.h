@@ -85,9 +85,11 @@ typedef struct {
   float gate_threshold; /* 0.6  mod.rs:279 */
   int32_t max_steps;    /* 1000 mod.rs:280 */
   int32_t fixed_steps;  /* 0 = use the gate; >0 = emit exactly this many frames */
-  int32_t dropout_mode; /* 0 off, 1 seeded */
+  int32_t dropout_mode; /* 0 off, 1 seeded, 2 explicit keep masks (below) */
   uint32_t dropout_seed;
   uint32_t item; /* utterance/chunk index mixed into the dropout stream */
+  const uint8_t *masks; /* dropout_mode 2: [mask_steps][2 layers][256] keep bytes of THIS chunk (non-zero = keep, x2) */
+  int32_t mask_steps;
 } orc_decoder_opts;
 
 void orc_decoder_opts_default(orc_decoder_opts *o);

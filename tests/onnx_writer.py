@@ -53,9 +53,22 @@ def node(op, inputs, outputs, attrs=b"", name=""):
               ld(3, name.encode()) + ld(4, op.encode()) + attrs)
 
 
-def model(nodes, inits):
+def model(nodes, inits, inputs=(), outputs=(), inits_as_inputs=()):
+    """inputs / outputs: graph value names (GraphProto.input = 11 / .output = 12, ValueInfoProto.name = 1);
+    inits_as_inputs: initialiser names listed among the inputs too, as IR version < 4 exporters do."""
     graph = b"".join(nodes) + ld(2, b"g") + b"".join(ld(5, t) for t in inits)
+    graph += b"".join(ld(11, ld(1, n.encode())) for n in list(inputs) + list(inits_as_inputs))
+    graph += b"".join(ld(12, ld(1, n.encode())) for n in outputs)
     return key(1, 0) + vint(7) + ld(2, b"pytorch") + ld(7, graph)
+
+
+# the names the reference binds (src/tacotron2/mod.rs:284-296,306-307,332-339,349; encoder positional, :379-385)
+ENC_IO = (["sequences", "sequence_lengths"], ["memory", "processed_memory", "lens"])
+DEC_IO = (["decoder_input", "attention_hidden", "attention_cell", "decoder_hidden", "decoder_cell", "attention_weights",
+           "attention_weights_cum", "attention_context", "memory", "processed_memory", "mask"],
+          ["decoder_output", "gate_prediction", "out_attention_hidden", "out_attention_cell", "out_decoder_hidden", "out_decoder_cell",
+           "out_attention_weights", "out_attention_weights_cum", "out_attention_context"])
+POST_IO = (["mel_outputs"], ["mel_outputs_postnet"])
 
 
 def onnx_gates(a, H):
@@ -72,7 +85,7 @@ def pack_lstm(dirs, H):
     return W, R, B
 
 
-def write_models(path, T, style):
+def write_models(path, T, style, dec_io=DEC_IO):
     """T: dict canonical name -> array (tools/onnx_to_xdtw.tensor_table names).  style 'folded': anonymous
     constants, MatMul with transposed weights, conv+BN pre-folded (BN tensors of T are ignored);
     style 'named': parameter names kept, Gemm transB=1, BatchNormalization nodes, mixed data encodings."""
@@ -144,7 +157,7 @@ def write_models(path, T, style):
     dirs = [{k: T["encoder.lstm.%s.%s" % (d, k)] for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")} for d in ("fwd", "bwd")]
     lstm(nodes, inits, x, "memory", dirs, 256, "encoder.lstm")
     lin(nodes, inits, "memory", "processed_memory", T["attention.memory_layer.weight"], None, "decoder.attention_layer.memory_layer")
-    open(os.path.join(path, "encoder.onnx"), "wb").write(model(nodes, inits))
+    open(os.path.join(path, "encoder.onnx"), "wb").write(model(nodes, inits, *ENC_IO))
 
     # decoder_iter.onnx
     nodes, inits = [], []
@@ -159,7 +172,8 @@ def write_models(path, T, style):
     lin(nodes, inits, "t", "e", T["attention.v.weight"].reshape(1, 128), None, "decoder.attention_layer.v")
     lin(nodes, inits, "hc", "decoder_output", T["linear_projection.weight"], T["linear_projection.bias"], "decoder.linear_projection")
     lin(nodes, inits, "hc", "gate_prediction", T["gate_layer.weight"].reshape(1, 1536), T["gate_layer.bias"], "decoder.gate_layer")
-    open(os.path.join(path, "decoder_iter.onnx"), "wb").write(model(nodes, inits))
+    # (the 'named' style also lists one initialiser among the graph inputs, as pre-IR-4 exporters do: it is not an input)
+    open(os.path.join(path, "decoder_iter.onnx"), "wb").write(model(nodes, inits, *dec_io, inits_as_inputs=[] if folded else ["decoder.gate_layer.weight"]))
 
     # postnet.onnx
     nodes, inits = [], []
@@ -167,4 +181,4 @@ def write_models(path, T, style):
     for i in range(5):
         conv(nodes, inits, x, "pc%d" % i, "postnet.convolutions.%d" % i, "postnet.convolutions.%d" % i)
         x = "pc%d" % i
-    open(os.path.join(path, "postnet.onnx"), "wb").write(model(nodes, inits))
+    open(os.path.join(path, "postnet.onnx"), "wb").write(model(nodes, inits, *POST_IO))

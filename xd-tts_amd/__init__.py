@@ -53,6 +53,8 @@ class InferOpts(C.Structure):
         ("max_chunk", C.c_int32),
         ("item_base", C.c_uint32),
         ("fixed_frames_per_id", C.c_float),
+        ("dropout_masks", C.c_void_p),      # dropout_mode 2: keep bytes [chunk][steps][2][256]
+        ("dropout_mask_steps", C.c_int32),
     ]
 
 
@@ -64,6 +66,7 @@ SYMBOLS = {
     "xdtts_infer_opts_default": (None, [C.POINTER(InferOpts)]),
     "xdtts_tacotron2_load": (_I32, [C.c_char_p, _I32, C.POINTER(_VP)]),
     "xdtts_model_dir_read": (_I32, [C.c_char_p, _VP, _SZ]),
+    "xdtts_model_dir_describe": (_I32, [C.c_char_p, C.c_char_p, _SZ, C.POINTER(_SZ)]),
     "xdtts_tacotron2_load_synthetic": (_I32, [_U32, _F, _I32, C.POINTER(_VP)]),
     "xdtts_tacotron2_load_blob": (_I32, [_VP, _SZ, _I32, C.POINTER(_VP)]),
     "xdtts_tacotron2_save": (_I32, [_VP, C.c_char_p]),
@@ -79,6 +82,7 @@ SYMBOLS = {
     "xdtts_tacotron2_encoder": (_I32, [_VP, _VP, _I32, _VP, _VP]),
     "xdtts_tacotron2_decoder": (_I32, [_VP, _VP, _VP, _I32, _I32, C.POINTER(InferOpts), _VP, _VP, C.POINTER(_SZ)]),
     "xdtts_tacotron2_decoder_step": (_I32, [_VP, _VP, _VP, _I32, _I32, C.POINTER(InferOpts), _U32] + [_VP] * 10),
+    "xdtts_tacotron2_decoder_steps": (_I32, [_VP, _I32, _I32, _VP, _VP, _I32, _VP, C.POINTER(InferOpts), _U32, _I32] + [_VP] * 10),
     "xdtts_tacotron2_engine_state": (_I32, [_VP, C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32)]),
     "xdtts_tacotron2_engine_reset": (_I32, [_VP]),
     "xdtts_tacotron2_postnet": (_I32, [_VP, _VP, _I32, _VP]),
@@ -171,10 +175,21 @@ def _ptr(a):
 
 
 def default_opts(**kw):
+    """xdtts_infer_opts with the reference's defaults; `dropout_masks=` takes a uint8 array (chunks, steps, 2, 256) of keep
+    bytes and selects dropout_mode 2 (the array is kept alive by the returned struct)."""
     o = InferOpts()
     lib.xdtts_infer_opts_default(C.byref(o))
+    masks = kw.pop("dropout_masks", None)
     for k, v in kw.items():
         setattr(o, k, v)
+    if masks is not None:
+        m = np.ascontiguousarray(masks, dtype=np.uint8)
+        if m.ndim != 4 or m.shape[2:] != (2, 256):
+            raise ValueError("dropout_masks must be (chunks, steps, 2, 256)")
+        o._masks_keepalive = m
+        o.dropout_masks = m.ctypes.data
+        o.dropout_mask_steps = m.shape[1]
+        o.dropout_mode = 2
     return o
 
 
@@ -197,6 +212,21 @@ def read_model_dir(path):
     blob = np.empty(lib.xdtts_tensor_total(), dtype=np.float32)
     _check(lib.xdtts_model_dir_read(os.fsencode(path), _ptr(blob), blob.size))
     return {n: blob[off : off + int(np.prod(shape))].reshape(shape) for n, shape, off in tensor_table()}
+
+
+def describe_model_dir(path):
+    """{file: (inputs, outputs)} of the three ONNX graphs of a model directory -- the names the reference binds at
+    src/tacotron2/mod.rs:284-296,306-307,332-339,349."""
+    need = C.c_size_t()
+    _check(lib.xdtts_model_dir_describe(os.fsencode(path), None, 0, C.byref(need)))
+    buf = C.create_string_buffer(need.value)
+    _check(lib.xdtts_model_dir_describe(os.fsencode(path), buf, need.value, None))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        f, rest = line.split(": inputs ", 1)
+        i, o = rest.split(" ; outputs ", 1)
+        out[f] = ([x for x in i.split(",") if x], [x for x in o.split(",") if x])
+    return out
 
 
 class _Pinned:
@@ -403,6 +433,24 @@ class Tacotron2:
         _check(lib.xdtts_tacotron2_decoder_step(self._h, _ptr(memory), _ptr(pmem), memory.shape[0], n_valid, C.byref(opts) if opts else None, step,
                                                 _ptr(din), *[_ptr(st[k]) for k in names], _ptr(out), _ptr(gate)))
         return out, float(gate[0]), st
+
+    ENGINES = {"launch": 0, "persistent": 1, "batched": 2}
+
+    def decoder_steps(self, engine, memory, pmem, n_valid, states, decoder_input, step0, n_steps=1, opts=None):
+        """n_steps decoder_iter calls for B chunks through the named engine ("launch" / "persistent" / "batched").
+        memory (B, T, 512), pmem (B, T, 128), n_valid (B,), decoder_input (B, 80); `states` = dict of (B, ...) arrays with the
+        reference's tensor names.  Returns (decoder_output (B, n_steps, 80), gate_prediction (B, n_steps), new states)."""
+        memory = np.ascontiguousarray(memory, dtype=np.float32)
+        pmem = np.ascontiguousarray(pmem, dtype=np.float32)
+        B, T = memory.shape[0], memory.shape[1]
+        nv = np.ascontiguousarray(n_valid, dtype=np.int32)
+        names = ("attention_hidden", "attention_cell", "decoder_hidden", "decoder_cell", "attention_weights", "attention_weights_cum", "attention_context")
+        st = {k: np.array(states[k], dtype=np.float32, order="C") for k in names}
+        din = np.ascontiguousarray(decoder_input, dtype=np.float32)
+        out, gate = np.empty((B, n_steps, N_MEL), dtype=np.float32), np.empty((B, n_steps), dtype=np.float32)
+        _check(lib.xdtts_tacotron2_decoder_steps(self._h, self.ENGINES[engine], B, _ptr(memory), _ptr(pmem), T, _ptr(nv), C.byref(opts) if opts else None,
+                                                 step0, n_steps, _ptr(din), *[_ptr(st[k]) for k in names], _ptr(out), _ptr(gate)))
+        return out, gate, st
 
     def engine_state(self):
         a, b, c = C.c_int32(), C.c_int32(), C.c_int32()

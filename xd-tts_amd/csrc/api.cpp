@@ -153,7 +153,7 @@ static std::recursive_mutex &chip_mutex(int device) {
 struct xdtts_tacotron2 {
   int device = 0;
   hipStream_t stream = nullptr;
-  std::mutex mu;
+  mutable std::mutex mu;
   std::vector<float> blob;  // canonical weights (host), for save/get_tensor
   DeviceWeights w;
   Events ev;
@@ -182,6 +182,8 @@ struct xdtts_tacotron2 {
   int persist_state = -1;                   // -1 unknown, 0 unavailable on this device / demoted, 1 usable
   bool persist_probe_ok = false;            // the device can host the persistent grid (occupancy probe)
   bool coop_ok = true;                      // cooperative encoder BiLSTM usable (cleared after a timed-out exchange)
+  bool coop_refused = false;                // the runtime refused its cooperative launch: never probed again
+  int enc_demoted_calls = 0;                // encoder calls since its demotion (own re-probe counter)
   int coop_group = 16;                      // chunks per cooperative BiLSTM launch: 8 workgroups of 1024 threads per
                                             // chunk must be co-resident, one per CU (set from the CU count in init)
   DevBuf<float> att_h, att_c, dec_h, dec_c, aw, awc, ctx, x, loc, e_part, pmel, frames, gates;
@@ -189,6 +191,8 @@ struct xdtts_tacotron2 {
   DevBuf<float> pmem_t;     // batched mode: processed_memory as [B][32][T][4]
   DevBuf<int> item_perm;    // batched mode: dropout-stream index of the (length-sorted) chunks
   DevBuf<float> dec_in_dev; // parity hook: decoder_input of xdtts_tacotron2_decoder_step
+  DevBuf<unsigned char> drop_dev;  // dropout_mode 2: the caller's keep masks
+  DevBuf<float> state_stage;       // parity hook: the seven state tensors in the caller's layout
   int demoted_calls = 0;    // decoder calls since a demotion (the fast engines are probed again after PROBE_AFTER)
   static constexpr int PROBE_AFTER = 64;
   DevBuf<float> ppA, ppB, mel_dev;
@@ -270,17 +274,33 @@ struct xdtts_tacotron2 {
       g.batch = B;
       launch_gemm_nt(g, stream);
     }
+    // a demoted encoder probes the cooperative recurrence again by itself (its own counter: the decoder's re-probe does not
+    // depend on it, and a batched decode never passes through use_persistent)
+    if (!coop_ok && !coop_refused && ++enc_demoted_calls >= PROBE_AFTER) {
+      enc_demoted_calls = 0;
+      coop_ok = true;
+    }
+    bool coop_ran = false;
     if (coop_ok) {
       // groups of four workgroups per direction, at most coop_group of them per launch; from coop_group + 1 chunks on a group
       // takes two chunks (52 chunks on 256 CUs: one launch of 26 two-chunk groups; it was 26 + 26 one-chunk groups)
       const int slots = B > coop_group ? (B + 1) / 2 : B;  // groups needed
       const int launches = (slots + coop_group - 1) / coop_group, group = B > coop_group ? coop_group : (B + launches - 1) / launches;
       enc_exchange.alloc(bilstm_coop_exchange_words(2 * group));
-      launch_bilstm_coop(xproj.p, w.enc_whhT[0].p, w.enc_whhT[1].p, memory.p, enc_exchange.p, enc_err.p, B, T, group,
-                         stream);
-    } else {
-      launch_bilstm(xproj.p, w.enc_whhT[0].p, w.enc_whhT[1].p, memory.p, B, T, stream);
+      try {
+        launch_bilstm_coop(xproj.p, w.enc_whhT[0].p, w.enc_whhT[1].p, memory.p, enc_exchange.p, enc_err.p, B, T, group,
+                           stream);
+        coop_ran = true;
+      } catch (const CoopRefused &) {
+        // the runtime refused the cooperative grid (CU masking, a smaller part): the single-workgroup recurrence serves
+        // this handle from now on -- the refusal is a property of the device, not a transient
+        coop_ok = false;
+        coop_refused = true;
+        std::fprintf(stderr, "libxdtts_hip: cooperative encoder BiLSTM launch refused by the runtime; this handle uses the "
+                             "single-workgroup recurrence\n");
+      }
     }
+    if (!coop_ran) launch_bilstm(xproj.p, w.enc_whhT[0].p, w.enc_whhT[1].p, memory.p, B, T, stream);
     GemmArgs g{};  // processed_memory = memory_layer(memory)
     g.A = memory.p;
     g.lda = EMB;
@@ -296,7 +316,21 @@ struct xdtts_tacotron2 {
     launch_gemm_nt(g, stream);
   }
 
-  DecoderBufs decoder_bufs(int B, int T, const float *mem, const float *pm, const xdtts_infer_opts &o) {
+  // dropout_mode 2 (SURVEY 8(b) "explicit(mask ptr)"): the caller's keep bytes [B][steps][2][256] go to the device; every
+  // chunk's step limit must lie inside them.  Any other mode value than 0 / 1 / 2 is refused here too.
+  void upload_dropout_masks(const xdtts_infer_opts &o, int B, const int *lim) {
+    if (o.dropout_mode < 0 || o.dropout_mode > 2) fail(XDTTS_ERR_BAD_ARG, "dropout_mode %d out of range (0 off, 1 seeded, 2 explicit)", o.dropout_mode);
+    if (o.dropout_mode != 2) return;
+    if (!o.dropout_masks || o.dropout_mask_steps <= 0) fail(XDTTS_ERR_BAD_ARG, "dropout_mode 2 needs dropout_masks and dropout_mask_steps");
+    for (int b = 0; b < B; ++b)
+      if (lim[b] > o.dropout_mask_steps)
+        fail(XDTTS_ERR_BAD_ARG, "chunk %d may run %d steps, the dropout masks cover %d", b, lim[b], o.dropout_mask_steps);
+    drop_dev.upload(o.dropout_masks, (size_t)B * o.dropout_mask_steps * 2 * PRENET, stream);
+  }
+
+  // force_batched: -1 = by batch size (the MFMA kernels from BATCH_MFMA_MIN chunks), 0 / 1 = the parity hook's choice
+  DecoderBufs decoder_bufs(int B, int T, const float *mem, const float *pm, const xdtts_infer_opts &o, int force_batched = -1) {
+    const bool batched = force_batched < 0 ? B >= BATCH_MFMA_MIN : force_batched != 0;
     const int ms = o.max_steps;
     att_h.alloc((size_t)2 * B * ATT_RNN);
     att_c.alloc((size_t)((B + 15) / 16 * 16) * ATT_RNN);  // (batched mode: [256][Bpad][4])
@@ -342,7 +376,11 @@ struct xdtts_tacotron2 {
     d.dropout_mode = o.dropout_mode;
     d.dropout_seed = o.dropout_seed;
     d.item_base = o.item_base;
-    if (B >= BATCH_MFMA_MIN) {  // MFMA B-operand copies [K/4][Bpad][4] of the vectors the LSTM GEMMs consume
+    if (o.dropout_mode == 2) {  // the caller's keep masks, uploaded by upload_dropout_masks()
+      d.drop_masks = drop_dev.p;
+      d.drop_steps = o.dropout_mask_steps;
+    }
+    if (batched) {  // MFMA B-operand copies [K/4][Bpad][4] of the vectors the LSTM GEMMs consume
       const int Bpad = (B + 15) / 16 * 16;
       frag.alloc((size_t)Bpad * (PRENET + EMB + 2 * ATT_RNN + 2 * DEC_RNN) + (size_t)B * T);
       d.Bpad = Bpad;
@@ -424,7 +462,6 @@ struct xdtts_tacotron2 {
     if (persist_state == 0 && persist_probe_ok && ++demoted_calls >= PROBE_AFTER) {
       demoted_calls = 0;
       persist_state = 1;
-      coop_ok = true;
     }
     return persist_state == 1;
   }
@@ -439,7 +476,7 @@ struct xdtts_tacotron2 {
       HIP_CHECK(hipMemcpyAsync(host_ctl + 2, d.nframes, sizeof(int) * d.B, hipMemcpyDeviceToHost, stream));
       HIP_CHECK(hipStreamSynchronize(stream));
     };
-    if (use_persistent(d)) {
+    if (use_persistent(d)) try {
       // one launch for the whole loop: the stop rule runs on the device and the kernel ends by itself.
       // Its grid must own the chip, so persistent launches of different handles never overlap.
       std::lock_guard<std::recursive_mutex> lk(chip_mutex(device));
@@ -467,6 +504,7 @@ struct xdtts_tacotron2 {
         v.gates += (size_t)b0 * d.max_steps;
         v.nframes += b0;
         v.item_base += (uint32_t)b0;
+        if (v.drop_masks) v.drop_masks += (size_t)b0 * d.drop_steps * 2 * PRENET;
         return v;
       };
       const char *no_shrink = getenv("XDTTS_NO_SHRINK");  // developer comparison aid
@@ -545,6 +583,16 @@ struct xdtts_tacotron2 {
       demoted_calls = 0;
       std::fprintf(stderr, "libxdtts_hip: persistent decoder exchange timed out (grid not co-resident); "
                            "this handle now uses the launch-per-stage decoder (probed again after %d calls)\n", PROBE_AFTER);
+      launch_decoder_init(d, limits.p, stream);
+    } catch (const CoopRefused &) {
+      // the runtime refused the cooperative grid: this device cannot host the persistent engine (not a transient, so no
+      // re-probe); decode the request on the launch-per-stage engine
+      persist_state = 0;
+      persist_probe_ok = false;
+      std::fprintf(stderr, "libxdtts_hip: persistent decoder launch refused by the runtime; this handle uses the "
+                           "launch-per-stage decoder\n");
+      HIP_CHECK(hipStreamSynchronize(stream));
+      HIP_CHECK(hipMemsetAsync(dec_err.p, 0, sizeof(int), stream));
       launch_decoder_init(d, limits.p, stream);
     }
     // the launch that holds the attention LSTM and the attention needs its 256 blocks resident together: like the
@@ -691,6 +739,7 @@ struct xdtts_tacotron2 {
       lim0[b] = std::min(std::max(l, 1), o.max_steps);
       order[b] = b;
     }
+    upload_dropout_masks(o, B, lim0.data());  // (caller's chunk order: a sorted batch finds its masks through item_perm)
     const bool gate_off = fixed_per_item || o.fixed_steps > 0 || o.fixed_frames_per_id > 0.f;
     if (B >= BATCH_MFMA_MIN)
       std::stable_sort(order.begin(), order.end(), [&](int a, int c) {
@@ -728,6 +777,9 @@ struct xdtts_tacotron2 {
       std::fprintf(stderr, "libxdtts_hip: encoder BiLSTM exchange timed out (grid not co-resident); "
                            "this handle now uses the single-workgroup recurrence\n");
       run_encoder(B, T);
+      // batched mode attends over the [B][32][T][4] transpose of processed_memory, written by decoder_bufs() from the
+      // timed-out encoder's output: redo it from the fresh one
+      if (d.pmem_t) launch_dimgroup_transpose(pmem.p, pmem_t.p, B, T, stream);
       last_steps = run_decoder(d, lim);
     }
     HIP_CHECK(hipEventRecord(ev.e[2], stream));
@@ -803,7 +855,7 @@ static void chunks_from_splits(const int64_t *ids, size_t n, const size_t *split
 struct xdtts_griffinlim {
   int device = 0;
   hipStream_t stream = nullptr;
-  std::mutex mu;
+  mutable std::mutex mu;
   int n_mels = 0, nb = 0, n_fft = 0, hop = 0, iters = 0;
   float power = 1.f, momentum = 0.99f;
   uint32_t seed = 0;
@@ -944,14 +996,18 @@ struct xdtts_griffinlim {
     launch_gl_pow_rows(nnls_x.p, NBP, S.p, nb, F, ex, stream);
   }
 
+  // Once per API call (never inside a retry attempt): a demoted handle counts the call and, after PROBE_AFTER of them,
+  // gives the persistent engine another try -- the cause of a timed-out exchange may have been transient.
+  void probe_tick() {
+    if (persist_state == 0 && n_cu > 0 && ++demoted_calls >= PROBE_AFTER) {
+      demoted_calls = 0;
+      persist_state = 1;
+    }
+  }
   bool persistent_usable() {
     const char *e = getenv("XDTTS_GL");
     if (e && std::string(e) == "launch") return false;  // developer comparison aid: launch-per-iteration engine
     if (persist_state < 0) persist_state = gl_persistent_supported(device, &n_cu) ? 1 : 0;
-    if (persist_state == 0 && n_cu > 0 && ++demoted_calls >= PROBE_AFTER) {  // a transient cause may be gone
-      demoted_calls = 0;
-      persist_state = 1;
-    }
     return persist_state == 1;
   }
 
@@ -1184,6 +1240,8 @@ void xdtts_infer_opts_default(xdtts_infer_opts *o) {
   o->max_chunk = 100;  // src/tacotron2/mod.rs:363,369-371,399
   o->item_base = 0;
   o->fixed_frames_per_id = 0.f;
+  o->dropout_masks = nullptr;
+  o->dropout_mask_steps = 0;
 }
 
 const char *xdtts_last_error(void) { return g_last_error.c_str(); }
@@ -1238,6 +1296,19 @@ xdtts_status xdtts_model_dir_read(const char *dir, float *blob, size_t n_floats)
     std::vector<float> v;
     load_model_dir(dir, v);
     std::memcpy(blob, v.data(), v.size() * sizeof(float));
+  });
+}
+
+xdtts_status xdtts_model_dir_describe(const char *dir, char *buf, size_t cap, size_t *needed) {
+  return guard([&] {
+    if (!dir || (!buf && cap)) fail(XDTTS_ERR_BAD_ARG, "null argument");
+    const std::string d = describe_onnx_dir(dir);
+    if (needed) *needed = d.size() + 1;
+    if (cap) {
+      const size_t n = std::min(cap - 1, d.size());
+      std::memcpy(buf, d.data(), n);
+      buf[n] = 0;
+    }
   });
 }
 
@@ -1396,8 +1467,9 @@ xdtts_status xdtts_tacotron2_decoder(xdtts_tacotron2 *h, const float *memory, co
     int nv = n_valid;
     h->n_valid.upload(&nv, 1, h->stream);
     HIP_CHECK(hipStreamSynchronize(h->stream));
-    DecoderBufs d = h->decoder_bufs(1, T, h->memory.p, h->pmem.p, o);
     std::vector<int> lim(1, std::min(o.fixed_steps > 0 ? o.fixed_steps : o.max_steps, o.max_steps));
+    h->upload_dropout_masks(o, 1, lim.data());
+    DecoderBufs d = h->decoder_bufs(1, T, h->memory.p, h->pmem.p, o);
     HIP_CHECK(hipEventRecord(h->ev.e[0], h->stream));
     HIP_CHECK(hipEventRecord(h->ev.e[1], h->stream));
     h->last_steps = h->run_decoder(d, lim);
@@ -1411,59 +1483,155 @@ xdtts_status xdtts_tacotron2_decoder(xdtts_tacotron2 *h, const float *memory, co
   });
 }
 
+// Parity hook: n_steps consecutive decoder_iter.onnx calls (mod.rs:304; each call's outputs fed back as mod.rs:328-341 does)
+// for B chunks from caller-held state, through the frame-loop engine the caller names.
+xdtts_status xdtts_tacotron2_decoder_steps(xdtts_tacotron2 *h, int32_t engine, int32_t B, const float *memory, const float *processed_memory,
+                                           int32_t T, const int32_t *n_valid, const xdtts_infer_opts *opts, uint32_t step0, int32_t n_steps,
+                                           const float *decoder_input, float *attention_hidden, float *attention_cell, float *decoder_hidden,
+                                           float *decoder_cell, float *attention_weights, float *attention_weights_cum, float *attention_context,
+                                           float *decoder_output, float *gate_prediction) {
+  return guard([&] {
+    if (!h || !memory || !processed_memory || !n_valid || !decoder_input || !attention_hidden || !attention_cell || !decoder_hidden ||
+        !decoder_cell || !attention_weights || !attention_weights_cum || !attention_context || !decoder_output || !gate_prediction)
+      fail(XDTTS_ERR_BAD_ARG, "null argument");
+    if (engine < 0 || engine > 2) fail(XDTTS_ERR_BAD_ARG, "engine %d out of range (0 launch-per-stage, 1 persistent, 2 batched MFMA)", engine);
+    if (B <= 0 || B > 64) fail(XDTTS_ERR_BAD_ARG, "batch %d out of range (1..64)", B);
+    if (T <= 0 || T > T_MAX) fail(XDTTS_ERR_BAD_ARG, "T %d out of range", T);
+    if (n_steps <= 0 || n_steps > 100000 || (uint64_t)step0 + (uint64_t)n_steps > (1u << 30)) fail(XDTTS_ERR_BAD_ARG, "bad step range");
+    for (int b = 0; b < B; ++b)
+      if (n_valid[b] <= 0 || n_valid[b] > T) fail(XDTTS_ERR_BAD_ARG, "chunk %d: bad n_valid %d", b, n_valid[b]);
+    if (engine == 1 && (B > PERSIST_B_MAX || T > PERSIST_T_MAX))
+      fail(XDTTS_ERR_BAD_ARG, "the persistent engine takes at most %d chunks of at most %d encoder steps", PERSIST_B_MAX, PERSIST_T_MAX);
+    if (engine == 1) {
+      // The persistent engine folds the context columns of its weights into the encoder memory and works from the attention
+      // WEIGHTS (decoder_persistent.hip), so the incoming context must be the one those weights give -- true for every state
+      // the graph itself produced (out_attention_context = out_attention_weights . memory, fed back at mod.rs:332-339).
+      for (int b = 0; b < B; ++b)
+        for (int j = 0; j < EMB; ++j) {
+          double c = 0;
+          for (int t = 0; t < T; ++t) c += (double)attention_weights[(size_t)b * T + t] * memory[((size_t)b * T + t) * EMB + j];
+          if (std::fabs(c - attention_context[(size_t)b * EMB + j]) > 1e-4 + 1e-4 * std::fabs(c))
+            fail(XDTTS_ERR_BAD_ARG, "engine 1 needs attention_context = attention_weights . memory (chunk %d, column %d: %g vs %g)", b, j,
+                 (double)attention_context[(size_t)b * EMB + j], c);
+        }
+    }
+    std::lock_guard<std::mutex> lk(h->mu);
+    HIP_CHECK(hipSetDevice(h->device));
+    xdtts_infer_opts o = resolve_opts(opts);
+    const int end = (int)step0 + n_steps;
+    o.max_steps = end + 1;
+    hipStream_t st = h->stream;
+    h->memory.upload(memory, (size_t)B * T * EMB, st);
+    h->pmem.upload(processed_memory, (size_t)B * T * ATT_DIM, st);
+    h->n_valid.upload(n_valid, B, st);
+    std::vector<int> lim((size_t)B, end);
+    h->upload_dropout_masks(o, B, lim.data());
+    if (engine == 2) h->w.ensure_batched_layout(h->blob, st);
+    DecoderBufs d = h->decoder_bufs(B, T, h->memory.p, h->pmem.p, o, engine == 2 ? 1 : 0);
+    d.use_gate = 0;  // the caller applies the stop rule to gate_prediction (mod.rs:319)
+    h->limits.upload(lim.data(), lim.size(), st);
+    launch_decoder_init(d, h->limits.p, st);
+    h->dec_in_dev.upload(decoder_input, (size_t)B * N_MEL, st);
+    // staging of the seven state tensors in the caller's row-major layout
+    const size_t nh = (size_t)B * ATT_RNN, nt = (size_t)B * T, nc = (size_t)B * EMB;
+    h->state_stage.alloc(4 * nh + 2 * nt + nc);
+    float *s_ah = h->state_stage.p, *s_ac = s_ah + nh, *s_dh = s_ac + nh, *s_dc = s_dh + nh, *s_aw = s_dc + nh, *s_awc = s_aw + nt, *s_ctx = s_awc + nt;
+    auto up = [&](float *dst, const float *src, size_t n) { HIP_CHECK(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyHostToDevice, st)); };
+    auto dd = [&](float *dst, const float *src, size_t n) { HIP_CHECK(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st)); };
+    up(s_ah, attention_hidden, nh);
+    up(s_ac, attention_cell, nh);
+    up(s_dh, decoder_hidden, nh);
+    up(s_dc, decoder_cell, nh);
+    up(s_aw, attention_weights, nt);
+    up(s_awc, attention_weights_cum, nt);
+    up(s_ctx, attention_context, nc);
+    const int s0 = (int)step0;
+    HIP_CHECK(hipMemcpyAsync(d.ctl, &s0, sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_CHECK(hipStreamSynchronize(st));  // the sources above are caller memory / locals
+    dd(d.aw, s_aw, nt);
+    dd(d.awc, s_awc, nt);
+    dd(d.ctx, s_ctx, nc);
+    if (engine == 2) {  // the batched kernels keep h, c and the context in MFMA-operand order
+      launch_frag_convert(s_ah, d.att_hf[0], B, d.Bpad, ATT_RNN, 0, st);
+      launch_frag_convert(s_dh, d.dec_hf[0], B, d.Bpad, DEC_RNN, 0, st);
+      launch_frag_convert(s_ac, d.att_c, B, d.Bpad, ATT_RNN, 0, st);
+      launch_frag_convert(s_dc, d.dec_c, B, d.Bpad, DEC_RNN, 0, st);
+      launch_frag_convert(s_ctx, d.ctxf, B, d.Bpad, EMB, 0, st);
+    } else {
+      dd(d.att_h[0], s_ah, nh);
+      dd(d.att_c, s_ac, nh);
+      dd(d.dec_h[0], s_dh, nh);
+      dd(d.dec_c, s_dc, nh);
+    }
+    d.dec_in = h->dec_in_dev.p;
+    int fin = 0;  // ping-pong half that holds the final hidden states
+    if (engine == 1) {
+      std::lock_guard<std::recursive_mutex> chip(chip_mutex(h->device));
+      launch_decoder_prenet(d, h->w, st);  // x(step0) = prenet(decoder_input): the persistent kernel's own prenet produces x(s + 1)
+      d.dec_in = nullptr;
+      h->dec_exchange.alloc(persist_granule_words(B));
+      PersistBufs g = persist_bufs(h->dec_exchange.p, h->dec_err.p, B);
+      launch_persist_seed_at(d, g, h->limits.p, s0, st);
+      launch_decoder_persistent(d, h->w, g, n_steps, st);
+      int e = 0;
+      HIP_CHECK(hipMemcpyAsync(&e, h->dec_err.p, sizeof(int), hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+      if (e) {
+        HIP_CHECK(hipMemsetAsync(h->dec_err.p, 0, sizeof(int), st));
+        fail(XDTTS_ERR_HIP, "persistent decoder exchange timed out (grid not co-resident)");
+      }
+    } else {
+      std::unique_lock<std::recursive_mutex> chip;
+      if (d.hg) chip = std::unique_lock<std::recursive_mutex>(chip_mutex(h->device));
+      if (engine == 0) launch_decoder_location(d, h->w, st);  // (the batched prenet launch computes them itself)
+      for (int i = 0; i < n_steps; ++i) {
+        launch_decoder_step_at(d, h->w, i, st);
+        d.dec_in = nullptr;  // from the second step on the loop feeds itself
+      }
+      launch_decoder_advance(d, n_steps, st);
+      launch_decoder_flush(d, h->w, st);  // decoder_output and gate_prediction of the last step
+      fin = n_steps & 1;
+      if (d.ep_g) {
+        int e = 0;
+        HIP_CHECK(hipMemcpyAsync(&e, h->dec_err.p, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (e) {
+          HIP_CHECK(hipMemsetAsync(h->dec_err.p, 0, sizeof(int), st));
+          fail(XDTTS_ERR_HIP, "batched attention exchange timed out (grid not co-resident)");
+        }
+      }
+    }
+    if (engine == 2) {
+      launch_frag_convert(s_ah, d.att_hf[fin], B, d.Bpad, ATT_RNN, 1, st);
+      launch_frag_convert(s_dh, d.dec_hf[fin], B, d.Bpad, DEC_RNN, 1, st);
+      launch_frag_convert(s_ac, d.att_c, B, d.Bpad, ATT_RNN, 1, st);
+      launch_frag_convert(s_dc, d.dec_c, B, d.Bpad, DEC_RNN, 1, st);
+    }
+    auto down = [&](float *dst, const float *src, size_t n) { HIP_CHECK(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToHost, st)); };
+    down(attention_hidden, engine == 2 ? s_ah : d.att_h[fin], nh);
+    down(attention_cell, engine == 2 ? s_ac : d.att_c, nh);
+    down(decoder_hidden, engine == 2 ? s_dh : d.dec_h[fin], nh);
+    down(decoder_cell, engine == 2 ? s_dc : d.dec_c, nh);
+    down(attention_weights, d.aw, nt);
+    down(attention_weights_cum, engine == 2 && (n_steps & 1) ? d.awc2 : d.awc, nt);  // (batched: ping-pong by step parity)
+    down(attention_context, d.ctx, nc);
+    for (int b = 0; b < B; ++b) {
+      down(decoder_output + (size_t)b * n_steps * N_MEL, d.frames + ((size_t)b * d.max_steps + step0) * N_MEL, (size_t)n_steps * N_MEL);
+      down(gate_prediction + (size_t)b * n_steps, d.gates + (size_t)b * d.max_steps + step0, (size_t)n_steps);
+    }
+    HIP_CHECK(hipStreamSynchronize(st));
+  });
+}
+
 // Parity hook: ONE decoder_iter.onnx call (mod.rs:304) from caller-held state, on the launch-per-stage kernels.
 xdtts_status xdtts_tacotron2_decoder_step(xdtts_tacotron2 *h, const float *memory, const float *processed_memory, int32_t T,
                                           int32_t n_valid, const xdtts_infer_opts *opts, uint32_t step, const float *decoder_input,
                                           float *attention_hidden, float *attention_cell, float *decoder_hidden, float *decoder_cell,
                                           float *attention_weights, float *attention_weights_cum, float *attention_context,
                                           float *decoder_output, float *gate_prediction) {
-  return guard([&] {
-    if (!h || !memory || !processed_memory || !decoder_input || !attention_hidden || !attention_cell || !decoder_hidden || !decoder_cell ||
-        !attention_weights || !attention_weights_cum || !attention_context || !decoder_output || !gate_prediction)
-      fail(XDTTS_ERR_BAD_ARG, "null argument");
-    if (T <= 0 || T > T_MAX || n_valid <= 0 || n_valid > T) fail(XDTTS_ERR_BAD_ARG, "bad T/n_valid");
-    std::lock_guard<std::mutex> lk(h->mu);
-    HIP_CHECK(hipSetDevice(h->device));
-    xdtts_infer_opts o = resolve_opts(opts);
-    if (o.max_steps <= 0 || (uint64_t)step + 2 > (uint64_t)o.max_steps) o.max_steps = (int32_t)std::min<uint64_t>((uint64_t)step + 2, 1u << 30);
-    hipStream_t st = h->stream;
-    h->memory.upload(memory, (size_t)T * EMB, st);
-    h->pmem.upload(processed_memory, (size_t)T * ATT_DIM, st);
-    int nv = n_valid;
-    h->n_valid.upload(&nv, 1, st);
-    DecoderBufs d = h->decoder_bufs(1, T, h->memory.p, h->pmem.p, o);
-    d.use_gate = 0;  // the caller applies the stop rule to gate_prediction (mod.rs:319)
-    const int lim = (int)step + 2;
-    h->limits.upload(&lim, 1, st);
-    launch_decoder_init(d, h->limits.p, st);
-    h->dec_in_dev.upload(decoder_input, N_MEL, st);
-    d.dec_in = h->dec_in_dev.p;
-    auto up = [&](float *dst, const float *src, size_t n) { HIP_CHECK(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyHostToDevice, st)); };
-    up(d.att_h[0], attention_hidden, ATT_RNN);
-    up(d.att_c, attention_cell, ATT_RNN);
-    up(d.dec_h[0], decoder_hidden, DEC_RNN);
-    up(d.dec_c, decoder_cell, DEC_RNN);
-    up(d.aw, attention_weights, (size_t)T);
-    up(d.awc, attention_weights_cum, (size_t)T);
-    up(d.ctx, attention_context, EMB);
-    const int s0 = (int)step;
-    HIP_CHECK(hipMemcpyAsync(d.ctl, &s0, sizeof(int), hipMemcpyHostToDevice, st));
-    HIP_CHECK(hipStreamSynchronize(st));  // the sources above are caller memory / locals
-    launch_decoder_single_step(d, h->w, st);
-    d.dec_in = nullptr;
-    launch_decoder_flush(d, h->w, st);  // decoder_output and gate_prediction of this step
-    auto down = [&](float *dst, const float *src, size_t n) { HIP_CHECK(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToHost, st)); };
-    down(attention_hidden, d.att_h[1], ATT_RNN);
-    down(attention_cell, d.att_c, ATT_RNN);
-    down(decoder_hidden, d.dec_h[1], DEC_RNN);
-    down(decoder_cell, d.dec_c, DEC_RNN);
-    down(attention_weights, d.aw, (size_t)T);
-    down(attention_weights_cum, d.awc, (size_t)T);
-    down(attention_context, d.ctx, EMB);
-    down(decoder_output, d.frames + (size_t)step * N_MEL, N_MEL);
-    down(gate_prediction, d.gates + step, 1);
-    HIP_CHECK(hipStreamSynchronize(st));
-  });
+  return xdtts_tacotron2_decoder_steps(h, 0, 1, memory, processed_memory, T, &n_valid, opts, step, 1, decoder_input, attention_hidden,
+                                       attention_cell, decoder_hidden, decoder_cell, attention_weights, attention_weights_cum,
+                                       attention_context, decoder_output, gate_prediction);
 }
 
 // Which engines this handle currently uses (1 = the persistent / cooperative one, 0 = demoted to the
@@ -1472,6 +1640,7 @@ xdtts_status xdtts_tacotron2_engine_state(const xdtts_tacotron2 *h, int32_t *dec
                                           int32_t *batched_attention) {
   return guard([&] {
     if (!h) fail(XDTTS_ERR_BAD_ARG, "null handle");
+    std::lock_guard<std::mutex> lk(h->mu);
     if (decoder_persistent) *decoder_persistent = h->persist_state;
     if (encoder_cooperative) *encoder_cooperative = h->coop_ok ? 1 : 0;
     if (batched_attention) *batched_attention = h->att_fused;
@@ -1614,6 +1783,7 @@ xdtts_status xdtts_griffinlim_set_opts(xdtts_griffinlim *g, const xdtts_griffinl
 xdtts_status xdtts_griffinlim_get_opts(const xdtts_griffinlim *g, xdtts_griffinlim_opts *o) {
   return guard([&] {
     if (!g || !o) fail(XDTTS_ERR_BAD_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(g->mu);
     *o = g->gopts;
   });
 }
@@ -1621,6 +1791,7 @@ xdtts_status xdtts_griffinlim_get_opts(const xdtts_griffinlim *g, xdtts_griffinl
 xdtts_status xdtts_griffinlim_set_seed(xdtts_griffinlim *g, uint32_t seed) {
   return guard([&] {
     if (!g) fail(XDTTS_ERR_BAD_ARG, "null handle");
+    std::lock_guard<std::mutex> lk(g->mu);
     g->seed = seed;
   });
 }
@@ -1633,6 +1804,7 @@ static void gl_iterate_and_fetch(xdtts_griffinlim *g, const GlBufs &b, const flo
                                  size_t *n_samples) {
   const size_t N = (size_t)g->hop * (size_t)(b.F - 1);
   std::lock_guard<std::recursive_mutex> chip(chip_mutex(g->device));
+  g->probe_tick();
   for (int attempt = 0; attempt < 2; ++attempt) {
     g->iterate(b, phase0_dev, iters);
     if (g->gopts.peak_normalise) launch_gl_peak_normalise(g->audio.p, (int)N, g->peak.p, g->stream);
@@ -1704,6 +1876,7 @@ static void gl_batch_from_device(xdtts_griffinlim *g, const float *mel_dev_all, 
     HIP_CHECK(hipStreamSynchronize(st));  // the host vector above
     const float alpha = g->momentum / (1.0f + g->momentum);
     std::lock_guard<std::recursive_mutex> chip(chip_mutex(g->device));
+    g->probe_tick();
     for (int attempt = 0;; ++attempt) {
       HIP_CHECK(hipEventRecord(g->ev.e[0], st));
       g->mel_to_linear(mel_dev_all, (int)Ftot);
@@ -1961,6 +2134,7 @@ xdtts_status xdtts_griffinlim_step(xdtts_griffinlim *g, const float *S, float *a
     launch_gl_prepare(b, g->stream);
     const float alpha = g->momentum / (1.0f + g->momentum);
     std::lock_guard<std::recursive_mutex> chip(chip_mutex(g->device));
+    g->probe_tick();
     for (int attempt = 0;; ++attempt) {
       const float2 *tp = nullptr;
       const float2 *fin = g->run_iterations(b, (int)n_iter, alpha, nullptr, true, &tp);
@@ -2089,7 +2263,16 @@ xdtts_status xdtts_synthesize_batch(xdtts_tacotron2 *h, xdtts_griffinlim *g, con
       }
     }
     gl_batch_from_device(g, h->mel_dev.p, Fu, audios, n_samples);
-    h->finish_timings();  // (stream sync: the mel copies have landed)
+    try {
+      h->finish_timings();  // (stream sync: the mel copies have landed)
+    } catch (...) {  // the caller gets either every buffer of the call or none
+      for (int u = 0; u < n_utt; ++u) {
+        if (audios[u]) pinned_pool().put(audios[u]);
+        audios[u] = nullptr;
+        n_samples[u] = 0;
+      }
+      throw;
+    }
     for (int u = 0; u < n_utt; ++u) {
       n_frames[u] = (size_t)Fu[u];
       if (mels) mels[u] = mel_out[(size_t)u].release();

@@ -79,6 +79,20 @@ inline hipError_t launch_coresident(bool coop_default, const void *fn, dim3 grid
   return coop ? hipLaunchCooperativeKernel(fn, grid, block, argv, (unsigned)lds, s) : hipLaunchKernel(fn, grid, block, argv, lds, s);
 }
 
+// A cooperative launch the runtime refused (hipErrorCooperativeLaunchTooLarge: CU masking, fewer CUs than the grid needs, a
+// register budget that no longer admits one block per CU): not an error of the request -- the caller switches the handle
+// to its launch-per-stage / single-workgroup engine and runs the request there.
+struct CoopRefused {};
+#define COOP_CHECK(expr)                                      \
+  do {                                                        \
+    const hipError_t ce_ = (expr);                            \
+    if (ce_ == hipErrorCooperativeLaunchTooLarge) {           \
+      (void)hipGetLastError(); /* clear the sticky error */   \
+      throw ::xdtts::CoopRefused();                           \
+    }                                                         \
+    HIP_CHECK(ce_);                                           \
+  } while (0)
+
 // ---- counter-based RNG (specification shared with oracle/, implemented independently) ----
 __host__ __device__ inline uint32_t mix32(uint32_t x) {
   x ^= x >> 16;

@@ -211,7 +211,8 @@ __global__ __launch_bounds__(256) void k_prenet(DecoderBufs d, int i, int flush,
   const float bias = tid < N_MEL + 1 ? proj_b[tid] : 0.f;
   const int step = d.ctl[0] + i;
   const int nf = d.nframes[b];
-  const uint32_t item = d.item_base + (uint32_t)(d.item_perm ? d.item_perm[b] : b);
+  const int chunk = d.item_perm ? d.item_perm[b] : b;
+  const uint32_t item = d.item_base + (uint32_t)chunk;
   if (m4 < MEL_LD / 4) *reinterpret_cast<float4 *>(&s_red[part][4 * m4]) = racc;
   __syncthreads();
   const bool forced = d.dec_in != nullptr && !flush;  // parity hook: the caller supplies decoder_input
@@ -250,8 +251,7 @@ __global__ __launch_bounds__(256) void k_prenet(DecoderBufs d, int i, int flush,
   __syncthreads();
   {
     float v = fmaxf((s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid]), 0.f);
-    if (d.dropout_mode)
-      v = (rng_u32(d.dropout_seed, 0x1000u + 2u * item, (uint32_t)step * 256u + (uint32_t)tid) >> 31) ? 0.f : 2.f * v;
+    if (d.dropout_mode) v = prenet_dropped(d.dropout_mode, d.dropout_seed, item, d.drop_masks, d.drop_steps, chunk, step, 0, tid) ? 0.f : 2.f * v;
     s_x1[tid] = v;
   }
   __syncthreads();
@@ -277,8 +277,7 @@ __global__ __launch_bounds__(256) void k_prenet(DecoderBufs d, int i, int flush,
   if (tid < PRENET_COLS) {
     float o = fmaxf((s_out[0][tid] + s_out[1][tid]) + (s_out[2][tid] + s_out[3][tid]), 0.f);
     const int j = col0 + tid;
-    if (d.dropout_mode)
-      o = (rng_u32(d.dropout_seed, 0x1001u + 2u * item, (uint32_t)step * 256u + (uint32_t)j) >> 31) ? 0.f : 2.f * o;
+    if (d.dropout_mode) o = prenet_dropped(d.dropout_mode, d.dropout_seed, item, d.drop_masks, d.drop_steps, chunk, step, 1, j) ? 0.f : 2.f * o;
     d.x[b * PRENET + j] = o;
     if (d.xf) d.xf[((size_t)(j >> 2) * d.Bpad + b) * 4 + (j & 3)] = o;
   }
@@ -495,7 +494,8 @@ __global__ __launch_bounds__(PRENET_BT) void k_prenet_b(DecoderBufs d, int i, in
   asm volatile("" : "+v"(bias_raw), "+v"(step_v), "+v"(nf_v), "+v"(perm_v) : : "memory");
   const int step = step_v + i;
   const int nf = nf_v;
-  const uint32_t item = d.item_base + (uint32_t)(d.item_perm ? perm_v : b);
+  const int chunk = d.item_perm ? perm_v : b;
+  const uint32_t item = d.item_base + (uint32_t)chunk;
   PPROBE(1);
   // ---- projection of the previous step: sum of the 264 partial rows in a fixed order ----
   {
@@ -512,7 +512,8 @@ __global__ __launch_bounds__(PRENET_BT) void k_prenet_b(DecoderBufs d, int i, in
   }
   __syncthreads();
   PPROBE(2);
-  const bool have_prev = step >= 1 && step - 1 < nf;  // the chunk was active at the previous step
+  const bool forced = d.dec_in != nullptr && !flush;  // parity hook: the caller supplies decoder_input
+  const bool have_prev = !forced && step >= 1 && step - 1 < nf;  // the chunk was active at the previous step
   if (tid < MEL_LD) {
     float v = 0.f;
     if (have_prev && tid < N_MEL + 1) {
@@ -520,6 +521,7 @@ __global__ __launch_bounds__(PRENET_BT) void k_prenet_b(DecoderBufs d, int i, in
 #pragma unroll
       for (int k = 0; k < NPART; ++k) v += s_red[k][tid];
     }
+    if (forced && tid < N_MEL) v = d.dec_in[b * N_MEL + tid];
     s_mel[tid] = v;  // step 0: decoder_input = 0 (mod.rs:208)
   }
   __syncthreads();
@@ -553,8 +555,7 @@ __global__ __launch_bounds__(PRENET_BT) void k_prenet_b(DecoderBufs d, int i, in
 #pragma unroll
     for (int k = 0; k < KG1; ++k) v += s_p1[k][tid];
     v = fmaxf(v, 0.f);
-    if (d.dropout_mode)
-      v = (rng_u32(d.dropout_seed, 0x1000u + 2u * item, (uint32_t)step * 256u + (uint32_t)tid) >> 31) ? 0.f : 2.f * v;
+    if (d.dropout_mode) v = prenet_dropped(d.dropout_mode, d.dropout_seed, item, d.drop_masks, d.drop_steps, chunk, step, 0, tid) ? 0.f : 2.f * v;
     s_x1[tid] = v;
   }
   __syncthreads();
@@ -579,8 +580,7 @@ __global__ __launch_bounds__(PRENET_BT) void k_prenet_b(DecoderBufs d, int i, in
     for (int k = 0; k < KG2; ++k) o += s_p2[k][tid];
     o = fmaxf(o, 0.f);
     const int j = HALF * half + tid;
-    if (d.dropout_mode)
-      o = (rng_u32(d.dropout_seed, 0x1001u + 2u * item, (uint32_t)step * 256u + (uint32_t)j) >> 31) ? 0.f : 2.f * o;
+    if (d.dropout_mode) o = prenet_dropped(d.dropout_mode, d.dropout_seed, item, d.drop_masks, d.drop_steps, chunk, step, 1, j) ? 0.f : 2.f * o;
     d.x[b * PRENET + j] = o;
     d.xf[((size_t)(j >> 2) * d.Bpad + b) * 4 + (j & 3)] = o;
   }
@@ -1467,8 +1467,23 @@ void launch_decoder_init(const DecoderBufs &d, const int *limits_dev, hipStream_
 // Steps are enqueued in (even, odd) pairs: node i uses ping-pong parity i & 1, so a sequence must
 // start on an even step and nsteps must be even.  The absolute step of node i is ctl[0] + i;
 // k_advance moves ctl[0] on by nsteps at the end, so the same captured graph replays anywhere.
+static void enqueue_steps(const DecoderBufs &d, const DeviceWeights &w, int i0, int nsteps, hipStream_t s);
 void launch_decoder_steps(const DecoderBufs &d, const DeviceWeights &w, int nsteps, hipStream_t s) {
   if (nsteps % 2 != 0) fail(XDTTS_ERR_BAD_ARG, "decoder steps are enqueued in even/odd pairs");
+  enqueue_steps(d, w, 0, nsteps, s);
+  hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, s, d, nsteps);
+  HIP_CHECK(hipGetLastError());
+}
+// Parity hook (xdtts_tacotron2_decoder_steps): node i alone, no advance of the step base
+void launch_decoder_step_at(const DecoderBufs &d, const DeviceWeights &w, int i, hipStream_t s) {
+  enqueue_steps(d, w, i, 1, s);
+  HIP_CHECK(hipGetLastError());
+}
+void launch_decoder_advance(const DecoderBufs &d, int n, hipStream_t s) {
+  hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, s, d, n);
+  HIP_CHECK(hipGetLastError());
+}
+static void enqueue_steps(const DecoderBufs &d, const DeviceWeights &w, int i0, int nsteps, hipStream_t s) {
   const int loc_tiles = (d.T + LOC_TT - 1) / LOC_TT;
   const float4 *att_w = reinterpret_cast<const float4 *>(w.att_w.p);
   const float4 *dec_w = reinterpret_cast<const float4 *>(w.dec_w.p);
@@ -1480,7 +1495,7 @@ void launch_decoder_steps(const DecoderBufs &d, const DeviceWeights &w, int nste
   const bool batched = d.B >= BATCH_MFMA_MIN && w.att_wm.p && w.dec_wm.p && d.xf;  // LSTMs as MFMA GEMMs
   const float4 *att_wm = reinterpret_cast<const float4 *>(w.att_wm.p), *dec_wm = reinterpret_cast<const float4 *>(w.dec_wm.p);
   const bool fuse_aq = batched && d.ep_g && d.hg && d.B <= 64;
-  for (int i = 0; i < nsteps; ++i) {
+  for (int i = i0; i < i0 + nsteps; ++i) {
     const int cur = i & 1;
     for (char k : order) {
       switch (k) {
@@ -1528,8 +1543,6 @@ void launch_decoder_steps(const DecoderBufs &d, const DeviceWeights &w, int nste
       }
     }
   }
-  hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, s, d, nsteps);
-  HIP_CHECK(hipGetLastError());
 }
 
 __global__ __launch_bounds__(256) void k_location_all(DecoderBufs d, const float *__restrict__ loc_convT, const float *__restrict__ loc_denseT) {
@@ -1537,19 +1550,33 @@ __global__ __launch_bounds__(256) void k_location_all(DecoderBufs d, const float
   location_role(d, blockIdx.x / tiles, blockIdx.x % tiles, loc_convT, loc_denseT);
 }
 
-void launch_decoder_single_step(const DecoderBufs &d, const DeviceWeights &w, hipStream_t s) {
-  if (d.xf) fail(XDTTS_ERR_BAD_ARG, "single-step hook runs the small-batch kernels");
+// Parity hook, launch-per-stage engine: the location features of the CURRENT attention weights (row-major layout)
+void launch_decoder_location(const DecoderBufs &d, const DeviceWeights &w, hipStream_t s) {
   const int loc_tiles = (d.T + LOC_TT - 1) / LOC_TT;
-  const float4 *q4 = reinterpret_cast<const float4 *>(w.q_w4.p), *wh4 = reinterpret_cast<const float4 *>(w.proj_wh4.p);
   hipLaunchKernelGGL(k_location_all, dim3(loc_tiles * d.B), dim3(256), 0, s, d, w.loc_conv.p, w.loc_denseT.p);
+  HIP_CHECK(hipGetLastError());
+}
+
+// Parity hook, persistent engine: x(step) = prenet(decoder_input) by the launch-per-stage prenet kernel (node 0)
+void launch_decoder_prenet(const DecoderBufs &d, const DeviceWeights &w, hipStream_t s) {
   hipLaunchKernelGGL(k_prenet, dim3(PRENET_BLOCKS * d.B), dim3(256), 0, s, d, 0, 0, w.pre0T.p, w.pre1T.p, w.proj_b.p);
-  hipLaunchKernelGGL((k_lstm<ATT_COLS, 0>), dim3(NBLK), dim3(256), 0, s, d, 0, 0, reinterpret_cast<const float4 *>(w.att_w.p), w.att_b.p, q4,
-                     w.loc_conv.p, w.loc_denseT.p);
-  hipLaunchKernelGGL(k_qenergy, dim3(ATT_DIM / 4, 1), dim3(256), 0, s, d, 0, 0, reinterpret_cast<const float4 *>(w.q_w.p), w.v_w.p);
-  hipLaunchKernelGGL(k_softmax_ctx, dim3(CTX_BLOCKS * d.B), dim3(256), 0, s, d, 0, w.proj_wc.p);
-  hipLaunchKernelGGL((k_lstm<DEC_COLS, 1>), dim3(loc_tiles * d.B + NBLK), dim3(256), 0, s, d, 0, 0, reinterpret_cast<const float4 *>(w.dec_w.p),
-                     w.dec_b.p, wh4, w.loc_conv.p, w.loc_denseT.p);
-  hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, s, d, 1);
+  HIP_CHECK(hipGetLastError());
+}
+
+// Parity hook, batched engine: row-major [B][n] vectors <-> the MFMA-operand order [n/4][Bpad][4] the batched kernels keep
+// their hidden states, cell states and context in (dir 0: import, 1: export)
+namespace {
+__global__ void k_frag_convert(float *rowmajor, float *frag, int B, int Bpad, int n, int dir) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * n) return;
+  const int b = i / n, j = i % n;
+  const size_t f = ((size_t)(j >> 2) * Bpad + b) * 4 + (j & 3);
+  if (dir) rowmajor[i] = frag[f];
+  else frag[f] = rowmajor[i];
+}
+}  // namespace
+void launch_frag_convert(float *rowmajor, float *frag, int B, int Bpad, int n, int dir, hipStream_t s) {
+  hipLaunchKernelGGL(k_frag_convert, dim3((unsigned)((B * n + 255) / 256)), dim3(256), 0, s, rowmajor, frag, B, Bpad, n, dir);
   HIP_CHECK(hipGetLastError());
 }
 

@@ -680,13 +680,13 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
         for (int k = 0; k < 4; ++k) w1r[r][k] = w.pre1T[(unsigned)((lane + 64 * k) * PRENET + 16 * rk + wave + NW * r)];
       // the Bernoulli(0.5) masks of step s+1 do not depend on the data: hash them while the mel is in flight
       unsigned drop1 = 0u, drop2 = 0u;
-      if (d.dropout_mode) {
+      if (d.dropout_mode) {  // (mode 2: the caller's keep bytes of chunk rb -- views of a batch advance d.drop_masks)
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-          drop1 |= (rng_u32(d.dropout_seed, 0x1000u + 2u * item, (uint32_t)(s + 1) * 256u + (uint32_t)(lane + 64 * k)) >> 31) << k;
+          drop1 |= (prenet_dropped(d.dropout_mode, d.dropout_seed, item, d.drop_masks, d.drop_steps, rb, s + 1, 0, lane + 64 * k) ? 1u : 0u) << k;
 #pragma unroll
         for (int r = 0; r < 2; ++r)
-          drop2 |= (rng_u32(d.dropout_seed, 0x1001u + 2u * item, (uint32_t)(s + 1) * 256u + (uint32_t)(16 * rk + wave + NW * r)) >> 31) << r;
+          drop2 |= (prenet_dropped(d.dropout_mode, d.dropout_seed, item, d.drop_masks, d.drop_steps, rb, s + 1, 1, 16 * rk + wave + NW * r) ? 1u : 0u) << r;
       }
       if (act_r) {
         if (tid < N_MEL + 1) {
@@ -801,9 +801,15 @@ __global__ void k_persist_seed(PersistBufs g, const int *limits, int B) {
   publish(g.x + (size_t)b * PRENET + i, 1u | (limits[b] > 0 ? ACT_BIT : 0u), 0.f);
 }
 
+// parity hook: x(step) from a caller-held state, computed by the launch-per-stage prenet kernel into x [B][256]
+__global__ void k_persist_seed_at(PersistBufs g, const int *limits, const float *x, int step) {
+  const int b = blockIdx.x, i = threadIdx.x;
+  publish(g.x + (size_t)(((step & 1) * GS + b) * PRENET + i), (unsigned)(step + 1) | (limits[b] > step ? ACT_BIT : 0u), x[b * PRENET + i]);
+}
+
 template <int PB>
 void launch_pb(const DecoderBufs &d, const PersistBufs &g, const PersistWeights &pw, int nsteps, hipStream_t s) {
-  HIP_CHECK(launch_coresident(true, reinterpret_cast<const void *>(k_decoder_persistent<PB>), dim3(P_NCU), dim3(PT), 0, s, d, g, pw, nsteps));
+  COOP_CHECK(launch_coresident(true, reinterpret_cast<const void *>(k_decoder_persistent<PB>), dim3(P_NCU), dim3(PT), 0, s, d, g, pw, nsteps));
 }
 
 }  // namespace
@@ -856,6 +862,12 @@ bool decoder_persistent_supported(int device, int B, int T) {
 void launch_persist_seed(const DecoderBufs &d, const PersistBufs &g, const int *limits_dev, hipStream_t s) {
   HIP_CHECK(hipMemsetAsync(g.x, 0, persist_granule_words(d.B) * sizeof(unsigned long long), s));
   hipLaunchKernelGGL(k_persist_seed, dim3(d.B), dim3(PRENET), 0, s, g, limits_dev, d.B);
+  HIP_CHECK(hipGetLastError());
+}
+
+void launch_persist_seed_at(const DecoderBufs &d, const PersistBufs &g, const int *limits_dev, int step, hipStream_t s) {
+  HIP_CHECK(hipMemsetAsync(g.x, 0, persist_granule_words(d.B) * sizeof(unsigned long long), s));
+  hipLaunchKernelGGL(k_persist_seed_at, dim3(d.B), dim3(PRENET), 0, s, g, limits_dev, d.x, step);
   HIP_CHECK(hipGetLastError());
 }
 

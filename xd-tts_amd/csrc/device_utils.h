@@ -47,6 +47,18 @@ __device__ __forceinline__ float4 ld_stream(const float4 *p) {
   const f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(p));
   return make_float4(v.x, v.y, v.z, v.w);
 }
+// Prenet dropout (D1; the exported decoder graph keeps it on at inference): is unit j of `layer` dropped at this step?
+//   mode 1: the seeded counter stream, keyed (seed, dropout-stream index of the chunk, step, layer, unit)
+//   mode 2: the caller's keep bytes [chunk][drop_steps][2][256] (chunk = index of the chunk within the call)
+__device__ __forceinline__ bool prenet_dropped(int mode, uint32_t seed, uint32_t item, const unsigned char *masks, int drop_steps, int chunk,
+                                               int step, int layer, int j) {
+  if (mode == 2) {
+    const int st = step < drop_steps ? step : drop_steps - 1;  // (speculative reads past a chunk's last step stay in bounds)
+    return masks[(((size_t)chunk * drop_steps + st) * 2 + layer) * PRENET + j] == 0;
+  }
+  return (rng_u32(seed, 0x1000u + (uint32_t)layer + 2u * item, (uint32_t)step * 256u + (uint32_t)j) >> 31) != 0;
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 // src/tacotron2/mod.rs:126-133: the two-branch sigmoid applied to the gate logit on the host
 __device__ __forceinline__ float gate_sigmoid(float x) {

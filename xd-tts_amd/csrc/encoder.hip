@@ -35,7 +35,8 @@ template <int NC>
 __global__ __launch_bounds__(1024) void k_bilstm_coop(const float *__restrict__ xproj,
                                                       const float *__restrict__ whhT_f,
                                                       const float *__restrict__ whhT_b, float *memory, u64 *exchange,
-                                                      int *err, int B, int T, int b0, int Btot) {
+                                                      int *err, int B, int T, int b0, int Btot, unsigned spin_limit, int fault) {
+  // (spin_limit / fault: test hooks -- poll limit, and a block (linear index + 1) that never publishes)
   // this launch runs chunks b0 .. b0+B-1 of a batch of Btot (xproj is [2][Btot][T][4H], memory [Btot][T][EMB])
   const int k = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x;
   const int bz = NC * blockIdx.z;             // first chunk of this group (within the launch)
@@ -97,7 +98,8 @@ __global__ __launch_bounds__(1024) void k_bilstm_coop(const float *__restrict__ 
         const int u = CO_UNITS * k + uu;
         h[j][u] = hn;
         memory[((size_t)(b0 + bz + j) * T + t) * EMB + dir * ENC_H + u] = hn;
-        if (s + 1 < T)  // publish: tag = step + 1 (never 0), one naturally aligned 8-byte store
+        const bool lost = fault && (int)(blockIdx.x + CO_BLOCKS * (blockIdx.y + 2 * blockIdx.z)) == fault - 1;
+        if (s + 1 < T && !lost)  // publish: tag = step + 1 (never 0), one naturally aligned 8-byte store
           __hip_atomic_store(ex[j] + (s & 1) * ENC_H + u, ((u64)(unsigned)(s + 1) << 32) | (u64)__float_as_uint(hn),
                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(1024) void k_bilstm_coop(const float *__restrict__ 
         while (!skip) {
           v = __hip_atomic_load(ex[j] + (s & 1) * ENC_H + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if ((unsigned)(v >> 32) == (unsigned)(s + 1)) break;
-          if (++spins > SPIN_LIMIT) {
+          if (++spins > spin_limit) {
             dead = 1;
             atomicExch(err, 1);
             break;
@@ -132,6 +134,10 @@ size_t bilstm_coop_exchange_words(int B) { return (size_t)2 * B * 2 * ENC_H; }
 
 void launch_bilstm_coop(const float *xproj, const float *whhT_fwd, const float *whhT_bwd, float *memory,
                         unsigned long long *exchange, int *err, int B, int T, int group, hipStream_t s) {
+  unsigned spins = SPIN_LIMIT;
+  int fault = 0;
+  if (const char *e = getenv("XDTTS_ENC_SPINS")) spins = (unsigned)atoi(e);  // test hooks for the lost-workgroup path
+  if (const char *e = getenv("XDTTS_ENC_FAULT")) fault = atoi(e);
   // 8 workgroups per group of chunks must be co-resident, so a large batch runs as launches of at most `group` groups each
   // (sized to the CU count by the caller); a batch of more than `group` chunks puts two chunks on a group.  The exchange
   // buffer (bilstm_coop_exchange_words(2 * group) then) is reused between launches.
@@ -141,8 +147,8 @@ void launch_bilstm_coop(const float *xproj, const float *whhT_fwd, const float *
     // tags must start at 0 for every launch
     HIP_CHECK(hipMemsetAsync(exchange, 0, bilstm_coop_exchange_words(n) * sizeof(unsigned long long), s));
     const void *fn = nc == 2 ? reinterpret_cast<const void *>(k_bilstm_coop<2>) : reinterpret_cast<const void *>(k_bilstm_coop<1>);
-    HIP_CHECK(launch_coresident(true, fn, dim3(CO_BLOCKS, 2, (n + nc - 1) / nc), dim3(1024), 0, s, xproj, whhT_fwd, whhT_bwd, memory, exchange,
-                                err, n, T, b0, B));
+    COOP_CHECK(launch_coresident(true, fn, dim3(CO_BLOCKS, 2, (n + nc - 1) / nc), dim3(1024), 0, s, xproj, whhT_fwd, whhT_bwd, memory, exchange,
+                                 err, n, T, b0, B, spins, fault));
   }
 }
 

@@ -32,6 +32,10 @@ struct DecoderBufs {
   float gate_threshold;
   int dropout_mode;
   uint32_t dropout_seed, item_base;
+  // dropout_mode 2: the caller's keep bytes [chunk][drop_steps][2][256] on the device (chunk = index within the call:
+  // item_perm[b] in a sorted batch, b otherwise; views of a batch advance the pointer)
+  const unsigned char *drop_masks;
+  int drop_steps;
   // Batched mode only (B >= BATCH_MFMA_MIN; null otherwise).  A second copy of the vectors the two
   // LSTM GEMMs consume, in MFMA B-operand order [K/4][Bpad][4] (Bpad = B rounded up to 16, padding
   // zero): lane (chunk, k-quad) of a 16-chunk tile loads one 16-byte vector and the 64 lanes of a wave
@@ -60,9 +64,14 @@ void launch_dimgroup_transpose(const float *in, float *out, int B, int T, hipStr
 
 // Enqueues `nsteps` decoder steps on `s` (5 kernels each) and advances the device step base.
 void launch_decoder_steps(const DecoderBufs &d, const DeviceWeights &w, int nsteps, hipStream_t s);
-// Parity hook: ONE step (i = 0, state read from the [0] halves, written to [1]) and the location features
-// of the CURRENT attention weights (a sequence normally gets them from its previous step).
-void launch_decoder_single_step(const DecoderBufs &d, const DeviceWeights &w, hipStream_t s);
+// Parity hook (xdtts_tacotron2_decoder_steps): node i of a sequence alone (state parity i & 1; absolute step ctl[0] + i),
+// the advance of the step base, the location features of the current attention weights (launch-per-stage engine; the
+// batched engine computes them inside its prenet launch), and the batched engine's state layout conversion.
+void launch_decoder_step_at(const DecoderBufs &d, const DeviceWeights &w, int i, hipStream_t s);
+void launch_decoder_advance(const DecoderBufs &d, int n, hipStream_t s);
+void launch_decoder_location(const DecoderBufs &d, const DeviceWeights &w, hipStream_t s);
+void launch_decoder_prenet(const DecoderBufs &d, const DeviceWeights &w, hipStream_t s);
+void launch_frag_convert(float *rowmajor, float *frag, int B, int Bpad, int n, int dir, hipStream_t s);
 // After the last step of a sequence: completes the final frame's projection (frames, gate).
 void launch_decoder_flush(const DecoderBufs &d, const DeviceWeights &w, hipStream_t s);
 size_t decoder_pmel_floats(int B);
@@ -90,6 +99,8 @@ PersistBufs persist_view(const PersistBufs &g, int b0);
 bool decoder_persistent_supported(int device, int B, int T);
 // After launch_decoder_init: clears the exchange and publishes x(0) with the chunks' active bits.
 void launch_persist_seed(const DecoderBufs &d, const PersistBufs &g, const int *limits_dev, hipStream_t s);
+// Parity hook: the same for a sequence that starts at `step` with the prenet output x [B][256] already computed (d.x)
+void launch_persist_seed_at(const DecoderBufs &d, const PersistBufs &g, const int *limits_dev, int step, hipStream_t s);
 // Runs up to `nsteps` decoder steps in one launch (ends early when every chunk has stopped);
 // frames/gates/nframes are complete on return, ctl[0] = steps executed.  No flush needed.
 void launch_decoder_persistent(const DecoderBufs &d, const DeviceWeights &w, const PersistBufs &g, int nsteps,

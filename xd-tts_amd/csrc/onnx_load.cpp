@@ -151,8 +151,14 @@ TensorP parse_tensor(Span s, const std::string &path, std::string *name) {
     }
   }
   if (dtype != 1) return nullptr;
-  for (long d : t->dims)
-    if (d < 0 || d > (1L << 28)) bad(path, "tensor with an invalid dimension");
+  {
+    size_t prod = 1;  // the dims come from an untrusted file: bound the product before it can wrap
+    for (long d : t->dims) {
+      if (d < 0 || d > (1L << 28)) bad(path, "tensor with an invalid dimension");
+      if (d != 0 && prod > ((size_t)1 << 31) / (size_t)d) bad(path, "tensor with more than 2^31 elements");
+      prod *= (size_t)d;
+    }
+  }
   const size_t n = t->numel();
   if (has_raw) {
     if (raw.n != n * 4) bad(path, "tensor raw_data size does not match its shape");
@@ -177,6 +183,7 @@ struct Graph {
   Bytes file;
   std::vector<Node> nodes;
   std::map<std::string, TensorP> tensors;
+  std::vector<std::string> inputs, outputs;  // GraphProto.input / .output names (initialisers listed as inputs by old exporters removed)
 
   explicit Graph(const std::string &p) : path(p) {
     std::ifstream f(p, std::ios::binary);
@@ -188,6 +195,7 @@ struct Graph {
            file.size());
     Span model{file.data(), file.size()}, graph;
     Field fd;
+    std::vector<std::string> init_names;
     for (Reader r(model, path); r.next(fd);)
       if (fd.num == 7 && fd.wire == 2) graph = fd.s;  // ModelProto.graph
     if (!graph.p) bad(path, "no GraphProto in the file (not an ONNX model?)");
@@ -198,8 +206,17 @@ struct Graph {
         std::string nm;
         TensorP t = parse_tensor(fd.s, path, &nm);
         if (t) tensors[nm] = t;
+        init_names.push_back(nm);
+      } else if ((fd.num == 11 || fd.num == 12) && fd.wire == 2) {  // ValueInfoProto: name = field 1
+        Field v;
+        for (Reader vr(fd.s, path); vr.next(v);)
+          if (v.num == 1 && v.wire == 2) (fd.num == 11 ? inputs : outputs).emplace_back((const char *)v.s.p, v.s.n);
       }
     }
+    for (const std::string &nm : init_names)  // IR version < 4 lists every initialiser among the inputs
+      for (size_t k = 0; k < inputs.size();)
+        if (inputs[k] == nm) inputs.erase(inputs.begin() + (long)k);
+        else ++k;
     for (const Node &n : nodes)  // Constant nodes are tensors too
       if (n.op == "Constant" && n.value && !n.out.empty()) tensors[n.out[0]] = n.value;
   }
@@ -383,6 +400,43 @@ void put_conv(Sink &sink, const std::string &prefix, const Graph::ConvLayer &L) 
 
 bool exists(const std::string &p) { return (bool)std::ifstream(p, std::ios::binary); }
 
+std::string join(const std::vector<std::string> &v) {
+  std::string o;
+  for (size_t i = 0; i < v.size(); ++i) o += (i ? "," : "") + v[i];
+  return o;
+}
+bool has(const std::vector<std::string> &v, const char *name) {
+  for (const std::string &x : v)
+    if (x == name) return true;
+  return false;
+}
+
+// The reference binds decoder_iter.onnx's tensors BY NAME (ort `inputs!["decoder_input" => ..]`, src/tacotron2/mod.rs:284-296;
+// outputs indexed by name at :306-307 and :332-339), postnet.onnx's output by name (:349) with one positional input (:347), and
+// encoder.onnx positionally: two inputs, three outputs (:379-385).  A model directory the reference itself could not run is
+// refused here too, naming what is missing.
+const char *const DEC_INPUTS[] = {"decoder_input", "attention_hidden", "attention_cell", "decoder_hidden", "decoder_cell", "attention_weights",
+                                  "attention_weights_cum", "attention_context", "memory", "processed_memory", "mask"};
+const char *const DEC_OUTPUTS[] = {"decoder_output", "gate_prediction", "out_attention_hidden", "out_attention_cell", "out_decoder_hidden",
+                                   "out_decoder_cell", "out_attention_weights", "out_attention_weights_cum", "out_attention_context"};
+void check_io(const Graph &enc, const Graph &dec, const Graph &post) {
+  if (enc.inputs.size() != 2 || enc.outputs.size() != 3)
+    fail(XDTTS_ERR_IO, "%s: the reference feeds 2 inputs and reads 3 outputs (mod.rs:379-385); the graph has inputs [%s] outputs [%s]",
+         enc.path.c_str(), join(enc.inputs).c_str(), join(enc.outputs).c_str());
+  for (const char *n : DEC_INPUTS)
+    if (!has(dec.inputs, n))
+      fail(XDTTS_ERR_IO, "%s: no graph input named %s (the reference binds it by name, mod.rs:284-296); inputs are [%s]", dec.path.c_str(), n,
+           join(dec.inputs).c_str());
+  if (dec.inputs.size() != sizeof DEC_INPUTS / sizeof *DEC_INPUTS)
+    fail(XDTTS_ERR_IO, "%s: %zu graph inputs, the reference feeds 11 (mod.rs:284-296): [%s]", dec.path.c_str(), dec.inputs.size(), join(dec.inputs).c_str());
+  for (const char *n : DEC_OUTPUTS)
+    if (!has(dec.outputs, n))
+      fail(XDTTS_ERR_IO, "%s: no graph output named %s (mod.rs:306-307,332-339); outputs are [%s]", dec.path.c_str(), n, join(dec.outputs).c_str());
+  if (post.inputs.size() != 1 || !has(post.outputs, "mel_outputs_postnet"))
+    fail(XDTTS_ERR_IO, "%s: the reference feeds one input and reads `mel_outputs_postnet` (mod.rs:347-349); the graph has inputs [%s] outputs [%s]",
+         post.path.c_str(), join(post.inputs).c_str(), join(post.outputs).c_str());
+}
+
 }  // namespace
 
 bool onnx_model_dir(const std::string &dir) {
@@ -391,6 +445,7 @@ bool onnx_model_dir(const std::string &dir) {
 
 void load_onnx_dir(const std::string &dir, std::vector<float> &blob) {
   const Graph enc(dir + "/encoder.onnx"), dec(dir + "/decoder_iter.onnx"), post(dir + "/postnet.onnx");
+  check_io(enc, dec, post);
   Sink sink(blob);
   std::vector<float> W, b;
   // encoder.onnx (mod.rs:246-249)
@@ -452,6 +507,17 @@ void load_onnx_dir(const std::string &dir, std::vector<float> &blob) {
     for (int i = 0; i < POST_CONVS; ++i) put_conv(sink, "postnet.convolutions." + std::to_string(i), pc[(size_t)i]);
   }
   sink.finish();
+}
+
+// "file: inputs a,b,... ; outputs x,y,...\n" per graph -- what a maintainer (and the tests) compare with the names the
+// reference binds
+std::string describe_onnx_dir(const std::string &dir) {
+  std::string out;
+  for (const char *f : {"encoder.onnx", "decoder_iter.onnx", "postnet.onnx"}) {
+    const Graph g(dir + "/" + f);
+    out += std::string(f) + ": inputs " + join(g.inputs) + " ; outputs " + join(g.outputs) + "\n";
+  }
+  return out;
 }
 
 }  // namespace xdtts

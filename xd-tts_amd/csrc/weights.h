@@ -25,6 +25,7 @@ void load_container(const std::string &dir, std::vector<float> &blob);
 // onnx_load.cpp: the reference's own model directory (encoder.onnx, decoder_iter.onnx, postnet.onnx)
 bool onnx_model_dir(const std::string &dir);
 void load_onnx_dir(const std::string &dir, std::vector<float> &blob);
+std::string describe_onnx_dir(const std::string &dir);
 // Tacotron2::load(dir): `dir`/tacotron2.xdtw if present, else the three ONNX graphs
 void load_model_dir(const std::string &dir, std::vector<float> &blob);
 void save_container(const std::string &dir, const std::vector<float> &blob);
