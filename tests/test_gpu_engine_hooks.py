@@ -136,9 +136,10 @@ def test_explicit_dropout_masks_on_every_engine(pkg, orc, blob, engine, B):
         ref = orc.infer_chunk(blob, ids[b], orc.default_opts(fixed_steps=steps[b], masks=masks[b]))
         assert mels[b].shape == ref.shape == (80, steps[b])
         assert rms(mels[b], ref) <= 1e-5, (engine, b, rms(mels[b], ref))
-    # and they differ from the seeded stream's result (the masks really were used)
+    # and the masks really were used: the seeded stream's result lies well outside the tolerance (the synthetic weights
+    # make the mel only weakly dependent on the prenet output: 7e-5 RMS between two dropout realisations)
     seeded = orc.infer_chunk(blob, ids[0], orc.default_opts(fixed_steps=steps[0], dropout_seed=1234, item=17))
-    assert rms(mels[0], seeded) > 1e-3
+    assert rms(mels[0], seeded) > 3e-5
 
 
 def test_explicit_dropout_masks_argument_errors(pkg, model):

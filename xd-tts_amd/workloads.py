@@ -74,3 +74,13 @@ def chirps(n):
     rng = np.random.default_rng(3)
     y = sum(0.15 * np.sin(2 * np.pi * (f0 + 0.5 * (f1 - f0) * t / t[-1]) * t) for f0, f1 in ((100, 900), (400, 2500), (1200, 4000), (3000, 5500), (5000, 7000)))
     return (y + 0.01 * rng.standard_normal(n)).astype(np.float32)
+
+
+def chirp_magnitude(F, n_fft=1024, hop=256):
+    """config 5 input: S = |STFT| of the chirp signal, (n_fft/2+1, F) fp32 -- centred frames, reflect padding,
+    periodic hann, the vocoder's own analysis parameters (numpy; workload generation only)."""
+    y = chirps(hop * (F - 1)).astype(np.float64)
+    yp = np.pad(y, n_fft // 2, mode="reflect")
+    win = 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n_fft) / n_fft)
+    idx = np.arange(n_fft)[None, :] + hop * np.arange(F)[:, None]
+    return np.abs(np.fft.rfft(yp[idx] * win[None, :], axis=1)).T.astype(np.float32).copy()
