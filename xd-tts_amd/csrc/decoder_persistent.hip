@@ -829,7 +829,8 @@ PersistBufs persist_bufs(unsigned long long *base, int *err, int B) {
   g.mel = g.hdec + (size_t)2 * GS * DEC_RNN;
   g.err = err;
   g.lazy = PERSIST_LAZY_DEFAULT;
-  g.xlazy = g.clazy = 2;
+  g.xlazy = 0;  // round 3 re-sweep (profiles/r03_lazy_sweep.txt): 0 / 1 / 2 / 3 / 4 -> 9.93 / 10.03 / 10.14 / 10.29 / 10.52 us per 1-chunk step
+  g.clazy = 2;
   g.shrink = 0;
   g.spins = 0;
   g.fault = 0;
