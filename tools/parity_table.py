@@ -20,3 +20,15 @@ for F in (800, 1000):
 for it in (30, 60, 120):
     s = d["gl_audio_F1000_it%d" % it]
     print("| configs[4] audio, F = 1000, %d free-running iterations (signal RMS %.2f) | %s | %s | %s |" % (it, s["signal_rms"], f(s["gpu_vs_f32"]), f(s["gpu_vs_f64"]), f(s["f32_vs_f64"])))
+if "config2_audio_30_iterations_gpu_vs_f32" in d:
+    print("| configs[1] audio, 30 free-running iterations (the reference's setting, mod.rs:456) | %s | | |" % f(d["config2_audio_30_iterations_gpu_vs_f32"]))
+for F in (800, 1000):
+    k = "gl_step_trajectory_F%d_worst_rebuilt_rel_rms" % F
+    if k in d:
+        print("| Griffin-Lim ONE teacher-forced iteration along the oracle's trajectory (iterations 0, 1, 2, 5, 10, 20, 30, 45, 59), F = %d: worst rebuilt spectrum, relative RMS | %s | | |" % (F, f(d[k])))
+for F, what in ((1000, "configs[4] input"), (800, "the chirp magnitude cut to 800 frames (recorded only)")):
+    k = "gl_audio_F%d_vs_f32" % F
+    if k in d:
+        s = d[k]
+        print("| free-running audio vs f32 oracle at 10 / 20 / 30 / 40 / 60 iterations, %s; first even iteration above 1e-4: %s | %s / %s / %s / %s / %s | | |" % (
+            what, s["first_iteration_above_1e-4"], f(s["it10"]), f(s["it20"]), f(s["it30"]), f(s["it40"]), f(s["it60"])))
