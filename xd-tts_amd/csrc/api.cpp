@@ -521,6 +521,7 @@ struct xdtts_tacotron2 {
         if (const char *cl = getenv("XDTTS_CLAZY")) g.clazy = atoi(cl);
         if (const char *sp = getenv("XDTTS_PERSIST_SPINS")) g.spins = atoi(sp);  // test hooks for the
         if (const char *ft = getenv("XDTTS_PERSIST_FAULT")) g.fault = atoi(ft);  // lost-workgroup path
+        if (const char *sl = getenv("XDTTS_PERSIST_SLOW")) g.slow = atoi(sl);    // straggler workgroup
         g.shrink = (n == 2 && !no_shrink) ? 1 : 0;
 #ifdef XDTTS_PERSIST_PROFILE
         static DevBuf<unsigned long long> prof;
@@ -1040,6 +1041,7 @@ struct xdtts_griffinlim {
       p.nblk = nblk;
       p.TF = TF;
       if (const char *sp = getenv("XDTTS_GL_SPINS")) p.spins = atoi(sp);  // test hook
+      if (const char *sl = getenv("XDTTS_GL_SLOW")) p.slow = atoi(sl);    // test hook: straggler workgroup
       p.gen_phase = gen_phase ? 1 : 0;
       p.seed = seed;
       epoch += (unsigned)n_iter + 2u;

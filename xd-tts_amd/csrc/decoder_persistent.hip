@@ -122,6 +122,11 @@ __device__ __forceinline__ void gather(const u64 *base, unsigned idx, unsigned s
 __device__ __forceinline__ void lazy_wait(int n) {
   for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(8);
 }
+// test hook (PersistBufs::slow): this workgroup is a straggler at point `at` of step s when at == s mod 6
+__device__ __forceinline__ void straggle(bool me, int s, int at) {
+  if (me && s % 6 == at)
+    for (int i = 0; i < 2; ++i) __builtin_amdgcn_s_sleep(127);  // 2 x 8128 clocks ~ 7 us
+}
 __device__ __forceinline__ float4 lds4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 // Hides a thread-index expression's known bits from the optimiser.  Without this `idx + CONST`
 // is canonicalised to `idx | CONST` wherever the bits are disjoint, the constant no longer folds
@@ -458,6 +463,8 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
     const bool prow_ok = pre && wave < 6 && prow <= N_MEL;
     const int p = s & 1;
     const unsigned want = (unsigned)(s + 1);
+    const bool lag = g.slow && c == g.slow - 1;
+    straggle(lag, s, 0);
     PROF_MARK(0);  // loop overhead / previous P6 tail
     // ---- P1: x(s) and the chunks' active bits ------------------------------------------------
     {
@@ -512,6 +519,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       s_cell[8 * PB + tid] = hn;
     }
     PROF_MARK(2);  // att tail + cell + publish
+    straggle(lag, s, 1);
     __builtin_amdgcn_sched_barrier(0);
     // ---- P2: h_att(s) ----------------------------------------------------------------------------
     {
@@ -576,6 +584,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
         chunk_fence();
       }
     PROF_MARK(4);  // q + energies (attention) + dec bulk
+    straggle(lag, s, 2);
     __builtin_amdgcn_sched_barrier(0);
     // ---- P3 (every workgroup): partial energies of the 8 slices of every chunk -> softmax -> weights in registers ----
     {
@@ -615,6 +624,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       s_awc[lane + 64] += wreg[rb][1];
     }
     PROF_MARK(6);  // softmax
+    straggle(lag, s, 3);
     __builtin_amdgcn_sched_barrier(0);
     // ---- P4: decoder LSTM (its context columns are folded into pmd) -----------------------------------
 #pragma unroll
@@ -641,6 +651,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
     }
     att_bulk(L4, false);  // for step s+1: ctx(s), h_att(s)
     PROF_MARK(7);  // dec tail + cell + publish + att bulk
+    straggle(lag, s, 4);
     __builtin_amdgcn_sched_barrier(0);
     // ---- P5: h_dec(s) -> projection rows ---------------------------------------------------------
     {
@@ -669,6 +680,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
     dec_bulk_h(L4, false);  // for step s+1
     if (attn && act_r) location(tid);
     PROF_MARK(9);  // projection rows + dec bulk + location
+    straggle(lag, s, 5);
     __builtin_amdgcn_sched_barrier(0);
     // ---- P6 (projection + prenet role): frame s, stop rule, x(s+1) ------------------------------
     if (pre && act_r) {  // a chunk's last x (active bit clear) is published at the step it stops
@@ -834,6 +846,7 @@ PersistBufs persist_bufs(unsigned long long *base, int *err, int B) {
   g.shrink = 0;
   g.spins = 0;
   g.fault = 0;
+  g.slow = 0;
   g.first = 2;  // ~0.4 us: the first polls of a critical consumer cannot succeed earlier (measured: -0.3 us per step)
   return g;
 }

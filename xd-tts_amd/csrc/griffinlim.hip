@@ -574,6 +574,10 @@ __global__ __launch_bounds__(64 * W) void k_gl_persistent(GlBufs g, GlPersist p,
   for (int it = 0; it <= n_iter; ++it) {
     const unsigned want = p.epoch + (unsigned)it + 1u;
     const int par = it & 1;
+    // test hook: a straggler workgroup -- before its transforms (even iterations) or between its publish and its polls (odd)
+    const bool lag = p.slow && b == p.slow - 1;
+    if (lag && !(it & 1))
+      for (int i = 0; i < 2; ++i) __builtin_amdgcn_s_sleep(127);
     GLP_MARK(0);  // loop overhead
     // ---- A: inverse transform of the own frame: irfft(1024) of S * angles, synthesis window -> fb ----
     if (own) {
@@ -628,6 +632,8 @@ __global__ __launch_bounds__(64 * W) void k_gl_persistent(GlBufs g, GlPersist p,
       }
     }
     GLP_MARK(10);  // B0: publish
+    if (lag && (it & 1))
+      for (int i = 0; i < 2; ++i) __builtin_amdgcn_s_sleep(127);
     // First poll of the neighbours' granules, issued NOW: the loads' round trip (~1 us) overlaps the own overlap-add
     // below; the neighbours run in lock-step with this workgroup, so their stores are usually on their way already.
     // What is not there yet is polled again in B2.

@@ -86,6 +86,8 @@ struct PersistBufs {
   unsigned long long *x, *hatt, *ep, *hdec, *mel;  // (neither the context nor the attention weights cross)
   int *err;  // set by a workgroup whose bounded spin ran out
   int spins, fault;  // developer/test knobs: poll limit (0 = default) and a workgroup (index + 1) that never runs
+  int slow;          // test hook: a workgroup (index + 1) that stalls ~7 us at a different point of every step (straggler:
+                     // the two-slot exchange must keep every other workgroup from running more than one step ahead of it)
   int shrink;  // 2-chunk launch: end as soon as one chunk stops (the host continues with a 1-chunk launch)
   int first;  // delay before a critical consumer's first poll, x 512 clocks (developer knob)
   int xlazy, clazy;  // first-poll delay of the x / ctx consumers that are not their producers, x 512 clocks
@@ -182,6 +184,7 @@ struct GlPersist {
   unsigned epoch;           // tag base of this call (tags = epoch + iteration + 1; never reused within the buffer's life)
   int nblk, TF;
   int spins;                // test hook: poll limit (0 = default)
+  int slow;                 // test hook: a workgroup (index + 1) that stalls ~7 us at a different point of every iteration
   int gen_phase;            // 1: the kernel draws the seeded initial phase itself (angles = exp(2 pi i u), previous spectrum 0)
   unsigned seed;            //    instead of reading ang_in / tprev_in (saves the phase-init launch and a round trip through HBM)
   float2 *ang_out, *tprev_out;  // parity hook: final state, or null
