@@ -83,7 +83,7 @@ def test_teacher_forced_step_all_nine_outputs_per_engine(pkg, model, orc, blob, 
     assert worst > 0  # two different implementations really were compared
 
 
-@pytest.mark.parametrize("engine,B", [("persistent", 1), ("persistent", 2), ("batched", 6)])
+@pytest.mark.parametrize("engine,B", [("persistent", 1), ("persistent", 2), ("batched", 6), ("batched", 1), ("launch", 2)])
 def test_written_back_state_after_a_60_step_run(pkg, model, orc, blob, engine, B):
     """n_steps = 60 from DecoderState::new (mod.rs:202-233): every frame, every gate logit and the seven state
     tensors the engine leaves behind against the oracle's after the same 60 calls."""
@@ -101,6 +101,34 @@ def test_written_back_state_after_a_60_step_run(pkg, model, orc, blob, engine, B
     out, gate, gst = model.decoder_steps(engine, mem, pm, lens, zero, np.zeros((B, 80), dtype=np.float32), 0, n, opts=pkg.default_opts(dropout_seed=7))
     after = snapshot(sts, T)
     assert rms(out, frames) <= 1e-5 and np.abs(gate - gates).max() <= 1e-5
+    for k in NAMES:
+        assert np.abs(gst[k] - after[k]).max() <= 1e-5, (engine, k, float(np.abs(gst[k] - after[k]).max()))
+
+
+@pytest.mark.parametrize("engine,B", [("persistent", 2), ("batched", 5), ("launch", 1)])
+def test_step_hook_with_a_short_encoder_window_and_an_odd_step_count(pkg, model, orc, blob, engine, B):
+    """T = 64 rows of encoder memory (not the reference's 100), 7 steps from step 3 of the oracle's run: odd counts end on the
+    other ping-pong half of the launch-per-stage and batched engines."""
+    T, n0, n = 64, 3, 7
+    rng = np.random.Generator(np.random.PCG64(77))
+    mem = (rng.standard_normal((B, T, 512)) * 0.5).astype(np.float32)
+    pm = (rng.standard_normal((B, T, 128)) * 0.5).astype(np.float32)
+    lens = [64, 41, 9, 57, 30][:B]
+    opts = [orc.default_opts(dropout_seed=3, item=10 + b) for b in range(B)]
+    sts = [orc.new_state() for _ in range(B)]
+    for step in range(n0):
+        for b in range(B):
+            orc.decoder_step(blob, mem[b], pm[b], lens[b], sts[b], opts[b], step)
+    snap = snapshot(sts, T)
+    dec_in = np.stack([np.array(s.dec_in, dtype=np.float32) for s in sts])
+    frames = np.zeros((B, n, 80), dtype=np.float32)
+    gates = np.zeros((B, n), dtype=np.float32)
+    for i in range(n):
+        for b in range(B):
+            frames[b, i], gates[b, i] = orc.decoder_step(blob, mem[b], pm[b], lens[b], sts[b], opts[b], n0 + i)
+    out, gate, gst = model.decoder_steps(engine, mem, pm, lens, snap, dec_in, n0, n, opts=pkg.default_opts(dropout_seed=3, item_base=10))
+    after = snapshot(sts, T)
+    assert np.abs(out - frames).max() <= 1e-5 and np.abs(gate - gates).max() <= 1e-5
     for k in NAMES:
         assert np.abs(gst[k] - after[k]).max() <= 1e-5, (engine, k, float(np.abs(gst[k] - after[k]).max()))
 

@@ -1492,7 +1492,8 @@ static void enqueue_steps(const DecoderBufs &d, const DeviceWeights &w, int i0, 
   // letters p,a,q,s,d selecting which kernels a step launches, e.g. "ppppp".
   const char *mix = getenv("XDTTS_DEBUG_MIX");
   const std::string order = mix ? mix : "paqsd";
-  const bool batched = d.B >= BATCH_MFMA_MIN && w.att_wm.p && w.dec_wm.p && d.xf;  // LSTMs as MFMA GEMMs
+  // LSTMs as MFMA GEMMs: the caller chose the batched layout (decoder_bufs: from BATCH_MFMA_MIN chunks, or the parity hook's engine 2 at any B)
+  const bool batched = d.xf && w.att_wm.p && w.dec_wm.p;
   const float4 *att_wm = reinterpret_cast<const float4 *>(w.att_wm.p), *dec_wm = reinterpret_cast<const float4 *>(w.dec_wm.p);
   const bool fuse_aq = batched && d.ep_g && d.hg && d.B <= 64;
   for (int i = i0; i < i0 + nsteps; ++i) {
