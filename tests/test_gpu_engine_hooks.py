@@ -170,6 +170,28 @@ def test_explicit_dropout_masks_on_every_engine(pkg, orc, blob, engine, B):
     assert rms(mels[0], seeded) > 3e-5
 
 
+def test_explicit_dropout_masks_with_the_gate_on(pkg, orc, blob):
+    """The reference's real mode: the stop rule decides the frame count (mod.rs:319-324).  The masks must then cover max_steps;
+    frame counts and frames equal the oracle's with the same masks (persistent engine, one chunk)."""
+    from test_gpu_tacotron2_more import rigged_gate_blob
+
+    n = 33
+    ids = np.zeros(100, dtype=np.int64)
+    ids[:n] = synth_ids(n, seed=1)
+    mem, pm = orc.encoder(blob, ids)
+    rig = rigged_gate_blob(orc, blob, mem, pm, n, 21, 30)
+    rng = np.random.Generator(np.random.PCG64(4))
+    masks = (rng.random((1, 90, 2, 256)) < 0.5).astype(np.uint8)
+    rframes, rgates = orc.run_decoder(rig, mem, pm, n, orc.default_opts(max_steps=90, masks=masks[0]))
+    assert 1 <= len(rframes) < 90
+    m = pkg.Tacotron2.from_blob(rig)
+    frames, gates = m.decoder(mem, pm, n, pkg.default_opts(max_steps=90, dropout_masks=masks))
+    assert frames.shape == rframes.shape and rms(frames, rframes) <= 1e-5 and np.abs(gates - rgates).max() <= 1e-5
+    with pytest.raises(pkg.XdttsError):   # masks shorter than max_steps cannot cover a gate-driven decode
+        m.decoder(mem, pm, n, pkg.default_opts(max_steps=100, dropout_masks=masks))
+    m.close()
+
+
 def test_explicit_dropout_masks_argument_errors(pkg, model):
     ids = [synth_ids(20, seed=1)]
     masks = np.ones((1, 10, 2, 256), dtype=np.uint8)

@@ -64,6 +64,22 @@ def test_unfused_export_has_the_size_of_the_reference_files(exported):
         assert abs(size - want) <= 2048, (f, size, want)
 
 
+@pytest.mark.parametrize("opset", [9, 11, 12, 17])
+def test_exports_of_other_opsets_load_bit_exactly(pkg, tmp_path, opset):
+    """The exporter's graph details change with the opset (Squeeze / Unsqueeze axes as attributes or inputs, Dropout's form, the
+    LSTM node's layout attribute): opsets 9 to 17 -- the range an export of the reference's vintage can have -- all load, every
+    tensor bit for bit; the decoder_iter.onnx of an opset-12 export is 72 766 097 bytes, the reference's 72 766 349."""
+    import os
+
+    T = random_tensors(pkg, 20 + opset)
+    nx.export_model_dir(str(tmp_path), T, opset=opset, fuse_bn=False)
+    got = pkg.read_model_dir(str(tmp_path))
+    for name in got:
+        assert np.array_equal(got[name], T[name]), (opset, name)
+    for f, want in LFS_SIZES.items():
+        assert abs(os.path.getsize(os.path.join(str(tmp_path), f)) - want) <= 2048, (opset, f)
+
+
 def test_fused_export_recovers_the_folded_convolutions(pkg, exported):
     d, T = exported[True]
     got = pkg.read_model_dir(d)
