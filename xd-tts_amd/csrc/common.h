@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -68,6 +69,31 @@ void set_last_error(const char *msg);
 // cooperative launch measured +17 us on a 200-350 us vocoder call (5 %), its grid is checked against the
 // occupancy query when the handle is created, and a grid that still is not resident is caught by the
 // bounded spins like everywhere else.  XDTTS_COOP=1 / 0 forces either form for all three.
+// A cooperative launch is what VALIDATES a grid (kernel, block size, LDS, grid size <= what the runtime's occupancy says the
+// device can hold at once); its residency is the same as a plain launch's.  So the check is paid once: the first launch of
+// a given (kernel, block, LDS) on a device goes through hipLaunchCooperativeKernel, and once a grid of N workgroups has been
+// accepted every later launch of <= N workgroups of the same configuration is a plain one (-17 us of host time each: three
+// such launches per utterance).  XDTTS_COOP=1 keeps every launch cooperative, XDTTS_COOP=0 makes every launch plain.
+struct CoopValidated {
+  const void *fn;
+  unsigned threads, blocks;
+  size_t lds;
+  int device;
+};
+inline bool coop_validated(const void *fn, unsigned threads, size_t lds, unsigned blocks, bool record) {
+  static std::vector<CoopValidated> seen;
+  static std::mutex mu;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(mu);
+  for (CoopValidated &v : seen)
+    if (v.fn == fn && v.threads == threads && v.lds == lds && v.device == dev) {
+      if (record && blocks > v.blocks) v.blocks = blocks;
+      return blocks <= v.blocks;
+    }
+  if (record) seen.push_back(CoopValidated{fn, threads, blocks, lds, dev});
+  return false;
+}
 template <class... Args>
 inline hipError_t launch_coresident(bool coop_default, const void *fn, dim3 grid, dim3 block, size_t lds, hipStream_t s, Args... args) {
   void *argv[] = {(void *)&args...};
@@ -75,8 +101,13 @@ inline hipError_t launch_coresident(bool coop_default, const void *fn, dim3 grid
     const char *e = getenv("XDTTS_COOP");
     return !e ? -1 : (e[0] == '0' ? 0 : 1);
   }();
-  const bool coop = forced < 0 ? coop_default : forced == 1;
-  return coop ? hipLaunchCooperativeKernel(fn, grid, block, argv, (unsigned)lds, s) : hipLaunchKernel(fn, grid, block, argv, lds, s);
+  const unsigned blocks = grid.x * grid.y * grid.z, threads = block.x * block.y * block.z;
+  bool coop = forced < 0 ? coop_default : forced == 1;
+  if (coop && forced < 0 && coop_validated(fn, threads, lds, blocks, false)) coop = false;  // this grid has been accepted before
+  if (!coop) return hipLaunchKernel(fn, grid, block, argv, lds, s);
+  const hipError_t e = hipLaunchCooperativeKernel(fn, grid, block, argv, (unsigned)lds, s);
+  if (e == hipSuccess) (void)coop_validated(fn, threads, lds, blocks, true);
+  return e;
 }
 
 // A cooperative launch the runtime refused (hipErrorCooperativeLaunchTooLarge: CU masking, fewer CUs than the grid needs, a
