@@ -169,6 +169,7 @@ struct xdtts_tacotron2 {
   DevBuf<unsigned long long> dec_exchange;  // granule buffers of the persistent decoder
   DevBuf<int> dec_err;
   DevBuf<unsigned long long> att_exchange;
+  DevBuf<float> att_part;  // early partial pre-activations of the attention LSTM (DecoderBufs::att_part)
   // batched mode: energies, softmax and context in one launch (XDTTS_ATT_FUSED=0: the two-kernel form; also after
   // an exchange of that launch timed out)
   static int att_fused_default() {
@@ -405,7 +406,14 @@ struct xdtts_tacotron2 {
         d.ep_g = att_exchange.p;
         d.att_err = dec_err.p;
         // ... and the attention LSTM in the same launch: its 256 blocks of 512 threads must be resident together, one per CU
-        if (att_fused > 1 && B <= 64 && n_cu >= ATT_RNN / 4) d.hg = att_exchange.p + ne;
+        if (att_fused > 1 && B <= 64 && n_cu >= ATT_RNN / 4) {
+          d.hg = att_exchange.p + ne;
+          static const bool no_early = getenv("XDTTS_NO_EARLY") != nullptr;  // developer comparison aid: the attention launch runs its whole K
+          if (!no_early) {  // early partial of the attention-LSTM GEMM, computed inside the prenet launch (kernels.h)
+            att_part.alloc((size_t)(ATT_RNN / 4) * 4 * 64 * 4);
+            d.att_part = att_part.p;
+          }
+        }
         if (const char *sp = getenv("XDTTS_ATT_SPINS")) d.att_spins = atoi(sp);  // test hooks for the
         if (const char *ft = getenv("XDTTS_ATT_FAULT")) d.att_fault = atoi(ft);  // lost-block path
       }
@@ -645,6 +653,7 @@ struct xdtts_tacotron2 {
         DecoderBufs d2 = d;
         d2.ep_g = nullptr;
         d2.hg = nullptr;
+        d2.att_part = nullptr;
         return run_decoder(d2, lim);
       }
     }
@@ -1586,6 +1595,7 @@ xdtts_status xdtts_tacotron2_decoder_steps(xdtts_tacotron2 *h, int32_t engine, i
       std::unique_lock<std::recursive_mutex> chip;
       if (d.hg) chip = std::unique_lock<std::recursive_mutex>(chip_mutex(h->device));
       if (engine == 0) launch_decoder_location(d, h->w, st);  // (the batched prenet launch computes them itself)
+      launch_decoder_early(d, h->w, 0, st);  // (batched engine: the first attention-LSTM pass's early partial, from the imported state)
       for (int i = 0; i < n_steps; ++i) {
         launch_decoder_step_at(d, h->w, i, st);
         d.dec_in = nullptr;  // from the second step on the loop feeds itself

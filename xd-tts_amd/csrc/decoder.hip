@@ -55,6 +55,7 @@ constexpr int MEL_LD = 84;          // 80 mel + gate, padded to a float4 multipl
 constexpr int CTX_BLOCKS = 8, CTX_COLS = EMB / CTX_BLOCKS;
 constexpr int PM_ROWS = CTX_BLOCKS + NBLK;  // partial-mel rows per chunk: 8 ctx blocks, then 256 h blocks
 static_assert(ATT_RNN == DEC_RNN, "both LSTMs use 256 blocks of 4 units");
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // DecoderState::new (mod.rs:202-233): all recurrent state zero.
 __global__ void k_decoder_init(DecoderBufs d, const int *limits) {
@@ -700,7 +701,6 @@ __global__ __launch_bounds__(256) void k_lstm(DecoderBufs d, int i, int cur, con
 // activations come from L2 with 64-byte segments per chunk.  Accumulators of the K-slices meet in LDS; wave t
 // then holds, per lane, the four gates of (chunk 16t + lane%16, unit lane/16) -- exactly the MFMA D layout --
 // and does the cell update in place.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Operands: the weights in MFMA A-fragment order (weights.h) stream in, one 16-byte load per
 // lane = the A operands of four MFMAs, the wave's whole slab in flight at kernel entry; the
@@ -713,18 +713,21 @@ struct NoHook {
 };
 // after_loop: runs once this wave has issued its last operand load (and the cell-state load of the tail): the
 // attention-LSTM launch puts the loads of its attention phase there, behind nothing the LSTM pass still waits for
-template <int NCOLS, int KIND, int NTA, class Hook = NoHook>
+// C0 / CN: the pass multiplies columns [C0, C0 + CN) only (wsrc points at the wave's first k-step of that range) and, with
+// PART, adds the early partial of the remaining columns (DecoderBufs::att_part) in the cell-update waves.
+template <int NCOLS, int KIND, int NTA, class Hook = NoHook, int C0 = 0, int CN = NCOLS, bool PART = false>
 __device__ __forceinline__ void lstm_mfma_pass(const DecoderBufs &d, int n0, int cur, int step, int blk, const float4 *__restrict__ wsrc,
                                                const float4 bz, const float (&wa)[6], float *s_acc, unsigned long long active,
                                                unsigned long long d_probe_entry = 0, Hook after_loop = Hook()) {  // active: bit j = chunk n0 + j still runs at this step
-  constexpr int NW = MFMA_WAVES, KW = NCOLS / NW, JJ = KW / 16;
+  constexpr int NW = MFMA_WAVES, KW = CN / NW, JJ = KW / 16;
+  static_assert(CN % (16 * NW) == 0 && C0 % 16 == 0, "whole k-steps per wave");
   constexpr int N0 = KIND == 0 ? PRENET : ATT_RNN, N1 = EMB;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fi = lane & 15, fg = lane >> 4;  // (wave index as a scalar: the segment choice in src() below is then scalar code, not exec-masked branches)
   const float4 *seg0 = reinterpret_cast<const float4 *>(KIND == 0 ? d.xf : d.att_hf[cur ^ 1]);
   const float4 *seg1 = reinterpret_cast<const float4 *>(d.ctxf);
   const float4 *seg2 = reinterpret_cast<const float4 *>(KIND == 0 ? d.att_hf[cur] : d.dec_hf[cur]);
   auto src = [&](int jj) {  // first 16-byte vector of this lane for k-step jj (wave-uniform segment choice)
-    const int col = wave * KW + 16 * jj;
+    const int col = C0 + wave * KW + 16 * jj;
     const float4 *sb = col < N0 ? seg0 + (size_t)(col >> 2) * d.Bpad
                                 : (col < N0 + N1 ? seg1 + (size_t)((col - N0) >> 2) * d.Bpad : seg2 + (size_t)((col - N0 - N1) >> 2) * d.Bpad);
     return sb + (size_t)fg * d.Bpad + n0 + fi;
@@ -783,6 +786,8 @@ __device__ __forceinline__ void lstm_mfma_pass(const DecoderBufs &d, int n0, int
   float *cst = KIND == 0 ? d.att_c : d.dec_c;
   const size_t ci = ((size_t)blk * d.Bpad + n0 + 16 * (wave < NTA ? wave : 0) + fi) * 4 + fg;
   float c_old = cst[wave < NTA && n0 + 16 * wave + fi < d.B ? ci : (size_t)blk * d.Bpad * 4];  // (unconditional: clamped to the block's first state)
+  f32x4 pin = (f32x4){0.f, 0.f, 0.f, 0.f};  // early partial of this lane's (chunk, unit): written by the previous launch
+  if (PART) pin = reinterpret_cast<const f32x4 *>(d.att_part)[((size_t)blk * 4 + (wave < NTA ? wave : 0)) * 64 + lane];
   asm volatile("" ::: "memory");
 #pragma unroll
   for (int jj = 0; jj < JJ; ++jj) {
@@ -830,6 +835,7 @@ __device__ __forceinline__ void lstm_mfma_pass(const DecoderBufs &d, int n0, int
     f32x4 g = *reinterpret_cast<const f32x4 *>(s_acc + ((size_t)wave * 64 + lane) * 4);
 #pragma unroll
     for (int q = 1; q < NW; ++q) g += *reinterpret_cast<const f32x4 *>(s_acc + ((size_t)(q * 4 + wave) * 64 + lane) * 4);
+    if (PART) g += pin;
     const int n = n0 + 16 * wave + fi, unit = blk * 4 + fg;
     float hn = 0.f;
     if (n < d.B) {
@@ -875,15 +881,134 @@ __device__ __forceinline__ void lstm_mfma_pass(const DecoderBufs &d, int n0, int
 #endif
 }
 
+
+// ---- early partial of the attention-LSTM GEMM (DecoderBufs::att_part) ----------------------------------------------------
+// Of the 1792 columns the attention LSTM of step s+1 multiplies, only the 256 prenet columns x(s+1) are new when its launch
+// starts: the context and its own hidden state of step s are complete when the attention launch of step s ends.  256 extra
+// blocks of the DECODER-LSTM launch of step s -- two 512-thread blocks of this kernel fit a CU, and its own blocks leave the
+// matrix cores idle at entry, while they wait for their last wave and in the cell update -- multiply those 1536 columns (86 %
+// of the pass, 25 of its 29 MB of weights): block blk = the 16 gate rows of LSTM block blk, its 8 waves take 12 k-steps (of 16
+// columns) each, operands as in lstm_mfma_pass (weights in A-fragment order, activations from the [K/4][Bpad][4] copies).
+// The 8 partial accumulators meet in LDS in a fixed order and leave as [blk][tile][lane] float4 = the D layout the cell-update
+// waves of the attention launch hold, which add them to their own 256-column product.  `hcur`: half of att_hf that holds h_att(s).
+#ifdef XDTTS_LSTM_PROBE
+__device__ __forceinline__ unsigned hw_place() {  // (xcc << 16) | HW_ID: which CU a block landed on
+  unsigned xcc, hw;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+  return ((xcc & 15u) << 16) | (hw & 0xffffu);
+}
+#endif
+constexpr int EARLY_K0 = PRENET / 16, EARLY_KS = (ATT_COLS - PRENET) / 16;  // k-steps 16 .. 111 of the 112
+template <int NTA>
+__device__ __forceinline__ void att_early_partial(const DecoderBufs &d, int hcur, int blk, const float4 *__restrict__ Wm, float *lds,
+                                                  unsigned long long t_entry = 0, int step = 0) {
+  constexpr int NWV = MFMA_WAVES, JJ = EARLY_KS / NWV;
+  static_assert(EARLY_KS % NWV == 0, "whole k-steps per wave");
+#ifdef XDTTS_LSTM_PROBE
+  unsigned long long ep[4];
+  ep[0] = wall_clock64();
+#endif
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fi = lane & 15, fg = lane >> 4;
+  const float4 *wsrc = Wm + ((size_t)blk * (ATT_COLS / 16) + EARLY_K0 + wave * JJ) * 64 + lane;
+  const float4 *seg1 = reinterpret_cast<const float4 *>(d.ctxf), *seg2 = reinterpret_cast<const float4 *>(d.att_hf[hcur]);
+  auto src = [&](int jj) {  // (wave-uniform segment choice: scalar code)
+    const int col = 16 * (wave * JJ + jj);  // column behind the prenet columns
+    const float4 *sb = col < EMB ? seg1 + (size_t)(col >> 2) * d.Bpad : seg2 + (size_t)((col - EMB) >> 2) * d.Bpad;
+    return sb + (size_t)fg * d.Bpad + fi;
+  };
+  constexpr int DW = NTA >= 3 ? 2 : 3, DX = NTA >= 3 ? 1 : 2, RX = DX + 1;  // prefetch depths of lstm_mfma_pass
+  f32x4 acc[NTA];
+#pragma unroll
+  for (int t = 0; t < NTA; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float4 ring[RX][NTA], wring[4];
+#pragma unroll
+  for (int p = 0; p < DW; ++p) {
+    wring[p] = wsrc[(size_t)p * 64];
+    if (p < DX) {
+      const float4 *sp = src(p);
+#pragma unroll
+      for (int t = 0; t < NTA; ++t) ring[p][t] = sp[16 * t];
+    }
+    asm volatile("" ::: "memory");
+  }
+#pragma unroll
+  for (int jj = 0; jj < JJ; ++jj) {
+    if (jj + DX < JJ) {
+      const float4 *sp = src(jj + DX);
+#pragma unroll
+      for (int t = 0; t < NTA; ++t) ring[(jj + DX) % RX][t] = sp[16 * t];
+    }
+    asm volatile("" ::: "memory");
+    if (jj + DW < JJ) wring[(jj + DW) % 4] = wsrc[(size_t)(jj + DW) * 64];
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    const float4 wv = wring[jj % 4];
+    const float4(&xv)[NTA] = ring[jj % RX];
+#pragma unroll
+    for (int t = 0; t < NTA; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, xv[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NTA; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, xv[t].y, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NTA; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.z, xv[t].z, acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NTA; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, xv[t].w, acc[t], 0, 0, 0);
+  }
+#ifdef XDTTS_LSTM_PROBE
+  ep[1] = wall_clock64();
+#endif
+  f32x4 *red = reinterpret_cast<f32x4 *>(lds);  // [wave][tile][lane]
+#pragma unroll
+  for (int t = 0; t < NTA; ++t) red[(wave * 4 + t) * 64 + lane] = acc[t];
+  __syncthreads();
+  if (wave < NTA) {
+    f32x4 g = red[wave * 64 + lane];
+#pragma unroll
+    for (int q = 1; q < NWV; ++q) g += red[(q * 4 + wave) * 64 + lane];
+    reinterpret_cast<f32x4 *>(d.att_part)[((size_t)blk * 4 + wave) * 64 + lane] = g;
+  }
+#ifdef XDTTS_LSTM_PROBE
+  ep[2] = wall_clock64();
+  if ((blk == 3 || blk == 100 || blk == 200 || blk == 255) && (tid == 0 || tid == 64 * 5) && (step == 100 || step == 101))
+    printf("probe early blk %d wave %d step %d NTA %d place %05x: entry %llu  entry->loop %llu  loop %llu  reduce %llu  (x10ns)\n", blk, wave, step, NTA, hw_place(),
+           t_entry % 100000ull, ep[0] - t_entry, ep[1] - ep[0], ep[2] - ep[1]);
+#endif
+}
+// the role as a whole: tiles by the chunks still active at step `next`
+__device__ __forceinline__ void att_early_role(const DecoderBufs &d, int next, int hcur, int blk, const float4 *__restrict__ Wm, float *lds, unsigned long long t_entry) {
+  const int lane = threadIdx.x & 63;
+  const bool a = lane < d.B && next < d.nframes[min(lane, d.B - 1)];  // (a chunk the next prenet launch stops still counts: its tile's partial is not read then)
+  const unsigned long long m = __ballot(a);
+  const int nta = m ? (63 - __clzll((long long)m)) / 16 + 1 : 0;
+  switch (nta) {
+    case 1: att_early_partial<1>(d, hcur, blk, Wm, lds, t_entry, next); break;
+    case 2: att_early_partial<2>(d, hcur, blk, Wm, lds, t_entry, next); break;
+    case 3: att_early_partial<3>(d, hcur, blk, Wm, lds, t_entry, next); break;
+    case 4: att_early_partial<4>(d, hcur, blk, Wm, lds, t_entry, next); break;
+    default: break;
+  }
+}
+// stand-alone form (parity hooks: a sequence that starts from caller-held state has no preceding decoder-LSTM launch)
+__global__ __launch_bounds__(64 * MFMA_WAVES) void k_att_early(DecoderBufs d, int i, const float4 *__restrict__ att_wm) {
+  __shared__ __attribute__((aligned(16))) float s_acc[MFMA_WAVES * 4 * 64 * 4];
+  att_early_role(d, d.ctl[0] + i, i & 1, blockIdx.x, att_wm, s_acc, 0);
+}
+
 template <int NCOLS, int KIND>
 __global__ __launch_bounds__(64 * MFMA_WAVES) void k_lstm_mfma(DecoderBufs d, int i, int cur, const float4 *__restrict__ Wm,
-                                                               const float *__restrict__ bias, const float4 *__restrict__ Wepi) {
+                                                               const float *__restrict__ bias, const float4 *__restrict__ Wepi,
+                                                               const float4 *__restrict__ att_wm) {
   constexpr int NW = MFMA_WAVES, KW = NCOLS / NW, JJ = KW / 16;
 #ifdef XDTTS_LSTM_PROBE
   const unsigned long long t_entry = wall_clock64();
 #else
   const unsigned long long t_entry = 0;
 #endif
+  __shared__ __attribute__((aligned(16))) float s_acc[NW * 4 * 64 * 4];  // [K-slice][tile][lane][gate]
+  if (KIND == 1 && (int)blockIdx.x >= NBLK) {  // blocks 256..511 of a decoder-LSTM launch with d.att_part: the NEXT step's early partial
+    att_early_role(d, d.ctl[0] + i + 1, cur ^ 1, (int)blockIdx.x - NBLK, att_wm, s_acc, t_entry);  // (this step's attention launch wrote h_att into half cur ^ 1)
+    return;
+  }
   const int blk = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fg = lane >> 4;
   const float4 *wsrc = Wm + ((size_t)(blk * NW + wave) * JJ) * 64 + lane;
@@ -900,7 +1025,6 @@ __global__ __launch_bounds__(64 * MFMA_WAVES) void k_lstm_mfma(DecoderBufs d, in
     const int mrow = 16 * rt + (lane & 15);
     wa[rt] = (KIND == 1 && wave < 4 && mrow < MEL_LD) ? reinterpret_cast<const float *>(Wepi)[((size_t)blk * MEL_LD + mrow) * 4 + fg] : 0.f;
   }
-  __shared__ __attribute__((aligned(16))) float s_acc[NW * 4 * 64 * 4];  // [K-slice][tile][lane][gate]
   switch (nta) {
     case 1: lstm_mfma_pass<NCOLS, KIND, 1>(d, n0, cur, step, blk, wsrc, bz, wa, s_acc, m, t_entry); break;
     case 2: lstm_mfma_pass<NCOLS, KIND, 2>(d, n0, cur, step, blk, wsrc, bz, wa, s_acc, m, t_entry); break;
@@ -1396,14 +1520,17 @@ __global__ __launch_bounds__(256) void k_attention_b(DecoderBufs d, int i, int c
 // four hidden units of every chunk as granules (next to the B-operand copy the decoder LSTM reads after the grid
 // boundary); blocks 4 b .. 4 b + 3 then turn into the attention blocks of chunk b.  All 256 blocks must be resident
 // together (one per CU), as for the persistent engine; the same bounded spin covers a grid that is not.
+// EARLY: the pass multiplies the 256 prenet columns only and adds d.att_part, the product of the other 1536 columns that
+// 256 blocks of the preceding decoder-LSTM launch computed (att_early_partial).
+template <bool EARLY>
 __global__ __launch_bounds__(64 * MFMA_WAVES) void k_att_lstm_attention(DecoderBufs d, int i, int cur, const float4 *__restrict__ Wm,
                                                                         const float *__restrict__ bias, const float4 *__restrict__ Wq,
                                                                         const float *__restrict__ v_w, const float *__restrict__ proj_wc) {
-  constexpr int NW = MFMA_WAVES, KW = ATT_COLS / NW, JJ = KW / 16;
+  constexpr int NW = MFMA_WAVES, CN = EARLY ? PRENET : ATT_COLS, JJ = CN / NW / 16;
   static_assert(NW == 8 && attention_lds_floats(512) <= NW * 4 * 64 * 4, "the attention phase reuses the accumulator exchange area");
   const int blk = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fg = lane >> 4;
-  const float4 *wsrc = Wm + ((size_t)(blk * NW + wave) * JJ) * 64 + lane;
+  const float4 *wsrc = Wm + ((size_t)blk * (ATT_COLS / 16) + wave * JJ) * 64 + lane;
   const int step = d.ctl[0] + i;
   const bool a = lane < d.B && step < d.nframes[min(lane, d.B - 1)];
   const unsigned long long m = __ballot(a);
@@ -1420,10 +1547,10 @@ __global__ __launch_bounds__(64 * MFMA_WAVES) void k_att_lstm_attention(DecoderB
     if (attn) attention_loads<512, true>(L, d, i, cur, b, part, Wq, v_w);  // (the late group follows the publish of h: attention_chunk)
   };
   switch (nta) {
-    case 1: lstm_mfma_pass<ATT_COLS, 0, 1>(d, 0, cur, step, blk, wsrc, bz, wa, s_acc, m, 0, hook); break;
-    case 2: lstm_mfma_pass<ATT_COLS, 0, 2>(d, 0, cur, step, blk, wsrc, bz, wa, s_acc, m, 0, hook); break;
-    case 3: lstm_mfma_pass<ATT_COLS, 0, 3>(d, 0, cur, step, blk, wsrc, bz, wa, s_acc, m, 0, hook); break;
-    case 4: lstm_mfma_pass<ATT_COLS, 0, 4>(d, 0, cur, step, blk, wsrc, bz, wa, s_acc, m, 0, hook); break;
+    case 1: lstm_mfma_pass<ATT_COLS, 0, 1, decltype(hook), 0, CN, EARLY>(d, 0, cur, step, blk, wsrc, bz, wa, s_acc, m, 0, hook); break;
+    case 2: lstm_mfma_pass<ATT_COLS, 0, 2, decltype(hook), 0, CN, EARLY>(d, 0, cur, step, blk, wsrc, bz, wa, s_acc, m, 0, hook); break;
+    case 3: lstm_mfma_pass<ATT_COLS, 0, 3, decltype(hook), 0, CN, EARLY>(d, 0, cur, step, blk, wsrc, bz, wa, s_acc, m, 0, hook); break;
+    case 4: lstm_mfma_pass<ATT_COLS, 0, 4, decltype(hook), 0, CN, EARLY>(d, 0, cur, step, blk, wsrc, bz, wa, s_acc, m, 0, hook); break;
     default: return;  // (no chunk is active: nothing to attend to either)
   }
   if (!attn) return;
@@ -1460,6 +1587,7 @@ void launch_decoder_init(const DecoderBufs &d, const int *limits_dev, hipStream_
   HIP_CHECK(hipMemsetAsync(d.pmel, 0, decoder_pmel_floats(d.B) * sizeof(float), s));
   if (d.ep_g) HIP_CHECK(hipMemsetAsync(d.ep_g, 0, sizeof(unsigned long long) * (size_t)d.B * CTX_BLOCKS * d.T, s));  // step tags restart at 1
   if (d.hg) HIP_CHECK(hipMemsetAsync(d.hg, 0, sizeof(unsigned long long) * (size_t)d.B * ATT_RNN, s));
+  if (d.att_part) HIP_CHECK(hipMemsetAsync(d.att_part, 0, sizeof(float) * (size_t)NBLK * 4 * 64 * 4, s));  // step 0: context and hidden state are zero
   hipLaunchKernelGGL(k_decoder_init, dim3(d.B), dim3(256), 0, s, d, limits_dev);
   HIP_CHECK(hipGetLastError());
 }
@@ -1479,6 +1607,13 @@ void launch_decoder_step_at(const DecoderBufs &d, const DeviceWeights &w, int i,
   enqueue_steps(d, w, i, 1, s);
   HIP_CHECK(hipGetLastError());
 }
+// Parity hooks, batched engine with d.att_part: the early partial of node i's attention-LSTM pass from the state as it stands
+// (inside a sequence the decoder-LSTM launch of node i - 1 computes it)
+void launch_decoder_early(const DecoderBufs &d, const DeviceWeights &w, int i, hipStream_t s) {
+  if (!(d.xf && w.att_wm.p && d.ep_g && d.hg && d.B <= 64 && d.att_part)) return;
+  hipLaunchKernelGGL(k_att_early, dim3(NBLK), dim3(64 * MFMA_WAVES), 0, s, d, i, reinterpret_cast<const float4 *>(w.att_wm.p));
+  HIP_CHECK(hipGetLastError());
+}
 void launch_decoder_advance(const DecoderBufs &d, int n, hipStream_t s) {
   hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, s, d, n);
   HIP_CHECK(hipGetLastError());
@@ -1496,6 +1631,7 @@ static void enqueue_steps(const DecoderBufs &d, const DeviceWeights &w, int i0, 
   const bool batched = d.xf && w.att_wm.p && w.dec_wm.p;
   const float4 *att_wm = reinterpret_cast<const float4 *>(w.att_wm.p), *dec_wm = reinterpret_cast<const float4 *>(w.dec_wm.p);
   const bool fuse_aq = batched && d.ep_g && d.hg && d.B <= 64;
+  const bool early = fuse_aq && d.att_part != nullptr;  // 1536 of the attention LSTM's 1792 columns ride in the previous decoder-LSTM launch
   for (int i = i0; i < i0 + nsteps; ++i) {
     const int cur = i & 1;
     for (char k : order) {
@@ -1509,11 +1645,14 @@ static void enqueue_steps(const DecoderBufs &d, const DeviceWeights &w, int i0, 
                                w.proj_b.p);
           break;
         case 'a':
-          if (fuse_aq)  // attention LSTM + energies + softmax + context ('q' and 's' are then no-ops)
-            hipLaunchKernelGGL(k_att_lstm_attention, dim3(NBLK), dim3(64 * MFMA_WAVES), 0, s, d, i, cur, att_wm, w.att_b.p,
+          if (early)  // attention LSTM (its 256 prenet columns + the early partial) + energies + softmax + context
+            hipLaunchKernelGGL(k_att_lstm_attention<true>, dim3(NBLK), dim3(64 * MFMA_WAVES), 0, s, d, i, cur, att_wm, w.att_b.p,
+                               reinterpret_cast<const float4 *>(w.q_w.p), w.v_w.p, w.proj_wc.p);
+          else if (fuse_aq)  // attention LSTM + energies + softmax + context ('q' and 's' are then no-ops)
+            hipLaunchKernelGGL(k_att_lstm_attention<false>, dim3(NBLK), dim3(64 * MFMA_WAVES), 0, s, d, i, cur, att_wm, w.att_b.p,
                                reinterpret_cast<const float4 *>(w.q_w.p), w.v_w.p, w.proj_wc.p);
           else if (batched)
-            hipLaunchKernelGGL((k_lstm_mfma<ATT_COLS, 0>), dim3(NBLK, (d.B + 63) / 64), dim3(64 * MFMA_WAVES), 0, s, d, i, cur, att_wm, w.att_b.p, q4);
+            hipLaunchKernelGGL((k_lstm_mfma<ATT_COLS, 0>), dim3(NBLK, (d.B + 63) / 64), dim3(64 * MFMA_WAVES), 0, s, d, i, cur, att_wm, w.att_b.p, q4, att_wm);
           else
             hipLaunchKernelGGL((k_lstm<ATT_COLS, 0>), dim3(NBLK), dim3(256), 0, s, d, i, cur, att_w, w.att_b.p, q4,
                                w.loc_conv.p, w.loc_denseT.p);
@@ -1534,7 +1673,8 @@ static void enqueue_steps(const DecoderBufs &d, const DeviceWeights &w, int i0, 
           break;
         case 'd':
           if (batched) {
-            hipLaunchKernelGGL((k_lstm_mfma<DEC_COLS, 1>), dim3(NBLK, (d.B + 63) / 64), dim3(64 * MFMA_WAVES), 0, s, d, i, cur, dec_wm, w.dec_b.p, wh4);
+            hipLaunchKernelGGL((k_lstm_mfma<DEC_COLS, 1>), dim3(early ? 2 * NBLK : NBLK, (d.B + 63) / 64), dim3(64 * MFMA_WAVES), 0, s, d, i, cur, dec_wm, w.dec_b.p, wh4,
+                               att_wm);  // (early: blocks 256..511 multiply the next attention-LSTM pass's 1536 known columns)
           } else
             hipLaunchKernelGGL((k_lstm<DEC_COLS, 1>), dim3(loc_tiles * d.B + NBLK), dim3(256), 0, s, d, i, cur, dec_w,
                                w.dec_b.p, wh4, w.loc_conv.p, w.loc_denseT.p);

@@ -56,6 +56,12 @@ struct DecoderBufs {
   // ... and the attention LSTM in the same launch (k_att_lstm_attention, B <= 64): its output as granules [B][1024]
   // in place of the row-major att_h; null = separate launches
   unsigned long long *hg;
+  // ... and, with it, the EARLY partial pre-activations: the columns of an LSTM GEMM whose operand exists one launch ahead
+  // are multiplied there, on matrix cores the other launch leaves idle.  att_part [256 blocks][4 tiles][64 lanes][4 gates]
+  // (the MFMA D layout of the block's cell-update waves) = W_att[:, 256..1791] . [ctx(s-1) ; h_att(s-1)], written by 256
+  // extra blocks of the decoder-LSTM launch of step s-1, added by the attention-LSTM pass of step s, which then only
+  // multiplies the 256 prenet columns.  null = the attention launch runs the whole K.
+  float *att_part;
   int att_spins, att_fault;  // test hooks: poll limit (0 = default) and a block (index + 1) that never publishes its energies
 };
 constexpr int ATT_EXCHANGE_BLOCKS = 8;  // granule rows per chunk (CTX_BLOCKS in decoder.hip)
@@ -69,6 +75,7 @@ void launch_decoder_steps(const DecoderBufs &d, const DeviceWeights &w, int nste
 // batched engine computes them inside its prenet launch), and the batched engine's state layout conversion.
 void launch_decoder_step_at(const DecoderBufs &d, const DeviceWeights &w, int i, hipStream_t s);
 void launch_decoder_advance(const DecoderBufs &d, int n, hipStream_t s);
+void launch_decoder_early(const DecoderBufs &d, const DeviceWeights &w, int i, hipStream_t s);  // (no-op without d.att_part)
 void launch_decoder_location(const DecoderBufs &d, const DeviceWeights &w, hipStream_t s);
 void launch_decoder_prenet(const DecoderBufs &d, const DeviceWeights &w, hipStream_t s);
 void launch_frag_convert(float *rowmajor, float *frag, int B, int Bpad, int n, int dir, hipStream_t s);
