@@ -322,6 +322,33 @@ def test_batched_attention_forms_agree(pkg, orc, blob):
         assert rms(out["2"][b], out["0"][b]) <= 1e-5 and rms(out["1"][b], out["0"][b]) <= 1e-5
 
 
+def test_early_attention_lstm_partial_agrees_with_the_whole_pass(pkg, orc, blob):
+    """In the one-launch attention form the attention LSTM's 1536 columns over [ctx ; h_att] are multiplied one launch
+    early (extra blocks of the previous step's decoder-LSTM launch) and the attention launch adds that partial to its
+    256 prenet columns; XDTTS_NO_EARLY (read per handle) makes the attention launch multiply the whole K.  Same
+    products, grouped differently: each within 1e-5 of the oracle over a 60-step decode of 21 chunks (two MFMA tiles, a
+    ragged second one, chunks stopping at different steps), and of each other."""
+    ids_list = [synth_ids(20 + 3 * i, seed=700 + i) for i in range(21)]
+    steps = [60 - 2 * i for i in range(21)]
+    out = {}
+    for early in (True, False):
+        if not early:
+            os.environ["XDTTS_NO_EARLY"] = "1"
+        try:
+            m = pkg.Tacotron2.from_blob(blob)
+        finally:
+            os.environ.pop("XDTTS_NO_EARLY", None)
+        out[early] = m.infer_batch(ids_list, opts=pkg.default_opts(dropout_seed=37), fixed_steps=steps)
+        assert m.engine_state()["batched_attention"] == 2
+        m.close()
+    for b in (0, 7, 15, 16, 20):
+        ref = orc.infer_chunk(blob, ids_list[b], orc.default_opts(fixed_steps=steps[b], dropout_seed=37, item=b))
+        for early in out:
+            assert out[early][b].shape == (80, steps[b]) and rms(out[early][b], ref) <= 1e-5, (early, b)
+    assert all(rms(a, c) <= 1e-5 for a, c in zip(out[True], out[False]))
+    assert any(not np.array_equal(a, c) for a, c in zip(out[True], out[False]))  # (the two forms really are different code)
+
+
 @pytest.mark.parametrize("form", ["2", "1"])
 def test_lost_attention_block_falls_back(pkg, orc, blob, capfd, form):
     """The blocks of a chunk wait for each other's partial energies inside one launch.  With one block never

@@ -180,6 +180,9 @@ struct xdtts_tacotron2 {
   bool att_demoted = false;
   int att_demoted_calls = 0;
   int att_fused = att_fused_default();  // 2: with the attention LSTM in the same launch, 1: attention alone, 0: two kernels
+  // XDTTS_NO_EARLY (read when a handle is created): the attention launch multiplies its whole K instead of adding the early
+  // partial of the previous decoder-LSTM launch (second form of the same arithmetic for the agreement test; results agree to 1e-5)
+  bool early_partial = getenv("XDTTS_NO_EARLY") == nullptr;
   int persist_state = -1;                   // -1 unknown, 0 unavailable on this device / demoted, 1 usable
   bool persist_probe_ok = false;            // the device can host the persistent grid (occupancy probe)
   bool coop_ok = true;                      // cooperative encoder BiLSTM usable (cleared after a timed-out exchange)
@@ -408,8 +411,7 @@ struct xdtts_tacotron2 {
         // ... and the attention LSTM in the same launch: its 256 blocks of 512 threads must be resident together, one per CU
         if (att_fused > 1 && B <= 64 && n_cu >= ATT_RNN / 4) {
           d.hg = att_exchange.p + ne;
-          static const bool no_early = getenv("XDTTS_NO_EARLY") != nullptr;  // developer comparison aid: the attention launch runs its whole K
-          if (!no_early) {  // early partial of the attention-LSTM GEMM, computed inside the prenet launch (kernels.h)
+          if (early_partial) {  // early partial of the attention-LSTM GEMM, computed by extra blocks of the decoder-LSTM launch (kernels.h)
             att_part.alloc((size_t)(ATT_RNN / 4) * 4 * 64 * 4);
             d.att_part = att_part.p;
           }

@@ -884,13 +884,19 @@ __device__ __forceinline__ void lstm_mfma_pass(const DecoderBufs &d, int n0, int
 
 // ---- early partial of the attention-LSTM GEMM (DecoderBufs::att_part) ----------------------------------------------------
 // Of the 1792 columns the attention LSTM of step s+1 multiplies, only the 256 prenet columns x(s+1) are new when its launch
-// starts: the context and its own hidden state of step s are complete when the attention launch of step s ends.  256 extra
-// blocks of the DECODER-LSTM launch of step s -- two 512-thread blocks of this kernel fit a CU, and its own blocks leave the
-// matrix cores idle at entry, while they wait for their last wave and in the cell update -- multiply those 1536 columns (86 %
-// of the pass, 25 of its 29 MB of weights): block blk = the 16 gate rows of LSTM block blk, its 8 waves take 12 k-steps (of 16
-// columns) each, operands as in lstm_mfma_pass (weights in A-fragment order, activations from the [K/4][Bpad][4] copies).
-// The 8 partial accumulators meet in LDS in a fixed order and leave as [blk][tile][lane] float4 = the D layout the cell-update
-// waves of the attention launch hold, which add them to their own 256-column product.  `hcur`: half of att_hf that holds h_att(s).
+// starts: the context and its own hidden state of step s are complete when the attention launch of step s ends, so those
+// 1536 columns (86 % of the pass, 25 of its 29 MB of weights) are multiplied one launch early -- inside a decode by 256 extra
+// blocks of the decoder-LSTM launch of step s (two 512-thread blocks of k_lstm_mfma fit a CU, and its own blocks leave the
+// matrix cores idle at entry, while they wait for their last wave and in the cell update); at the start of a sequence that
+// begins from caller-held state by the stand-alone k_att_early.  Block blk = the 16 gate rows of LSTM block blk, its 8 waves
+// take 12 k-steps (of 16 columns) each, operands as in lstm_mfma_pass (weights in A-fragment order, activations from the
+// [K/4][Bpad][4] copies).  The 8 partial accumulators meet in LDS in a fixed order and leave as [blk][tile][lane] float4 = the
+// D layout the cell-update waves of the attention launch hold, which add them to their own 256-column product.  `hcur`: half
+// of att_hf that holds h_att(s).  The attention launch shrinks by 6.2 us (its pass is 2 k-steps per wave), the decoder-LSTM
+// launch grows by 5.3 (configs[2], rocprofv3).  Measured against it and rejected: the same 256 blocks inside the PRENET launch
+// (its 1024-thread blocks hold 128 VGPRs: ONE block per CU, so the two roles ran one after the other, 14.4 us); ONE block per
+// CU that feeds the shared operand [h_att ; ctx] to both weight slabs (k-loop of 12 + 8 k-steps per wave, activation reads
+// 214 -> 139 MB per iteration: 39.9 us per iteration against 36.4, with 16 waves 42.0); see DESIGN.md, Appendix A.
 #ifdef XDTTS_LSTM_PROBE
 __device__ __forceinline__ unsigned hw_place() {  // (xcc << 16) | HW_ID: which CU a block landed on
   unsigned xcc, hw;
@@ -994,6 +1000,7 @@ __global__ __launch_bounds__(64 * MFMA_WAVES) void k_att_early(DecoderBufs d, in
   att_early_role(d, d.ctl[0] + i, i & 1, blockIdx.x, att_wm, s_acc, 0);
 }
 
+
 template <int NCOLS, int KIND>
 __global__ __launch_bounds__(64 * MFMA_WAVES) void k_lstm_mfma(DecoderBufs d, int i, int cur, const float4 *__restrict__ Wm,
                                                                const float *__restrict__ bias, const float4 *__restrict__ Wepi,
@@ -1005,7 +1012,10 @@ __global__ __launch_bounds__(64 * MFMA_WAVES) void k_lstm_mfma(DecoderBufs d, in
   const unsigned long long t_entry = 0;
 #endif
   __shared__ __attribute__((aligned(16))) float s_acc[NW * 4 * 64 * 4];  // [K-slice][tile][lane][gate]
-  if (KIND == 1 && (int)blockIdx.x >= NBLK) {  // blocks 256..511 of a decoder-LSTM launch with d.att_part: the NEXT step's early partial
+  // Blocks 256..511 of a decoder-LSTM launch with the early role: the NEXT step's attention-LSTM partial (att_early_partial).
+  // Two 512-thread blocks of this kernel fit a CU; which role's blocks are dispatched first, and s_setprio for either role,
+  // measured the same to 0.1 us per iteration.
+  if (KIND == 1 && (int)blockIdx.x >= NBLK) {
     att_early_role(d, d.ctl[0] + i + 1, cur ^ 1, (int)blockIdx.x - NBLK, att_wm, s_acc, t_entry);  // (this step's attention launch wrote h_att into half cur ^ 1)
     return;
   }
@@ -1672,9 +1682,9 @@ static void enqueue_steps(const DecoderBufs &d, const DeviceWeights &w, int i0, 
           hipLaunchKernelGGL(k_softmax_ctx, dim3(CTX_BLOCKS * d.B), dim3(256), 0, s, d, i, w.proj_wc.p);
           break;
         case 'd':
-          if (batched) {
+          if (batched) {  // (early: 256 more blocks multiply the next attention-LSTM pass's 1536 known columns)
             hipLaunchKernelGGL((k_lstm_mfma<DEC_COLS, 1>), dim3(early ? 2 * NBLK : NBLK, (d.B + 63) / 64), dim3(64 * MFMA_WAVES), 0, s, d, i, cur, dec_wm, w.dec_b.p, wh4,
-                               att_wm);  // (early: blocks 256..511 multiply the next attention-LSTM pass's 1536 known columns)
+                               att_wm);
           } else
             hipLaunchKernelGGL((k_lstm<DEC_COLS, 1>), dim3(loc_tiles * d.B + NBLK), dim3(256), 0, s, d, i, cur, dec_w,
                                w.dec_b.p, wh4, w.loc_conv.p, w.loc_denseT.p);
