@@ -170,6 +170,7 @@ struct xdtts_tacotron2 {
   DevBuf<int> dec_err;
   DevBuf<unsigned long long> att_exchange;
   DevBuf<float> att_part;  // early partial pre-activations of the attention LSTM (DecoderBufs::att_part)
+  DevBuf<unsigned long long> tail_exchange;  // two-launch form: h_dec and mel granules (DecoderBufs::hdg, melg)
   // batched mode: energies, softmax and context in one launch (XDTTS_ATT_FUSED=0: the two-kernel form; also after
   // an exchange of that launch timed out)
   static int att_fused_default() {
@@ -183,6 +184,7 @@ struct xdtts_tacotron2 {
   // XDTTS_NO_EARLY (read when a handle is created): the attention launch multiplies its whole K instead of adding the early
   // partial of the previous decoder-LSTM launch (second form of the same arithmetic for the agreement test; results agree to 1e-5)
   bool early_partial = getenv("XDTTS_NO_EARLY") == nullptr;
+  bool two_launch = getenv("XDTTS_NO_TAIL") == nullptr;  // (XDTTS_NO_TAIL: keep the prenet launch; read when a handle is created)
   int persist_state = -1;                   // -1 unknown, 0 unavailable on this device / demoted, 1 usable
   bool persist_probe_ok = false;            // the device can host the persistent grid (occupancy probe)
   bool coop_ok = true;                      // cooperative encoder BiLSTM usable (cleared after a timed-out exchange)
@@ -414,6 +416,11 @@ struct xdtts_tacotron2 {
           if (early_partial) {  // early partial of the attention-LSTM GEMM, computed by extra blocks of the decoder-LSTM launch (kernels.h)
             att_part.alloc((size_t)(ATT_RNN / 4) * 4 * 64 * 4);
             d.att_part = att_part.p;
+            if (two_launch && T <= PERSIST_T_MAX) {  // ... and the prenet as the tail of that launch (h_dec / mel cross as granules)
+              tail_exchange.alloc((size_t)B * (DEC_RNN + 96));
+              d.hdg = tail_exchange.p;
+              d.melg = d.hdg + (size_t)B * DEC_RNN;
+            }
           }
         }
         if (const char *sp = getenv("XDTTS_ATT_SPINS")) d.att_spins = atoi(sp);  // test hooks for the
@@ -479,6 +486,7 @@ struct xdtts_tacotron2 {
   int run_decoder(const DecoderBufs &d, const std::vector<int> &lim) {
     limits.upload(lim.data(), lim.size(), stream);
     launch_decoder_init(d, limits.p, stream);
+    launch_decoder_prologue(d, w, stream);
     const int max_lim = *std::max_element(lim.begin(), lim.end());
     int launched = 0;
     auto fetch = [&]() {
@@ -656,6 +664,7 @@ struct xdtts_tacotron2 {
         d2.ep_g = nullptr;
         d2.hg = nullptr;
         d2.att_part = nullptr;
+        d2.hdg = d2.melg = nullptr;
         return run_decoder(d2, lim);
       }
     }
@@ -1598,6 +1607,7 @@ xdtts_status xdtts_tacotron2_decoder_steps(xdtts_tacotron2 *h, int32_t engine, i
       if (d.hg) chip = std::unique_lock<std::recursive_mutex>(chip_mutex(h->device));
       if (engine == 0) launch_decoder_location(d, h->w, st);  // (the batched prenet launch computes them itself)
       launch_decoder_early(d, h->w, 0, st);  // (batched engine: the first attention-LSTM pass's early partial, from the imported state)
+      launch_decoder_prologue(d, h->w, st);  // (two-launch form: x and location features of the first step; d.dec_in = decoder_input)
       for (int i = 0; i < n_steps; ++i) {
         launch_decoder_step_at(d, h->w, i, st);
         d.dec_in = nullptr;  // from the second step on the loop feeds itself

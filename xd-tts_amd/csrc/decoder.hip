@@ -356,8 +356,10 @@ __device__ __forceinline__ void location_blocks(const DecoderBufs &d, int i, int
 // rides with).  Operands come from LDS: lane l of an A fragment is (row l % 16, k l / 16), of a B fragment
 // (k l / 16, column l % 16); a D register r of lane l is (row 4 (l / 16) + r, column l % 16).
 constexpr int LOC_MFMA_T = 128;
+template <int NWV = PRENET_BT / 64>  // waves of the block: 16 inside the prenet launch, 8 inside the decoder-LSTM launch (two-launch form)
 __device__ __forceinline__ void location_chunk_mfma(const DecoderBufs &d, int i, int lb, const float *__restrict__ loc_convT,
                                                     const float *__restrict__ loc_denseT) {
+  static_assert(NWV == 8 || NWV == 16, "conv: one (time tile, filter half) per wave 0..7; dense: 32 / NWV time tiles per wave");
   const int b = lb >> 1, half = lb & 1;  // two blocks per chunk: time tiles 0..3 and 4..7
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   constexpr int PADK = (LOC_K - 1) / 2, KC = 64;  // conv contraction: 2 x 31 taps, padded to 64
@@ -368,7 +370,7 @@ __device__ __forceinline__ void location_chunk_mfma(const DecoderBufs &d, int i,
   const bool act = step < d.nframes[b];
   const float *aw = d.aw + b * T, *awc = ((i & 1) ? d.awc2 : d.awc) + b * T;  // weights of step s-1 (cumulative: ping-pong by parity)
   constexpr int SZ = LOC_MFMA_T + 2 * PADK + 2;
-  for (int k = tid; k < 2 * SZ; k += PRENET_BT) {
+  for (int k = tid; k < 2 * SZ; k += 64 * NWV) {
     const int c = k / SZ, t = k % SZ - PADK;
     s_aw[c][t + PADK] = (t >= 0 && t < T) ? (c ? awc[t] : aw[t]) : 0.f;  // zero-padded: channel 0 = previous weights, 1 = cumulative
   }
@@ -389,7 +391,7 @@ __device__ __forceinline__ void location_chunk_mfma(const DecoderBufs &d, int i,
   __syncthreads();
   if (!act) return;  // (block-uniform)
   // ---- conv: (time tile mt, filter tile nt) per wave ----
-  for (int tp = wave; tp < 8; tp += PRENET_BT / 64) {  // (waves 0..7)
+  for (int tp = wave; tp < 8; tp += NWV) {  // (waves 0..7)
     const int mt = 4 * half + (tp >> 1), nt = tp & 1;
     if (mt >= MT) continue;
     f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;  // two chains: a dependent MFMA waits ~40 cycles
@@ -407,8 +409,8 @@ __device__ __forceinline__ void location_chunk_mfma(const DecoderBufs &d, int i,
   // ---- dense: (time tile mt, dim tile nt = wave % 8) per wave; the wave's eight B fragments stay in registers ----
   {
     const int nt = wave & 7;
-    // its two time tiles mt = 4 half + wave / 8 + 2 j side by side: independent accumulator chains
-    constexpr int NJ = 2;
+    // its time tiles mt = 4 half + wave / 8 + (NWV / 8) j side by side: independent accumulator chains
+    constexpr int NJ = 32 / NWV;
     f32x4 acc[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -416,14 +418,14 @@ __device__ __forceinline__ void location_chunk_mfma(const DecoderBufs &d, int i,
     for (int ks = 0; ks < LOC_F / 4; ++ks)
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        const int mt = 4 * half + (wave >> 3) + 2 * j;  // (rows past the chunk's tiles hold stale LDS; their results are dropped)
+        const int mt = 4 * half + (wave >> 3) + (NWV / 8) * j;  // (rows past the chunk's tiles hold stale LDS; their results are dropped)
         acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(s_lc[16 * mt + fi][4 * ks + fg], bw[ks], acc[j], 0, 0, 0);
       }
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int t = 16 * (4 * half + (wave >> 3) + 2 * j) + 4 * fg + r;
+        const int t = 16 * (4 * half + (wave >> 3) + (NWV / 8) * j) + 4 * fg + r;
         if (t < T) d.loc[(((size_t)b * (ATT_DIM / 4) + 4 * nt + (fi >> 2)) * T + t) * 4 + (fi & 3)] = acc[j][r];  // batched layout [B][32][T][4]
       }
   }
@@ -708,6 +710,40 @@ __global__ __launch_bounds__(256) void k_lstm(DecoderBufs d, int i, int cur, con
 // software-pipelined three k-steps deep so that L2 latency hides behind the other tiles' MFMAs.
 // Tiles whose 16 chunks have all stopped are skipped (the batch is sorted by length, so the active
 // tiles form a prefix): NTA = active tiles of this pass, a compile-time count per code path.
+// tagged 8-byte granules {tag = step + 1, value}: the in-launch exchanges of the batched kernels (comments at k_attention_b)
+typedef unsigned long long u64;
+constexpr unsigned AB_SPIN_LIMIT = 1u << 20;
+__device__ __forceinline__ void granule_store(u64 *slot, unsigned tag, float v) {
+  __hip_atomic_store(slot, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// N granules at base[idx + k * stride], polled together until every tag equals `want`; a timed-out slot reads as 0.0f
+template <int N>
+__device__ __forceinline__ void granule_gather(const u64 *base, size_t idx, size_t stride, unsigned want, float (&out)[N], int *err,
+                                               unsigned limit) {
+  unsigned pending = (1u << N) - 1u, spins = 0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) out[k] = 0.f;
+  while (pending) {
+    u64 g[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+      if (pending >> k & 1u) g[k] = __hip_atomic_load(base + idx + (size_t)k * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+      if ((pending >> k & 1u) && (unsigned)(g[k] >> 32) == want) {
+        out[k] = __uint_as_float((unsigned)g[k]);
+        pending &= ~(1u << k);
+      }
+    if (pending) {
+      if (++spins > limit || ((spins & 127u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+        atomicExch(err, 1);
+        return;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+}
+
 struct NoHook {
   __device__ __forceinline__ void operator()() const {}
 };
@@ -715,7 +751,9 @@ struct NoHook {
 // attention-LSTM launch puts the loads of its attention phase there, behind nothing the LSTM pass still waits for
 // C0 / CN: the pass multiplies columns [C0, C0 + CN) only (wsrc points at the wave's first k-step of that range) and, with
 // PART, adds the early partial of the remaining columns (DecoderBufs::att_part) in the cell-update waves.
-template <int NCOLS, int KIND, int NTA, class Hook = NoHook, int C0 = 0, int CN = NCOLS, bool PART = false>
+// TAIL (decoder LSTM, two-launch form): h_dec leaves as granules d.hdg for the chunk's projection / prenet blocks of the same
+// launch (dec_tail_chunk) instead of the partial-mel rows the prenet launch would sum.
+template <int NCOLS, int KIND, int NTA, class Hook = NoHook, int C0 = 0, int CN = NCOLS, bool PART = false, bool TAIL = false>
 __device__ __forceinline__ void lstm_mfma_pass(const DecoderBufs &d, int n0, int cur, int step, int blk, const float4 *__restrict__ wsrc,
                                                const float4 bz, const float (&wa)[6], float *s_acc, unsigned long long active,
                                                unsigned long long d_probe_entry = 0, Hook after_loop = Hook()) {  // active: bit j = chunk n0 + j still runs at this step
@@ -855,9 +893,10 @@ __device__ __forceinline__ void lstm_mfma_pass(const DecoderBufs &d, int n0, int
             h_out[(size_t)n * ATT_RNN + unit] = hn;
         }
         hf_out[((size_t)blk * d.Bpad + n) * 4 + fg] = hn;
+        if (TAIL) granule_store(d.hdg + (size_t)n * DEC_RNN + unit, (unsigned)step + 1u, hn);
       }
     }
-    if (KIND == 1) {
+    if (KIND == 1 && !TAIL) {
       // Partial mel of this block's four hidden units, pm[m][chunk] = sum_u W_p[m][4 blk + u] h[chunk][u], on the matrix cores: the lane
       // that has just produced h of (chunk fi, unit fg) holds exactly the B fragment of a 16x16x4 MFMA (k = unit, column = chunk); the A
       // fragments -- W_p[16 rt + fi][4 blk + fg], six 16-row tiles -- were fetched at kernel entry.  D register r of the lane is mel row
@@ -1001,10 +1040,162 @@ __global__ __launch_bounds__(64 * MFMA_WAVES) void k_att_early(DecoderBufs d, in
 }
 
 
+
+struct TailWeights {  // what the two-launch form's extra roles of the decoder-LSTM launch read
+  const float4 *proj_w4;  // [81][1536] rows of [W_p ; w_gate]
+  const float *proj_b, *W0T, *W1T, *loc_convT, *loc_denseT;
+};
+// ---- two-launch form: projection, stop rule and prenet as the tail of the decoder-LSTM launch ---------------------------------
+// What made the prenet its own launch is the projection: mel(s) needs ALL of h_dec(s).  As with h_att in the attention launch,
+// that vector is small enough to cross inside the launch: the 256 decoder-LSTM blocks publish their four units of every chunk as
+// granules (d.hdg), and blocks 4 b .. 4 b + 3 then turn into chunk b's tail blocks -- gather h_dec(b), 21 / 20 rows of
+// [W_p ; w_gate] each (row m = part + 4 r; the context columns against d.ctx of this step's attention launch), exchange the 81
+// values (d.melg), frame / gate store and stop rule (mod.rs:319-324, block 0), prenet layer 1 (all 256 outputs, every block) and
+// 64 columns of layer 2 -> x(s + 1) and its B-operand copy.  lds: 1024 + 512 + 96 + 8 x 256 + 256 + 32 x 64 floats.
+constexpr int TAIL_PARTS = 4, TAIL_NT = 64 * MFMA_WAVES;
+constexpr int TAIL_LDS_FLOATS = DEC_RNN + EMB + 96 + (TAIL_NT / 64) * PRENET + PRENET + (TAIL_NT / (PRENET / TAIL_PARTS / 4)) * (PRENET / TAIL_PARTS);
+__device__ __forceinline__ void dec_tail_chunk(const DecoderBufs &d, int step, int b, int part, float *lds, const float4 *__restrict__ proj_w4,
+                                               const float *__restrict__ proj_b, const float *__restrict__ W0T, const float *__restrict__ W1T) {
+  constexpr int NT = TAIL_NT, NWV = NT / 64, COLS2 = PRENET / TAIL_PARTS;  // 64 layer-2 columns per block
+  constexpr int KG1 = NT / 64, IN1 = N_MEL / KG1;                          // layer 1: 8 input groups of 10
+  constexpr int KG2 = NT / (COLS2 / 4), IN2 = PRENET / KG2;                // layer 2: 32 input groups of 8
+  static_assert(N_MEL % KG1 == 0 && PRENET % KG2 == 0 && (DEC_RNN + EMB) % 256 == 0, "tail mappings");
+  float *s_h = lds, *s_c = s_h + DEC_RNN, *s_mel = s_c + EMB, *s_p1 = s_mel + 96, *s_x1 = s_p1 + KG1 * PRENET, *s_p2 = s_x1 + PRENET;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned want = (unsigned)step + 1u, spin_limit = d.att_spins > 0 ? (unsigned)d.att_spins : AB_SPIN_LIMIT;
+#ifdef XDTTS_LSTM_PROBE
+  unsigned long long tq[8];
+  tq[0] = wall_clock64();
+#define TPROBE(i) tq[i] = wall_clock64()
+#else
+#define TPROBE(i) do { } while (0)
+#endif
+  // the wave's three projection rows (18 KB) do not depend on h_dec: in flight while it is gathered (issued behind the gather,
+  // row by row, the phase measured 2.4 - 4 us: three exposed round trips through an L1 the co-resident early block is filling)
+  constexpr int C4 = (DEC_RNN + EMB) / 4 / 64;  // 6 vectors per lane and row
+  float4 wv[3][C4];
+#pragma unroll
+  for (int rr = 0; rr < 3; ++rr) {
+    const int m = min(part + TAIL_PARTS * (wave + NWV * rr), N_MEL);  // (clamped: unconditional loads)
+    const float4 *wr = proj_w4 + (size_t)m * ((DEC_RNN + EMB) / 4);
+#pragma unroll
+    for (int k = 0; k < C4; ++k) wv[rr][k] = wr[lane + 64 * k];
+  }
+  asm volatile("" ::: "memory");
+  // ---- h_dec(b) from the 256 LSTM blocks of this launch, ctx(b) from the attention launch ----
+  {
+    float g[DEC_RNN / NT];
+    granule_gather<DEC_RNN / NT>(d.hdg, (size_t)b * DEC_RNN + tid, NT, want, g, d.att_err, spin_limit);
+#pragma unroll
+    for (int k = 0; k < DEC_RNN / NT; ++k) s_h[tid + NT * k] = g[k];
+    s_c[tid] = d.ctx[b * EMB + tid];
+  }
+  __syncthreads();
+  TPROBE(1);
+  // ---- projection rows m = part + 4 r, r = wave, wave + 8, wave + 16: lane takes float4 columns lane + 64 k of the 384 ----
+  {
+    float4 hv[C4];
+#pragma unroll
+    for (int k = 0; k < C4; ++k) hv[k] = *reinterpret_cast<const float4 *>(s_h + 4 * (lane + 64 * k));  // (s_c follows s_h)
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) {
+      const int m = part + TAIL_PARTS * (wave + NWV * rr);
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < C4; ++k) a = dot4(wv[rr][k], hv[k], a);
+      a = wave_sum(a);
+      if (lane == 0 && m <= N_MEL) granule_store(d.melg + (size_t)b * 96 + m, want, a + proj_b[m]);
+    }
+  }
+  TPROBE(2);
+  // the prenet weights of this thread, in flight while the mel crosses
+  const int o4 = tid & 63, kg1 = tid >> 6;
+  const int c4 = tid % (COLS2 / 4), kg2 = tid / (COLS2 / 4);
+  float4 w0[IN1], w1[IN2];
+#pragma unroll
+  for (int k = 0; k < IN1; ++k) w0[k] = reinterpret_cast<const float4 *>(W0T)[(size_t)(kg1 * IN1 + k) * (PRENET / 4) + o4];
+#pragma unroll
+  for (int k = 0; k < IN2; ++k) w1[k] = reinterpret_cast<const float4 *>(W1T)[((size_t)(kg2 * IN2 + k) * PRENET + COLS2 * part) / 4 + c4];
+  if (tid <= N_MEL) {
+    float g[1];
+    granule_gather<1>(d.melg, (size_t)b * 96 + tid, 0, want, g, d.att_err, spin_limit);
+    s_mel[tid] = g[0];
+  }
+  __syncthreads();
+  TPROBE(3);
+  const float gate = s_mel[N_MEL];
+  const bool fired = d.use_gate && gate_sigmoid(gate) > d.gate_threshold;
+  const int nf = d.nframes[b];
+  if (part == 0) {
+    if (tid < N_MEL) d.frames[((size_t)b * d.max_steps + step) * N_MEL + tid] = s_mel[tid];
+    if (tid == 0) {
+      d.gates[(size_t)b * d.max_steps + step] = gate;
+      if (fired) d.nframes[b] = step + 1;  // frame `step` is the last one (mod.rs:319-324: the tripping frame is kept)
+    }
+  }
+  if (fired || step + 1 >= nf) return;  // (block-uniform) the chunk stops here: no x(s + 1)
+  const int chunk = d.item_perm ? d.item_perm[b] : b;
+  const uint32_t item = d.item_base + (uint32_t)chunk;
+  // ---- prenet layer 1 (every block, all 256 outputs) ----
+  {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < IN1; ++k) {
+      const float m = s_mel[kg1 * IN1 + k];
+      acc.x = fmaf(w0[k].x, m, acc.x);
+      acc.y = fmaf(w0[k].y, m, acc.y);
+      acc.z = fmaf(w0[k].z, m, acc.z);
+      acc.w = fmaf(w0[k].w, m, acc.w);
+    }
+    *reinterpret_cast<float4 *>(s_p1 + kg1 * PRENET + 4 * o4) = acc;
+  }
+  __syncthreads();
+  if (tid < PRENET) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < KG1; ++k) v += s_p1[k * PRENET + tid];
+    v = fmaxf(v, 0.f);
+    if (d.dropout_mode) v = prenet_dropped(d.dropout_mode, d.dropout_seed, item, d.drop_masks, d.drop_steps, chunk, step + 1, 0, tid) ? 0.f : 2.f * v;
+    s_x1[tid] = v;
+  }
+  __syncthreads();
+  TPROBE(4);
+  // ---- prenet layer 2, this block's 64 columns ----
+  {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < IN2; ++k) {
+      const float m = s_x1[kg2 * IN2 + k];
+      acc.x = fmaf(w1[k].x, m, acc.x);
+      acc.y = fmaf(w1[k].y, m, acc.y);
+      acc.z = fmaf(w1[k].z, m, acc.z);
+      acc.w = fmaf(w1[k].w, m, acc.w);
+    }
+    *reinterpret_cast<float4 *>(s_p2 + kg2 * COLS2 + 4 * c4) = acc;
+  }
+  __syncthreads();
+  if (tid < COLS2) {
+    float o = 0.f;
+#pragma unroll
+    for (int k = 0; k < KG2; ++k) o += s_p2[k * COLS2 + tid];
+    o = fmaxf(o, 0.f);
+    const int j = COLS2 * part + tid;
+    if (d.dropout_mode) o = prenet_dropped(d.dropout_mode, d.dropout_seed, item, d.drop_masks, d.drop_steps, chunk, step + 1, 1, j) ? 0.f : 2.f * o;
+    d.x[b * PRENET + j] = o;
+    d.xf[((size_t)(j >> 2) * d.Bpad + b) * 4 + (j & 3)] = o;
+  }
+#ifdef XDTTS_LSTM_PROBE
+  TPROBE(5);
+  if (tid == 0 && step == 100 && (b == 0 || b == 17 || b == 40) && part == 0)
+    printf("probe tail chunk %d step %d: entry %llu  h gathered %llu  rows + publish %llu  mel gathered %llu  layer 1 %llu  layer 2 + store %llu (x10ns)\n", b, step,
+           tq[0] % 100000ull, tq[1] - tq[0], tq[2] - tq[1], tq[3] - tq[2], tq[4] - tq[3], tq[5] - tq[4]);
+#endif
+}
+
 template <int NCOLS, int KIND>
 __global__ __launch_bounds__(64 * MFMA_WAVES) void k_lstm_mfma(DecoderBufs d, int i, int cur, const float4 *__restrict__ Wm,
                                                                const float *__restrict__ bias, const float4 *__restrict__ Wepi,
-                                                               const float4 *__restrict__ att_wm) {
+                                                               const float4 *__restrict__ att_wm, TailWeights tw) {
   constexpr int NW = MFMA_WAVES, KW = NCOLS / NW, JJ = KW / 16;
 #ifdef XDTTS_LSTM_PROBE
   const unsigned long long t_entry = wall_clock64();
@@ -1016,7 +1207,20 @@ __global__ __launch_bounds__(64 * MFMA_WAVES) void k_lstm_mfma(DecoderBufs d, in
   // Two 512-thread blocks of this kernel fit a CU; which role's blocks are dispatched first, and s_setprio for either role,
   // measured the same to 0.1 us per iteration.
   if (KIND == 1 && (int)blockIdx.x >= NBLK) {
-    att_early_role(d, d.ctl[0] + i + 1, cur ^ 1, (int)blockIdx.x - NBLK, att_wm, s_acc, t_entry);  // (this step's attention launch wrote h_att into half cur ^ 1)
+    const int e = (int)blockIdx.x - NBLK;
+    att_early_role(d, d.ctl[0] + i + 1, cur ^ 1, e, att_wm, s_acc, t_entry);  // (this step's attention launch wrote h_att into half cur ^ 1)
+    // two-launch form: the first 2 B early blocks also compute the next step's location features (the prenet launch's location role)
+    // two-launch form: the next step's location features (the prenet launch's location role, 2 units per chunk): one unit each for
+    // the decoder-LSTM blocks that are no chunk's tail (below), the rest behind the partial of the LAST early blocks (the first
+    // ones share their CUs with tail blocks: 0.3 us per iteration slower; three units per free block: 0.6 us slower at 52 chunks)
+    if (d.hdg) {
+      const int nfree = NBLK - TAIL_PARTS * d.B, ne = max(0, 2 * d.B - nfree);
+      if (e >= NBLK - ne) location_chunk_mfma<MFMA_WAVES>(d, i + 1, nfree + e - (NBLK - ne), tw.loc_convT, tw.loc_denseT);
+    }
+#ifdef XDTTS_LSTM_PROBE
+    if (threadIdx.x == 0 && d.ctl[0] + i == 100 && (e == 3 || e == 100 || e == 200))
+      printf("probe early+loc blk %d: entry %llu  end %llu (x10ns)\n", e, t_entry % 100000ull, wall_clock64() % 100000ull);
+#endif
     return;
   }
   const int blk = blockIdx.x;
@@ -1034,6 +1238,25 @@ __global__ __launch_bounds__(64 * MFMA_WAVES) void k_lstm_mfma(DecoderBufs d, in
   for (int rt = 0; rt < 6; ++rt) {
     const int mrow = 16 * rt + (lane & 15);
     wa[rt] = (KIND == 1 && wave < 4 && mrow < MEL_LD) ? reinterpret_cast<const float *>(Wepi)[((size_t)blk * MEL_LD + mrow) * 4 + fg] : 0.f;
+  }
+  if (KIND == 1 && d.hdg) {  // two-launch form: h_dec as granules, then the chunk's projection / prenet tail
+    switch (nta) {
+      case 1: lstm_mfma_pass<NCOLS, KIND, 1, NoHook, 0, NCOLS, false, KIND == 1>(d, n0, cur, step, blk, wsrc, bz, wa, s_acc, m, t_entry); break;
+      case 2: lstm_mfma_pass<NCOLS, KIND, 2, NoHook, 0, NCOLS, false, KIND == 1>(d, n0, cur, step, blk, wsrc, bz, wa, s_acc, m, t_entry); break;
+      case 3: lstm_mfma_pass<NCOLS, KIND, 3, NoHook, 0, NCOLS, false, KIND == 1>(d, n0, cur, step, blk, wsrc, bz, wa, s_acc, m, t_entry); break;
+      case 4: lstm_mfma_pass<NCOLS, KIND, 4, NoHook, 0, NCOLS, false, KIND == 1>(d, n0, cur, step, blk, wsrc, bz, wa, s_acc, m, t_entry); break;
+      default: return;
+    }
+    const int b = blk >> 2;
+    static_assert(TAIL_LDS_FLOATS <= NW * 4 * 64 * 4, "the tail reuses the accumulator exchange area");
+#ifdef XDTTS_LSTM_PROBE
+    if (threadIdx.x == 0 && step == 100 && (blk == 0 || blk == 68 || blk == 160 || blk == 250))
+      printf("probe D blk %d: entry %llu  pass done %llu (x10ns)\n", blk, t_entry % 100000ull, wall_clock64() % 100000ull);
+#endif
+    if (b < d.B && step < d.nframes[b]) dec_tail_chunk(d, step, b, blk & 3, s_acc, tw.proj_w4, tw.proj_b, tw.W0T, tw.W1T);
+    if (blk >= TAIL_PARTS * d.B && blk - TAIL_PARTS * d.B < 2 * d.B)  // free after the pass: one location unit, done well inside the tails' time
+      location_chunk_mfma<MFMA_WAVES>(d, i + 1, blk - TAIL_PARTS * d.B, tw.loc_convT, tw.loc_denseT);
+    return;
   }
   switch (nta) {
     case 1: lstm_mfma_pass<NCOLS, KIND, 1>(d, n0, cur, step, blk, wsrc, bz, wa, s_acc, m, t_entry); break;
@@ -1265,39 +1488,6 @@ __global__ __launch_bounds__(256) void k_softmax_ctx(DecoderBufs d, int i, const
 // agent-scope (sc1) accesses, no fence, no counter.  Every block publishes before it polls, the blocks of a chunk are
 // neighbours in dispatch order, so the wait is short; a bounded spin sets d.att_err instead of hanging (the host
 // then decodes the request again with the two-kernel form, api.cpp).  Chunks that have stopped are skipped.
-typedef unsigned long long u64;
-constexpr unsigned AB_SPIN_LIMIT = 1u << 20;
-__device__ __forceinline__ void granule_store(u64 *slot, unsigned tag, float v) {
-  __hip_atomic_store(slot, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// N granules at base[idx + k * stride], polled together until every tag equals `want`; a timed-out slot reads as 0.0f
-template <int N>
-__device__ __forceinline__ void granule_gather(const u64 *base, size_t idx, size_t stride, unsigned want, float (&out)[N], int *err,
-                                               unsigned limit) {
-  unsigned pending = (1u << N) - 1u, spins = 0;
-#pragma unroll
-  for (int k = 0; k < N; ++k) out[k] = 0.f;
-  while (pending) {
-    u64 g[N];
-#pragma unroll
-    for (int k = 0; k < N; ++k)
-      if (pending >> k & 1u) g[k] = __hip_atomic_load(base + idx + (size_t)k * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-    for (int k = 0; k < N; ++k)
-      if ((pending >> k & 1u) && (unsigned)(g[k] >> 32) == want) {
-        out[k] = __uint_as_float((unsigned)g[k]);
-        pending &= ~(1u << k);
-      }
-    if (pending) {
-      if (++spins > limit || ((spins & 127u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-        atomicExch(err, 1);
-        return;
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
-  }
-}
-
 // Every global load of the attention phase that does not depend on this step's attention-LSTM output, issued in the
 // order the values are needed (vmcnt retires in issue order).
 struct AttentionLoads {
@@ -1598,6 +1788,7 @@ void launch_decoder_init(const DecoderBufs &d, const int *limits_dev, hipStream_
   if (d.ep_g) HIP_CHECK(hipMemsetAsync(d.ep_g, 0, sizeof(unsigned long long) * (size_t)d.B * CTX_BLOCKS * d.T, s));  // step tags restart at 1
   if (d.hg) HIP_CHECK(hipMemsetAsync(d.hg, 0, sizeof(unsigned long long) * (size_t)d.B * ATT_RNN, s));
   if (d.att_part) HIP_CHECK(hipMemsetAsync(d.att_part, 0, sizeof(float) * (size_t)NBLK * 4 * 64 * 4, s));  // step 0: context and hidden state are zero
+  if (d.hdg) HIP_CHECK(hipMemsetAsync(d.hdg, 0, sizeof(unsigned long long) * (size_t)d.B * (DEC_RNN + 96), s));  // (melg follows hdg)
   hipLaunchKernelGGL(k_decoder_init, dim3(d.B), dim3(256), 0, s, d, limits_dev);
   HIP_CHECK(hipGetLastError());
 }
@@ -1624,6 +1815,15 @@ void launch_decoder_early(const DecoderBufs &d, const DeviceWeights &w, int i, h
   hipLaunchKernelGGL(k_att_early, dim3(NBLK), dim3(64 * MFMA_WAVES), 0, s, d, i, reinterpret_cast<const float4 *>(w.att_wm.p));
   HIP_CHECK(hipGetLastError());
 }
+// Two-launch form: the exchange buffers exist, the MFMA location role serves T, the fused attention launch is on
+bool decoder_two_launch(const DecoderBufs &d) { return d.hdg && d.melg && d.att_part && d.xf && d.ep_g && d.hg && d.B <= 64 && d.T <= LOC_MFMA_T; }
+// ... its sequence start: x and the location features of the first step (node 0) by the prenet launch; every later step's come
+// from the tail / the early blocks of the previous decoder-LSTM launch.  No-op in the three-launch form.
+void launch_decoder_prologue(const DecoderBufs &d, const DeviceWeights &w, hipStream_t s) {
+  if (!(decoder_two_launch(d) && w.att_wm.p && w.dec_wm.p)) return;
+  hipLaunchKernelGGL(k_prenet_b, dim3(PRENET_SPLIT * d.B + 2 * d.B), dim3(PRENET_BT), 0, s, d, 0, 0, w.pre0T.p, w.pre1T.p, w.proj_b.p, w.loc_conv.p, w.loc_denseT.p);
+  HIP_CHECK(hipGetLastError());
+}
 void launch_decoder_advance(const DecoderBufs &d, int n, hipStream_t s) {
   hipLaunchKernelGGL(k_advance, dim3(1), dim3(1), 0, s, d, n);
   HIP_CHECK(hipGetLastError());
@@ -1642,11 +1842,16 @@ static void enqueue_steps(const DecoderBufs &d, const DeviceWeights &w, int i0, 
   const float4 *att_wm = reinterpret_cast<const float4 *>(w.att_wm.p), *dec_wm = reinterpret_cast<const float4 *>(w.dec_wm.p);
   const bool fuse_aq = batched && d.ep_g && d.hg && d.B <= 64;
   const bool early = fuse_aq && d.att_part != nullptr;  // 1536 of the attention LSTM's 1792 columns ride in the previous decoder-LSTM launch
+  const bool two = early && decoder_two_launch(d);       // ... and the prenet launch is the tail of the decoder-LSTM launch
+  DecoderBufs dd = d;                                    // what the decoder-LSTM launch sees
+  if (!two) dd.hdg = dd.melg = nullptr;
+  const TailWeights tw{reinterpret_cast<const float4 *>(w.proj_w.p), w.proj_b.p, w.pre0T.p, w.pre1T.p, w.loc_conv.p, w.loc_denseT.p};
   for (int i = i0; i < i0 + nsteps; ++i) {
     const int cur = i & 1;
     for (char k : order) {
       switch (k) {
         case 'p':
+          if (two) break;  // (launch_decoder_prologue ran the first step's prenet; every later one is the previous decoder-LSTM launch's tail)
           if (batched)
             hipLaunchKernelGGL(k_prenet_b, dim3(PRENET_SPLIT * d.B + d.B * (d.T <= LOC_MFMA_T ? 2 : ((d.T + LOC_TT - 1) / LOC_TT + 7) / 8)), dim3(PRENET_BT), 0, s, d, i, 0, w.pre0T.p, w.pre1T.p,
                                w.proj_b.p, w.loc_conv.p, w.loc_denseT.p);
@@ -1662,7 +1867,7 @@ static void enqueue_steps(const DecoderBufs &d, const DeviceWeights &w, int i0, 
             hipLaunchKernelGGL(k_att_lstm_attention<false>, dim3(NBLK), dim3(64 * MFMA_WAVES), 0, s, d, i, cur, att_wm, w.att_b.p,
                                reinterpret_cast<const float4 *>(w.q_w.p), w.v_w.p, w.proj_wc.p);
           else if (batched)
-            hipLaunchKernelGGL((k_lstm_mfma<ATT_COLS, 0>), dim3(NBLK, (d.B + 63) / 64), dim3(64 * MFMA_WAVES), 0, s, d, i, cur, att_wm, w.att_b.p, q4, att_wm);
+            hipLaunchKernelGGL((k_lstm_mfma<ATT_COLS, 0>), dim3(NBLK, (d.B + 63) / 64), dim3(64 * MFMA_WAVES), 0, s, d, i, cur, att_wm, w.att_b.p, q4, att_wm, tw);
           else
             hipLaunchKernelGGL((k_lstm<ATT_COLS, 0>), dim3(NBLK), dim3(256), 0, s, d, i, cur, att_w, w.att_b.p, q4,
                                w.loc_conv.p, w.loc_denseT.p);
@@ -1683,8 +1888,8 @@ static void enqueue_steps(const DecoderBufs &d, const DeviceWeights &w, int i0, 
           break;
         case 'd':
           if (batched) {  // (early: 256 more blocks multiply the next attention-LSTM pass's 1536 known columns)
-            hipLaunchKernelGGL((k_lstm_mfma<DEC_COLS, 1>), dim3(early ? 2 * NBLK : NBLK, (d.B + 63) / 64), dim3(64 * MFMA_WAVES), 0, s, d, i, cur, dec_wm, w.dec_b.p, wh4,
-                               att_wm);
+            hipLaunchKernelGGL((k_lstm_mfma<DEC_COLS, 1>), dim3(early ? 2 * NBLK : NBLK, (d.B + 63) / 64), dim3(64 * MFMA_WAVES), 0, s, dd, i, cur, dec_wm, w.dec_b.p, wh4,
+                               att_wm, tw);
           } else
             hipLaunchKernelGGL((k_lstm<DEC_COLS, 1>), dim3(loc_tiles * d.B + NBLK), dim3(256), 0, s, d, i, cur, dec_w,
                                w.dec_b.p, wh4, w.loc_conv.p, w.loc_denseT.p);
@@ -1733,6 +1938,7 @@ void launch_frag_convert(float *rowmajor, float *frag, int B, int Bpad, int n, i
 
 // After the last step of a sequence: finishes the projection of the final step (frames, gate).
 void launch_decoder_flush(const DecoderBufs &d, const DeviceWeights &w, hipStream_t s) {
+  if (decoder_two_launch(d) && w.att_wm.p && w.dec_wm.p) return;  // (two-launch form: every step's tail stored its own frame)
   if (d.xf)
     hipLaunchKernelGGL(k_prenet_b, dim3(PRENET_SPLIT * d.B), dim3(PRENET_BT), 0, s, d, 0, 1, w.pre0T.p, w.pre1T.p, w.proj_b.p, w.loc_conv.p, w.loc_denseT.p);
   else

@@ -62,6 +62,10 @@ struct DecoderBufs {
   // extra blocks of the decoder-LSTM launch of step s-1, added by the attention-LSTM pass of step s, which then only
   // multiplies the 256 prenet columns.  null = the attention launch runs the whole K.
   float *att_part;
+  // ... and the TWO-launch form (decoder.hip: dec_tail_chunk): h_dec as granules [B][1024], published by the decoder-LSTM blocks and
+  // gathered by the chunk's four projection / prenet blocks of the same launch, which exchange the mel + gate values [B][96];
+  // null = the prenet launch sums the partial-mel rows.  One allocation: melg = hdg + B * 1024.
+  unsigned long long *hdg, *melg;
   int att_spins, att_fault;  // test hooks: poll limit (0 = default) and a block (index + 1) that never publishes its energies
 };
 constexpr int ATT_EXCHANGE_BLOCKS = 8;  // granule rows per chunk (CTX_BLOCKS in decoder.hip)
@@ -76,6 +80,8 @@ void launch_decoder_steps(const DecoderBufs &d, const DeviceWeights &w, int nste
 void launch_decoder_step_at(const DecoderBufs &d, const DeviceWeights &w, int i, hipStream_t s);
 void launch_decoder_advance(const DecoderBufs &d, int n, hipStream_t s);
 void launch_decoder_early(const DecoderBufs &d, const DeviceWeights &w, int i, hipStream_t s);  // (no-op without d.att_part)
+bool decoder_two_launch(const DecoderBufs &d);
+void launch_decoder_prologue(const DecoderBufs &d, const DeviceWeights &w, hipStream_t s);  // (no-op in the three-launch form)
 void launch_decoder_location(const DecoderBufs &d, const DeviceWeights &w, hipStream_t s);
 void launch_decoder_prenet(const DecoderBufs &d, const DeviceWeights &w, hipStream_t s);
 void launch_frag_convert(float *rowmajor, float *frag, int B, int Bpad, int n, int dir, hipStream_t s);
