@@ -349,6 +349,51 @@ def test_early_attention_lstm_partial_agrees_with_the_whole_pass(pkg, orc, blob)
     assert any(not np.array_equal(a, c) for a, c in zip(out[True], out[False]))  # (the two forms really are different code)
 
 
+def test_two_launch_form_agrees_with_the_prenet_launch(pkg, orc, blob):
+    """Batches of 5..64 chunks run TWO launches per lock-step iteration: the decoder-LSTM blocks publish h_dec as granules and
+    blocks 4b..4b+3 run chunk b's projection, stop rule and prenet as their tail, the location features ride on other blocks
+    of that launch; XDTTS_NO_TAIL (read per handle) keeps the prenet launch that sums partial-mel rows.  Same arithmetic,
+    sums grouped differently: with fixed step counts (21 chunks, ragged second tile, chunks stopping at different steps, and 56
+    chunks: no decoder-LSTM block is free for a location unit) and with the gate deciding (frame counts equal), every chunk
+    within 1e-5 of the oracle and of the other form."""
+    def both(blob_, ids_list, **kw):
+        out = {}
+        for tail in (True, False):
+            if not tail:
+                os.environ["XDTTS_NO_TAIL"] = "1"
+            try:
+                m = pkg.Tacotron2.from_blob(blob_)
+            finally:
+                os.environ.pop("XDTTS_NO_TAIL", None)
+            out[tail] = m.infer_batch(ids_list, **kw)
+            assert m.engine_state()["batched_attention"] == 2
+            m.close()
+        return out
+    for n in (21, 56):
+        ids_list = [synth_ids(20 + (3 * i) % 70, seed=800 + i) for i in range(n)]
+        steps = [40 - (2 * i) % 31 for i in range(n)]
+        out = both(blob, ids_list, opts=pkg.default_opts(dropout_seed=41), fixed_steps=steps)
+        for b in (0, 7, 15, 16, n - 1):
+            ref = orc.infer_chunk(blob, ids_list[b], orc.default_opts(fixed_steps=steps[b], dropout_seed=41, item=b))
+            for tail in out:
+                assert out[tail][b].shape == (80, steps[b]) and rms(out[tail][b], ref) <= 1e-5, (n, tail, b)
+        assert all(rms(a, c) <= 1e-5 for a, c in zip(out[True], out[False]))
+        assert any(not np.array_equal(a, c) for a, c in zip(out[True], out[False]))  # (the two forms really are different code)
+    ids_list = [synth_ids(20 + 3 * i, seed=70 + i) for i in range(9)]
+    padded = np.zeros(100, dtype=np.int64)
+    padded[: len(ids_list[0])] = ids_list[0]
+    mem, pm = orc.encoder(blob, padded)
+    rig = rigged_gate_blob(orc, blob, mem, pm, len(ids_list[0]), 4, 40)
+    out = both(rig, ids_list, opts=pkg.default_opts(dropout_seed=4, max_steps=70))
+    counts = set()
+    for b, ids in enumerate(ids_list):
+        ref = orc.infer_chunk(rig, ids, orc.default_opts(dropout_seed=4, max_steps=70, item=b))
+        for tail in out:
+            assert out[tail][b].shape == ref.shape and rms(out[tail][b], ref) <= 1e-5, (tail, b)
+        counts.add(ref.shape[1])
+    assert len(counts) > 1
+
+
 @pytest.mark.parametrize("form", ["2", "1"])
 def test_lost_attention_block_falls_back(pkg, orc, blob, capfd, form):
     """The blocks of a chunk wait for each other's partial energies inside one launch.  With one block never

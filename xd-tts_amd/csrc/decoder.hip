@@ -1116,6 +1116,14 @@ __device__ __forceinline__ void dec_tail_chunk(const DecoderBufs &d, int step, i
   for (int k = 0; k < IN1; ++k) w0[k] = reinterpret_cast<const float4 *>(W0T)[(size_t)(kg1 * IN1 + k) * (PRENET / 4) + o4];
 #pragma unroll
   for (int k = 0; k < IN2; ++k) w1[k] = reinterpret_cast<const float4 *>(W1T)[((size_t)(kg2 * IN2 + k) * PRENET + COLS2 * part) / 4 + c4];
+  // the Bernoulli(0.5) masks of step s + 1 do not depend on the data: hashed while the mel crosses
+  const int chunk = d.item_perm ? d.item_perm[b] : b;
+  const uint32_t item = d.item_base + (uint32_t)chunk;
+  bool drop1 = false, drop2 = false;
+  if (d.dropout_mode) {
+    if (tid < PRENET) drop1 = prenet_dropped(d.dropout_mode, d.dropout_seed, item, d.drop_masks, d.drop_steps, chunk, step + 1, 0, tid);
+    if (tid < COLS2) drop2 = prenet_dropped(d.dropout_mode, d.dropout_seed, item, d.drop_masks, d.drop_steps, chunk, step + 1, 1, COLS2 * part + tid);
+  }
   if (tid <= N_MEL) {
     float g[1];
     granule_gather<1>(d.melg, (size_t)b * 96 + tid, 0, want, g, d.att_err, spin_limit);
@@ -1134,8 +1142,6 @@ __device__ __forceinline__ void dec_tail_chunk(const DecoderBufs &d, int step, i
     }
   }
   if (fired || step + 1 >= nf) return;  // (block-uniform) the chunk stops here: no x(s + 1)
-  const int chunk = d.item_perm ? d.item_perm[b] : b;
-  const uint32_t item = d.item_base + (uint32_t)chunk;
   // ---- prenet layer 1 (every block, all 256 outputs) ----
   {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1155,7 +1161,7 @@ __device__ __forceinline__ void dec_tail_chunk(const DecoderBufs &d, int step, i
 #pragma unroll
     for (int k = 0; k < KG1; ++k) v += s_p1[k * PRENET + tid];
     v = fmaxf(v, 0.f);
-    if (d.dropout_mode) v = prenet_dropped(d.dropout_mode, d.dropout_seed, item, d.drop_masks, d.drop_steps, chunk, step + 1, 0, tid) ? 0.f : 2.f * v;
+    if (d.dropout_mode) v = drop1 ? 0.f : 2.f * v;
     s_x1[tid] = v;
   }
   __syncthreads();
@@ -1180,7 +1186,7 @@ __device__ __forceinline__ void dec_tail_chunk(const DecoderBufs &d, int step, i
     for (int k = 0; k < KG2; ++k) o += s_p2[k * COLS2 + tid];
     o = fmaxf(o, 0.f);
     const int j = COLS2 * part + tid;
-    if (d.dropout_mode) o = prenet_dropped(d.dropout_mode, d.dropout_seed, item, d.drop_masks, d.drop_steps, chunk, step + 1, 1, j) ? 0.f : 2.f * o;
+    if (d.dropout_mode) o = drop2 ? 0.f : 2.f * o;
     d.x[b * PRENET + j] = o;
     d.xf[((size_t)(j >> 2) * d.Bpad + b) * 4 + (j & 3)] = o;
   }
