@@ -29,7 +29,7 @@ for k in sorted(f, key=lambda k: -(2 * f[k][1] + w.get(k, (0, 0.0))[1]) * f[k][0
     tr = (2 * fe + wr) * 1024 / 1e6
     if k.startswith(STEP): tot += tr * n
     print("%-28s %8d %14.1f %14.1f %16.2f" % (k, n, fe, wr, tr))
-it = f.get("k_prenet_b", (1, 0))[0] - 1  # (one more prenet launch: the flush)
+it = max([n for k, (n, _) in f.items() if k.startswith("k_lstm_mfma<2560")] or [f.get("k_prenet_b", (2, 0))[0] - 1])  # one decoder-LSTM launch per iteration
 print("the kernels of a decoder step: %.1f MB per lock-step iteration (%d iterations) against 73 MB algorithmic (71.3 MB of LSTM weights + per-chunk state)" % (tot / max(it, 1), it))
 print("(FETCH_SIZE counts what leaves the L2s, Infinity-Cache hits included: the LSTM weights are re-read every step, the 0.4 - 0.65 MB activation operand once per XCD;")
 print(" the small kernels' traffic is the partial-mel rows, the encoder memory and the location / energy arrays)")
