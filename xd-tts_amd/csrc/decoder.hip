@@ -1529,16 +1529,19 @@ __device__ __forceinline__ void attention_loads(AttentionLoads &L, const Decoder
   asm volatile("" ::: "memory");
 }
 // ... and those the stages after the softmax consume (projection rows, this block's slice of the encoder memory)
-template <int NT>
+// PMEL false (two-launch form: the decoder-LSTM launch's tail multiplies the context columns of W_p itself): no projection rows
+template <int NT, bool PMEL = true>
 __device__ __forceinline__ void attention_loads_late(AttentionLoads &L, const DecoderBufs &d, int b, int part, const float *__restrict__ proj_wc) {
   constexpr int NWV = NT / 64, NB = ATT_DIM / (4 * NWV), COLS = EMB / NB, C4 = COLS / 4, TG = NT / C4;
   const int tid = threadIdx.x, T = d.T;
   // projection rows of the 64-column block cblk: thread (m, half) of each 256-thread group holds 32 columns of row m
   const int csub = tid >> 8, pm_m = (tid & 255) >> 1, pm_half = tid & 1, cblk = (COLS / CTX_COLS) * part + csub;
+  if (PMEL) {
 #pragma unroll
-  for (int k = 0; k < 8; ++k)
-    L.wc[k] = pm_m <= N_MEL ? reinterpret_cast<const float4 *>(proj_wc + ((size_t)cblk * (N_MEL + 1) + pm_m) * CTX_COLS + 32 * pm_half)[k]
-                            : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < 8; ++k)
+      L.wc[k] = pm_m <= N_MEL ? reinterpret_cast<const float4 *>(proj_wc + ((size_t)cblk * (N_MEL + 1) + pm_m) * CTX_COLS + 32 * pm_half)[k]
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   const int c4 = tid % C4, tg = tid / C4;
   const float4 *mem = reinterpret_cast<const float4 *>(d.memory + (size_t)b * T * EMB) + part * C4;
 #pragma unroll
@@ -1551,7 +1554,7 @@ __device__ __forceinline__ void attention_loads_late(AttentionLoads &L, const De
 
 // lds: T_MAX + (NT / 64) T_MAX + 17 (512 / NB) + 1024 floats.  HG: the attention-LSTM output of this step
 // arrives as granules d.hg[b][1024] (published by the LSTM phase of the same launch) instead of the row-major vector.
-template <int NT, bool HG>
+template <int NT, bool HG, bool PMEL = true>
 __device__ __forceinline__ void attention_chunk(const DecoderBufs &d, int i, int step, int b, int part, float *lds, AttentionLoads &L,
                                                 const float *__restrict__ proj_wc) {
   constexpr int NWV = NT / 64, NB = ATT_DIM / (4 * NWV);       // a wave takes four attention dims
@@ -1584,7 +1587,7 @@ __device__ __forceinline__ void attention_chunk(const DecoderBufs &d, int i, int
   const float4 *mem = reinterpret_cast<const float4 *>(d.memory + (size_t)b * T * EMB) + part * C4;
   // behind this block's own publish of h, ahead of the wait for everyone else's (issued behind the gather instead -- the polls then
   // do not queue behind these 166 KB -- the iteration measured 0.3-0.5 us slower: the other blocks' h is the later event either way)
-  if (HG) attention_loads_late<NT>(L, d, b, part, proj_wc);
+  if (HG) attention_loads_late<NT, PMEL>(L, d, b, part, proj_wc);
   APROBE(1);
   if (HG) {  // the 256 LSTM blocks of this launch each publish four units of every chunk
     constexpr int NG = ATT_RNN / NT;
@@ -1691,8 +1694,8 @@ __device__ __forceinline__ void attention_chunk(const DecoderBufs &d, int i, int
     d.ctx[b * EMB + j] = v;
     d.ctxf[((size_t)(j >> 2) * d.Bpad + b) * 4 + (j & 3)] = v;
   }
-  __syncthreads();
-  {
+  if (PMEL) {
+    __syncthreads();
     float pv = 0.f;
 #pragma unroll
     for (int k2 = 0; k2 < 8; ++k2) pv = dot4(wc[k2], *reinterpret_cast<const float4 *>(&s_ctx[CTX_COLS * csub + 32 * pm_half + 4 * k2]), pv);
@@ -1728,7 +1731,8 @@ __global__ __launch_bounds__(256) void k_attention_b(DecoderBufs d, int i, int c
 // together (one per CU), as for the persistent engine; the same bounded spin covers a grid that is not.
 // EARLY: the pass multiplies the 256 prenet columns only and adds d.att_part, the product of the other 1536 columns that
 // 256 blocks of the preceding decoder-LSTM launch computed (att_early_partial).
-template <bool EARLY>
+// TWO: two-launch form -- no partial-mel rows of the context columns (the decoder-LSTM launch's tail reads d.ctx)
+template <bool EARLY, bool TWO = false>
 __global__ __launch_bounds__(64 * MFMA_WAVES) void k_att_lstm_attention(DecoderBufs d, int i, int cur, const float4 *__restrict__ Wm,
                                                                         const float *__restrict__ bias, const float4 *__restrict__ Wq,
                                                                         const float *__restrict__ v_w, const float *__restrict__ proj_wc) {
@@ -1760,7 +1764,7 @@ __global__ __launch_bounds__(64 * MFMA_WAVES) void k_att_lstm_attention(DecoderB
     default: return;  // (no chunk is active: nothing to attend to either)
   }
   if (!attn) return;
-  attention_chunk<512, true>(d, i, step, b, part, s_acc, L, proj_wc);
+  attention_chunk<512, true, !TWO>(d, i, step, b, part, s_acc, L, proj_wc);
 }
 
 }  // namespace
@@ -1866,7 +1870,10 @@ static void enqueue_steps(const DecoderBufs &d, const DeviceWeights &w, int i0, 
                                w.proj_b.p);
           break;
         case 'a':
-          if (early)  // attention LSTM (its 256 prenet columns + the early partial) + energies + softmax + context
+          if (two)  // ... and no partial-mel rows: the decoder-LSTM launch's tail projects h_dec and the context itself
+            hipLaunchKernelGGL((k_att_lstm_attention<true, true>), dim3(NBLK), dim3(64 * MFMA_WAVES), 0, s, d, i, cur, att_wm, w.att_b.p,
+                               reinterpret_cast<const float4 *>(w.q_w.p), w.v_w.p, w.proj_wc.p);
+          else if (early)  // attention LSTM (its 256 prenet columns + the early partial) + energies + softmax + context
             hipLaunchKernelGGL(k_att_lstm_attention<true>, dim3(NBLK), dim3(64 * MFMA_WAVES), 0, s, d, i, cur, att_wm, w.att_b.p,
                                reinterpret_cast<const float4 *>(w.q_w.p), w.v_w.p, w.proj_wc.p);
           else if (fuse_aq)  // attention LSTM + energies + softmax + context ('q' and 's' are then no-ops)
