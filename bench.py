@@ -366,7 +366,7 @@ def main():
                                  "frac": POSTNET_FLOP_PER_FRAME * fr / (tm["postnet_ms"] * 1e-3) / 1e12 / MFMA_F32_PEAK_TF},
             "us_per_lockstep_iteration": tm["decoder_ms"] * 1e3 / it,
             "roofline": {
-                "kernel": "the decoder iteration of the batched path (three launches: k_prenet_b with the location blocks, k_att_lstm_attention, k_lstm_mfma<DEC> with the next iteration's early attention-LSTM blocks)",
+                "kernel": "the decoder iteration of the batched path (two launches: k_att_lstm_attention, k_lstm_mfma<DEC> with the next iteration's early attention-LSTM blocks and the projection / stop rule / prenet tail)",
                 "bound": "mfma",
                 "achieved": c3_flops / dsec / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": c3_flops / dsec / 1e12 / MFMA_F32_PEAK_TF,
                 "hbm_achieved_GBs": c3_bytes / dsec / 1e9, "hbm_frac": c3_bytes / dsec / 1e9 / HBM_PEAK_GBS,
