@@ -171,6 +171,7 @@ struct xdtts_tacotron2 {
   DevBuf<int> dec_err;
   DevBuf<unsigned long long> att_exchange;
   DevBuf<float> att_part;  // early partial pre-activations of the attention LSTM (DecoderBufs::att_part)
+  DevBuf<float> dec_part;  // two-launch form: early partial of the decoder LSTM's h_dec columns (DecoderBufs::dec_part)
   DevBuf<unsigned long long> tail_exchange;  // two-launch form: h_dec and mel granules (DecoderBufs::hdg, melg)
   // batched mode: energies, softmax and context in one launch (XDTTS_ATT_FUSED=0: the two-kernel form; also after
   // an exchange of that launch timed out)
@@ -421,6 +422,11 @@ struct xdtts_tacotron2 {
               tail_exchange.alloc((size_t)B * (DEC_RNN + 96));
               d.hdg = tail_exchange.p;
               d.melg = d.hdg + (size_t)B * DEC_RNN;
+              static const bool no_dh = getenv("XDTTS_NO_DHEARLY") != nullptr;  // developer comparison aid
+              if (!no_dh) {
+                dec_part.alloc((size_t)(DEC_RNN / 4) * 4 * 64 * 4);
+                d.dec_part = dec_part.p;
+              }
             }
           }
         }
@@ -666,6 +672,7 @@ struct xdtts_tacotron2 {
         d2.hg = nullptr;
         d2.att_part = nullptr;
         d2.hdg = d2.melg = nullptr;
+        d2.dec_part = nullptr;
         return run_decoder(d2, lim);
       }
     }

@@ -825,7 +825,7 @@ __device__ __forceinline__ void lstm_mfma_pass(const DecoderBufs &d, int n0, int
   const size_t ci = ((size_t)blk * d.Bpad + n0 + 16 * (wave < NTA ? wave : 0) + fi) * 4 + fg;
   float c_old = cst[wave < NTA && n0 + 16 * wave + fi < d.B ? ci : (size_t)blk * d.Bpad * 4];  // (unconditional: clamped to the block's first state)
   f32x4 pin = (f32x4){0.f, 0.f, 0.f, 0.f};  // early partial of this lane's (chunk, unit): written by the previous launch
-  if (PART) pin = reinterpret_cast<const f32x4 *>(d.att_part)[((size_t)blk * 4 + (wave < NTA ? wave : 0)) * 64 + lane];
+  if (PART) pin = reinterpret_cast<const f32x4 *>(KIND == 0 ? d.att_part : d.dec_part)[((size_t)blk * 4 + (wave < NTA ? wave : 0)) * 64 + lane];
   asm volatile("" ::: "memory");
 #pragma unroll
   for (int jj = 0; jj < JJ; ++jj) {
@@ -944,22 +944,27 @@ __device__ __forceinline__ unsigned hw_place() {  // (xcc << 16) | HW_ID: which 
   return ((xcc & 15u) << 16) | (hw & 0xffffu);
 }
 #endif
+// KIND 1 (two-launch form, d.dec_part): the same for the DECODER LSTM's own-state columns -- W_dec[:, 1536..2559] . h_dec(s-1), 40 % of its
+// pass, complete when the decoder-LSTM launch of step s-1 ends -- by 256 extra blocks of the ATTENTION launch of step s, whose own
+// blocks are a latency chain; the decoder-LSTM launch of step s then multiplies [h_att(s) ; ctx(s)] only.  hcur: half of dec_hf.
 constexpr int EARLY_K0 = PRENET / 16, EARLY_KS = (ATT_COLS - PRENET) / 16;  // k-steps 16 .. 111 of the 112
-template <int NTA>
+constexpr int EARLY_K0_D = (ATT_RNN + EMB) / 16, EARLY_KS_D = DEC_RNN / 16;  // decoder LSTM: k-steps 96 .. 159 of the 160
+template <int NTA, int KIND = 0>
 __device__ __forceinline__ void att_early_partial(const DecoderBufs &d, int hcur, int blk, const float4 *__restrict__ Wm, float *lds,
                                                   unsigned long long t_entry = 0, int step = 0) {
-  constexpr int NWV = MFMA_WAVES, JJ = EARLY_KS / NWV;
-  static_assert(EARLY_KS % NWV == 0, "whole k-steps per wave");
+  constexpr int NWV = MFMA_WAVES, K0 = KIND ? EARLY_K0_D : EARLY_K0, KS = KIND ? EARLY_KS_D : EARLY_KS, JJ = KS / NWV;
+  constexpr int KSTEPS = (KIND ? DEC_COLS : ATT_COLS) / 16;
+  static_assert(KS % NWV == 0, "whole k-steps per wave");
 #ifdef XDTTS_LSTM_PROBE
   unsigned long long ep[4];
   ep[0] = wall_clock64();
 #endif
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fi = lane & 15, fg = lane >> 4;
-  const float4 *wsrc = Wm + ((size_t)blk * (ATT_COLS / 16) + EARLY_K0 + wave * JJ) * 64 + lane;
-  const float4 *seg1 = reinterpret_cast<const float4 *>(d.ctxf), *seg2 = reinterpret_cast<const float4 *>(d.att_hf[hcur]);
+  const float4 *wsrc = Wm + ((size_t)blk * KSTEPS + K0 + wave * JJ) * 64 + lane;
+  const float4 *seg1 = reinterpret_cast<const float4 *>(d.ctxf), *seg2 = reinterpret_cast<const float4 *>(KIND ? d.dec_hf[hcur] : d.att_hf[hcur]);
   auto src = [&](int jj) {  // (wave-uniform segment choice: scalar code)
-    const int col = 16 * (wave * JJ + jj);  // column behind the prenet columns
-    const float4 *sb = col < EMB ? seg1 + (size_t)(col >> 2) * d.Bpad : seg2 + (size_t)((col - EMB) >> 2) * d.Bpad;
+    const int col = 16 * (wave * JJ + jj);  // column behind the prenet columns (KIND 1: of h_dec)
+    const float4 *sb = KIND ? seg2 + (size_t)(col >> 2) * d.Bpad : (col < EMB ? seg1 + (size_t)(col >> 2) * d.Bpad : seg2 + (size_t)((col - EMB) >> 2) * d.Bpad);
     return sb + (size_t)fg * d.Bpad + fi;
   };
   constexpr int DW = NTA >= 3 ? 2 : 3, DX = NTA >= 3 ? 1 : 2, RX = DX + 1;  // prefetch depths of lstm_mfma_pass
@@ -1010,7 +1015,7 @@ __device__ __forceinline__ void att_early_partial(const DecoderBufs &d, int hcur
     f32x4 g = red[wave * 64 + lane];
 #pragma unroll
     for (int q = 1; q < NWV; ++q) g += red[(q * 4 + wave) * 64 + lane];
-    reinterpret_cast<f32x4 *>(d.att_part)[((size_t)blk * 4 + wave) * 64 + lane] = g;
+    reinterpret_cast<f32x4 *>(KIND ? d.dec_part : d.att_part)[((size_t)blk * 4 + wave) * 64 + lane] = g;
   }
 #ifdef XDTTS_LSTM_PROBE
   ep[2] = wall_clock64();
@@ -1020,23 +1025,25 @@ __device__ __forceinline__ void att_early_partial(const DecoderBufs &d, int hcur
 #endif
 }
 // the role as a whole: tiles by the chunks still active at step `next`
+template <int KIND = 0>
 __device__ __forceinline__ void att_early_role(const DecoderBufs &d, int next, int hcur, int blk, const float4 *__restrict__ Wm, float *lds, unsigned long long t_entry) {
   const int lane = threadIdx.x & 63;
   const bool a = lane < d.B && next < d.nframes[min(lane, d.B - 1)];  // (a chunk the next prenet launch stops still counts: its tile's partial is not read then)
   const unsigned long long m = __ballot(a);
   const int nta = m ? (63 - __clzll((long long)m)) / 16 + 1 : 0;
   switch (nta) {
-    case 1: att_early_partial<1>(d, hcur, blk, Wm, lds, t_entry, next); break;
-    case 2: att_early_partial<2>(d, hcur, blk, Wm, lds, t_entry, next); break;
-    case 3: att_early_partial<3>(d, hcur, blk, Wm, lds, t_entry, next); break;
-    case 4: att_early_partial<4>(d, hcur, blk, Wm, lds, t_entry, next); break;
+    case 1: att_early_partial<1, KIND>(d, hcur, blk, Wm, lds, t_entry, next); break;
+    case 2: att_early_partial<2, KIND>(d, hcur, blk, Wm, lds, t_entry, next); break;
+    case 3: att_early_partial<3, KIND>(d, hcur, blk, Wm, lds, t_entry, next); break;
+    case 4: att_early_partial<4, KIND>(d, hcur, blk, Wm, lds, t_entry, next); break;
     default: break;
   }
 }
 // stand-alone form (parity hooks: a sequence that starts from caller-held state has no preceding decoder-LSTM launch)
-__global__ __launch_bounds__(64 * MFMA_WAVES) void k_att_early(DecoderBufs d, int i, const float4 *__restrict__ att_wm) {
+__global__ __launch_bounds__(64 * MFMA_WAVES) void k_att_early(DecoderBufs d, int i, const float4 *__restrict__ att_wm, const float4 *__restrict__ dec_wm) {
   __shared__ __attribute__((aligned(16))) float s_acc[MFMA_WAVES * 4 * 64 * 4];
-  att_early_role(d, d.ctl[0] + i, i & 1, blockIdx.x, att_wm, s_acc, 0);
+  if ((int)blockIdx.x < NBLK) att_early_role<0>(d, d.ctl[0] + i, i & 1, blockIdx.x, att_wm, s_acc, 0);
+  else att_early_role<1>(d, d.ctl[0] + i, i & 1, (int)blockIdx.x - NBLK, dec_wm, s_acc, 0);  // (grid 512 with d.dec_part)
 }
 
 
@@ -1246,12 +1253,24 @@ __global__ __launch_bounds__(64 * MFMA_WAVES) void k_lstm_mfma(DecoderBufs d, in
     wa[rt] = (KIND == 1 && wave < 4 && mrow < MEL_LD) ? reinterpret_cast<const float *>(Wepi)[((size_t)blk * MEL_LD + mrow) * 4 + fg] : 0.f;
   }
   if (KIND == 1 && d.hdg) {  // two-launch form: h_dec as granules, then the chunk's projection / prenet tail
-    switch (nta) {
-      case 1: lstm_mfma_pass<NCOLS, KIND, 1, NoHook, 0, NCOLS, false, KIND == 1>(d, n0, cur, step, blk, wsrc, bz, wa, s_acc, m, t_entry); break;
-      case 2: lstm_mfma_pass<NCOLS, KIND, 2, NoHook, 0, NCOLS, false, KIND == 1>(d, n0, cur, step, blk, wsrc, bz, wa, s_acc, m, t_entry); break;
-      case 3: lstm_mfma_pass<NCOLS, KIND, 3, NoHook, 0, NCOLS, false, KIND == 1>(d, n0, cur, step, blk, wsrc, bz, wa, s_acc, m, t_entry); break;
-      case 4: lstm_mfma_pass<NCOLS, KIND, 4, NoHook, 0, NCOLS, false, KIND == 1>(d, n0, cur, step, blk, wsrc, bz, wa, s_acc, m, t_entry); break;
-      default: return;
+    if (d.dec_part) {  // ... and the h_dec(s-1) columns were multiplied by the attention launch's extra blocks: [h_att ; ctx] only
+      constexpr int CNS = KIND == 1 ? ATT_RNN + EMB : NCOLS;
+      const float4 *ws = Wm + ((size_t)blk * (NCOLS / 16) + wave * (CNS / NW / 16)) * 64 + lane;
+      switch (nta) {
+        case 1: lstm_mfma_pass<NCOLS, KIND, 1, NoHook, 0, CNS, KIND == 1, KIND == 1>(d, n0, cur, step, blk, ws, bz, wa, s_acc, m, t_entry); break;
+        case 2: lstm_mfma_pass<NCOLS, KIND, 2, NoHook, 0, CNS, KIND == 1, KIND == 1>(d, n0, cur, step, blk, ws, bz, wa, s_acc, m, t_entry); break;
+        case 3: lstm_mfma_pass<NCOLS, KIND, 3, NoHook, 0, CNS, KIND == 1, KIND == 1>(d, n0, cur, step, blk, ws, bz, wa, s_acc, m, t_entry); break;
+        case 4: lstm_mfma_pass<NCOLS, KIND, 4, NoHook, 0, CNS, KIND == 1, KIND == 1>(d, n0, cur, step, blk, ws, bz, wa, s_acc, m, t_entry); break;
+        default: return;
+      }
+    } else {
+      switch (nta) {
+        case 1: lstm_mfma_pass<NCOLS, KIND, 1, NoHook, 0, NCOLS, false, KIND == 1>(d, n0, cur, step, blk, wsrc, bz, wa, s_acc, m, t_entry); break;
+        case 2: lstm_mfma_pass<NCOLS, KIND, 2, NoHook, 0, NCOLS, false, KIND == 1>(d, n0, cur, step, blk, wsrc, bz, wa, s_acc, m, t_entry); break;
+        case 3: lstm_mfma_pass<NCOLS, KIND, 3, NoHook, 0, NCOLS, false, KIND == 1>(d, n0, cur, step, blk, wsrc, bz, wa, s_acc, m, t_entry); break;
+        case 4: lstm_mfma_pass<NCOLS, KIND, 4, NoHook, 0, NCOLS, false, KIND == 1>(d, n0, cur, step, blk, wsrc, bz, wa, s_acc, m, t_entry); break;
+        default: return;
+      }
     }
     const int b = blk >> 2;
     static_assert(TAIL_LDS_FLOATS <= NW * 4 * 64 * 4, "the tail reuses the accumulator exchange area");
@@ -1587,7 +1606,9 @@ __device__ __forceinline__ void attention_chunk(const DecoderBufs &d, int i, int
   const float4 *mem = reinterpret_cast<const float4 *>(d.memory + (size_t)b * T * EMB) + part * C4;
   // behind this block's own publish of h, ahead of the wait for everyone else's (issued behind the gather instead -- the polls then
   // do not queue behind these 166 KB -- the iteration measured 0.3-0.5 us slower: the other blocks' h is the later event either way)
-  if (HG) attention_loads_late<NT, PMEL>(L, d, b, part, proj_wc);
+  // (two-launch form: the memory slice is fetched behind the energies instead -- below -- so that the block fits 128 VGPRs and a
+  // second block, the decoder LSTM's early partial, shares the CU)
+  if (HG && PMEL) attention_loads_late<NT, PMEL>(L, d, b, part, proj_wc);
   APROBE(1);
   if (HG) {  // the 256 LSTM blocks of this launch each publish four units of every chunk
     constexpr int NG = ATT_RNN / NT;
@@ -1635,6 +1656,7 @@ __device__ __forceinline__ void attention_chunk(const DecoderBufs &d, int i, int
     for (int k = 0; k < NWV; k += 4) e += (s_eg[k * T_MAX + t] + s_eg[(k + 1) * T_MAX + t]) + (s_eg[(k + 2) * T_MAX + t] + s_eg[(k + 3) * T_MAX + t]);
     if (!(d.att_fault && (int)blockIdx.x == d.att_fault - 1)) granule_store(slots + (size_t)part * T + t, want, e);
   }
+  if (HG && !PMEL) attention_loads_late<NT, PMEL>(L, d, b, part, proj_wc);  // (in flight while the partial energies cross)
   for (int t = tid; t < T; t += NT) {
     float pe[NB];
     granule_gather<NB>(slots, t, T, want, pe, d.att_err, spin_limit);
@@ -1733,9 +1755,10 @@ __global__ __launch_bounds__(256) void k_attention_b(DecoderBufs d, int i, int c
 // 256 blocks of the preceding decoder-LSTM launch computed (att_early_partial).
 // TWO: two-launch form -- no partial-mel rows of the context columns (the decoder-LSTM launch's tail reads d.ctx)
 template <bool EARLY, bool TWO = false>
-__global__ __launch_bounds__(64 * MFMA_WAVES) void k_att_lstm_attention(DecoderBufs d, int i, int cur, const float4 *__restrict__ Wm,
+__global__ __launch_bounds__(64 * MFMA_WAVES, TWO ? 4 : 2) void k_att_lstm_attention(DecoderBufs d, int i, int cur, const float4 *__restrict__ Wm,
                                                                         const float *__restrict__ bias, const float4 *__restrict__ Wq,
-                                                                        const float *__restrict__ v_w, const float *__restrict__ proj_wc) {
+                                                                        const float *__restrict__ v_w, const float *__restrict__ proj_wc,
+                                                                        const float4 *__restrict__ dec_wm) {
   constexpr int NW = MFMA_WAVES, CN = EARLY ? PRENET : ATT_COLS, JJ = CN / NW / 16;
   static_assert(NW == 8 && attention_lds_floats(512) <= NW * 4 * 64 * 4, "the attention phase reuses the accumulator exchange area");
   const int blk = blockIdx.x;
@@ -1748,6 +1771,10 @@ __global__ __launch_bounds__(64 * MFMA_WAVES) void k_att_lstm_attention(DecoderB
   const float4 bz = *reinterpret_cast<const float4 *>(bias + (blk * 4 + fg) * 4);
   const float wa[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   __shared__ __attribute__((aligned(16))) float s_acc[NW * 4 * 64 * 4];
+  if (TWO && (int)blockIdx.x >= NBLK) {  // blocks 256..511 (with d.dec_part): the early partial of THIS step's decoder-LSTM pass over h_dec(s-1)
+    att_early_role<1>(d, d.ctl[0] + i, cur, (int)blockIdx.x - NBLK, dec_wm, s_acc, 0);
+    return;
+  }
   // blocks 4 b .. 4 b + 3 are the attention blocks of chunk b; their loads for that phase go out as soon as the wave has
   // issued the last load of its LSTM pass, and arrive while it waits for the other waves and the other blocks
   const int b = blk >> 2, part = blk & 3;
@@ -1798,6 +1825,7 @@ void launch_decoder_init(const DecoderBufs &d, const int *limits_dev, hipStream_
   if (d.ep_g) HIP_CHECK(hipMemsetAsync(d.ep_g, 0, sizeof(unsigned long long) * (size_t)d.B * CTX_BLOCKS * d.T, s));  // step tags restart at 1
   if (d.hg) HIP_CHECK(hipMemsetAsync(d.hg, 0, sizeof(unsigned long long) * (size_t)d.B * ATT_RNN, s));
   if (d.att_part) HIP_CHECK(hipMemsetAsync(d.att_part, 0, sizeof(float) * (size_t)NBLK * 4 * 64 * 4, s));  // step 0: context and hidden state are zero
+  if (d.dec_part) HIP_CHECK(hipMemsetAsync(d.dec_part, 0, sizeof(float) * (size_t)NBLK * 4 * 64 * 4, s));
   if (d.hdg) HIP_CHECK(hipMemsetAsync(d.hdg, 0, sizeof(unsigned long long) * (size_t)d.B * (DEC_RNN + 96), s));  // (melg follows hdg)
   hipLaunchKernelGGL(k_decoder_init, dim3(d.B), dim3(256), 0, s, d, limits_dev);
   HIP_CHECK(hipGetLastError());
@@ -1822,7 +1850,8 @@ void launch_decoder_step_at(const DecoderBufs &d, const DeviceWeights &w, int i,
 // (inside a sequence the decoder-LSTM launch of node i - 1 computes it)
 void launch_decoder_early(const DecoderBufs &d, const DeviceWeights &w, int i, hipStream_t s) {
   if (!(d.xf && w.att_wm.p && d.ep_g && d.hg && d.B <= 64 && d.att_part)) return;
-  hipLaunchKernelGGL(k_att_early, dim3(NBLK), dim3(64 * MFMA_WAVES), 0, s, d, i, reinterpret_cast<const float4 *>(w.att_wm.p));
+  hipLaunchKernelGGL(k_att_early, dim3(decoder_two_launch(d) && d.dec_part ? 2 * NBLK : NBLK), dim3(64 * MFMA_WAVES), 0, s, d, i,
+                     reinterpret_cast<const float4 *>(w.att_wm.p), reinterpret_cast<const float4 *>(w.dec_wm.p));
   HIP_CHECK(hipGetLastError());
 }
 // Two-launch form: the exchange buffers exist, the MFMA location role serves T, the fused attention launch is on
@@ -1855,6 +1884,7 @@ static void enqueue_steps(const DecoderBufs &d, const DeviceWeights &w, int i0, 
   const bool two = early && decoder_two_launch(d);       // ... and the prenet launch is the tail of the decoder-LSTM launch
   DecoderBufs dd = d;                                    // what the decoder-LSTM launch sees
   if (!two) dd.hdg = dd.melg = nullptr;
+  if (!two) dd.dec_part = nullptr;
   const TailWeights tw{reinterpret_cast<const float4 *>(w.proj_w.p), w.proj_b.p, w.pre0T.p, w.pre1T.p, w.loc_conv.p, w.loc_denseT.p};
   for (int i = i0; i < i0 + nsteps; ++i) {
     const int cur = i & 1;
@@ -1871,14 +1901,14 @@ static void enqueue_steps(const DecoderBufs &d, const DeviceWeights &w, int i0, 
           break;
         case 'a':
           if (two)  // ... and no partial-mel rows: the decoder-LSTM launch's tail projects h_dec and the context itself
-            hipLaunchKernelGGL((k_att_lstm_attention<true, true>), dim3(NBLK), dim3(64 * MFMA_WAVES), 0, s, d, i, cur, att_wm, w.att_b.p,
-                               reinterpret_cast<const float4 *>(w.q_w.p), w.v_w.p, w.proj_wc.p);
+            hipLaunchKernelGGL((k_att_lstm_attention<true, true>), dim3(dd.dec_part ? 2 * NBLK : NBLK), dim3(64 * MFMA_WAVES), 0, s, dd, i, cur, att_wm, w.att_b.p,
+                               reinterpret_cast<const float4 *>(w.q_w.p), w.v_w.p, w.proj_wc.p, dec_wm);  // (+ 256 blocks: the decoder LSTM's h_dec(s-1) columns)
           else if (early)  // attention LSTM (its 256 prenet columns + the early partial) + energies + softmax + context
             hipLaunchKernelGGL(k_att_lstm_attention<true>, dim3(NBLK), dim3(64 * MFMA_WAVES), 0, s, d, i, cur, att_wm, w.att_b.p,
-                               reinterpret_cast<const float4 *>(w.q_w.p), w.v_w.p, w.proj_wc.p);
+                               reinterpret_cast<const float4 *>(w.q_w.p), w.v_w.p, w.proj_wc.p, dec_wm);
           else if (fuse_aq)  // attention LSTM + energies + softmax + context ('q' and 's' are then no-ops)
             hipLaunchKernelGGL(k_att_lstm_attention<false>, dim3(NBLK), dim3(64 * MFMA_WAVES), 0, s, d, i, cur, att_wm, w.att_b.p,
-                               reinterpret_cast<const float4 *>(w.q_w.p), w.v_w.p, w.proj_wc.p);
+                               reinterpret_cast<const float4 *>(w.q_w.p), w.v_w.p, w.proj_wc.p, dec_wm);
           else if (batched)
             hipLaunchKernelGGL((k_lstm_mfma<ATT_COLS, 0>), dim3(NBLK, (d.B + 63) / 64), dim3(64 * MFMA_WAVES), 0, s, d, i, cur, att_wm, w.att_b.p, q4, att_wm, tw);
           else

@@ -66,6 +66,9 @@ struct DecoderBufs {
   // gathered by the chunk's four projection / prenet blocks of the same launch, which exchange the mel + gate values [B][96];
   // null = the prenet launch sums the partial-mel rows.  One allocation: melg = hdg + B * 1024.
   unsigned long long *hdg, *melg;
+  // ... with the decoder LSTM's own-state columns early too: dec_part [256][4][64][4] = W_dec[:, 1536..2559] . h_dec(s-1), written by 256
+  // extra blocks of the attention launch of step s, added by the decoder-LSTM pass of step s, which then multiplies [h_att ; ctx] only
+  float *dec_part;
   int att_spins, att_fault;  // test hooks: poll limit (0 = default) and a block (index + 1) that never publishes its energies
 };
 constexpr int ATT_EXCHANGE_BLOCKS = 8;  // granule rows per chunk (CTX_BLOCKS in decoder.hip)
