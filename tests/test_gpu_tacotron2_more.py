@@ -423,6 +423,29 @@ def test_lost_attention_block_falls_back(pkg, orc, blob, capfd, form):
     m.close()
 
 
+def test_lost_h_dec_in_the_two_launch_form_falls_back(pkg, orc, blob, capfd):
+    """In the two-launch form the four tail blocks of a chunk wait, inside the decoder-LSTM launch, for the h_dec granules of all
+    256 LSTM blocks.  With one block never publishing (test hook) the bounded spins run out, the error word is set and the
+    handle decodes the request again with separate kernels: correct frames, a message on stderr, no hang."""
+    ids_list, steps = _batch_case(8)
+    os.environ["XDTTS_TAIL_FAULT"] = "7"
+    os.environ["XDTTS_ATT_SPINS"] = "20000"
+    try:
+        m = pkg.Tacotron2.from_blob(blob)
+        mels = m.infer_batch(ids_list, opts=pkg.default_opts(dropout_seed=31), fixed_steps=steps)
+        assert "batched attention exchange timed out" in capfd.readouterr().err
+    finally:
+        del os.environ["XDTTS_TAIL_FAULT"], os.environ["XDTTS_ATT_SPINS"]
+    assert m.engine_state()["batched_attention"] == 0
+    for b, (ids, st) in enumerate(zip(ids_list, steps)):
+        ref = orc.infer_chunk(blob, ids, orc.default_opts(fixed_steps=st, dropout_seed=31, item=b))
+        assert rms(mels[b], ref) <= 1e-5, b
+    m.engine_reset()
+    again = m.infer_batch(ids_list, opts=pkg.default_opts(dropout_seed=31), fixed_steps=steps)
+    assert m.engine_state()["batched_attention"] == 2 and all(rms(a, b) <= 1e-5 for a, b in zip(again, mels))
+    m.close()
+
+
 def test_gemm_tile_shapes_give_identical_results(tmp_path):
     """k_gemm_nt picks 32x32 tiles for the single-utterance shapes and 64x64 once a grid fills the chip twice;
     both accumulate every output element's K products in ascending order, so a batch decoded with either

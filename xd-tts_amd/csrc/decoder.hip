@@ -893,7 +893,7 @@ __device__ __forceinline__ void lstm_mfma_pass(const DecoderBufs &d, int n0, int
             h_out[(size_t)n * ATT_RNN + unit] = hn;
         }
         hf_out[((size_t)blk * d.Bpad + n) * 4 + fg] = hn;
-        if (TAIL) granule_store(d.hdg + (size_t)n * DEC_RNN + unit, (unsigned)step + 1u, hn);
+        if (TAIL && !(d.tail_fault && blk == d.tail_fault - 1)) granule_store(d.hdg + (size_t)n * DEC_RNN + unit, (unsigned)step + 1u, hn);
       }
     }
     if (KIND == 1 && !TAIL) {

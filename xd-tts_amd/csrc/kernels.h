@@ -70,6 +70,7 @@ struct DecoderBufs {
   // extra blocks of the attention launch of step s, added by the decoder-LSTM pass of step s, which then multiplies [h_att ; ctx] only
   float *dec_part;
   int att_spins, att_fault;  // test hooks: poll limit (0 = default) and a block (index + 1) that never publishes its energies
+  int tail_fault;            // test hook, two-launch form: a decoder-LSTM block (index + 1) that never publishes its h_dec granules
 };
 constexpr int ATT_EXCHANGE_BLOCKS = 8;  // granule rows per chunk (CTX_BLOCKS in decoder.hip)
 // [B][T][128] -> [B][32][T][4]
