@@ -56,3 +56,23 @@ def test_persistent_griffinlim_with_a_straggler_workgroup(pkg, orc):
         with env(XDTTS_GL_SLOW=wg):
             assert np.array_equal(voc.infer_linear(S), want), wg
     voc.close()
+
+
+def test_batched_decoder_with_a_straggler_block(pkg, model):
+    """Lock-step batches of 5..64 chunks: two launches per step whose blocks hand h_att, the partial energies, h_dec and the mel
+    rows to each other as tagged granules.  One block of BOTH launches stalls ~7 us between its LSTM pass and its exchange role, every
+    other step (test hook XDTTS_ATT_SLOW): an attention / tail block of chunk 0, one of another chunk, a decoder-LSTM block that is no chunk's tail, the
+    last block.  Results bit-identical to the undisturbed run."""
+    n = 21
+    ids = [synth_ids(20 + 3 * i, seed=900 + i) for i in range(n)]
+    steps = np.array([30 - (i % 9) for i in range(n)], dtype=np.int32)
+    o = pkg.default_opts(dropout_seed=12)
+    m = pkg.Tacotron2.synthetic()
+    want = [x.copy() for x in m.infer_batch(ids, opts=o, fixed_steps=steps)]
+    for blk in (1, 2, 47, 201, 256):
+        with env(XDTTS_ATT_SLOW=blk):
+            got = m.infer_batch(ids, opts=o, fixed_steps=steps)
+        for g, w in zip(got, want):
+            assert np.array_equal(g, w), blk
+    assert m.engine_state()["batched_attention"] == 2   # no exchange timed out
+    m.close()

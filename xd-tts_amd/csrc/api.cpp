@@ -433,6 +433,7 @@ struct xdtts_tacotron2 {
         if (const char *sp = getenv("XDTTS_ATT_SPINS")) d.att_spins = atoi(sp);  // test hooks for the
         if (const char *ft = getenv("XDTTS_ATT_FAULT")) d.att_fault = atoi(ft);  // lost-block path
         if (const char *ft = getenv("XDTTS_TAIL_FAULT")) d.tail_fault = atoi(ft);  // (two-launch form: a block whose h_dec never arrives)
+        if (const char *sl = getenv("XDTTS_ATT_SLOW")) d.att_slow = atoi(sl);      // straggler block
       }
     }
     return d;

@@ -744,6 +744,12 @@ __device__ __forceinline__ void granule_gather(const u64 *base, size_t idx, size
   }
 }
 
+// test hook (DecoderBufs::att_slow): this block is a straggler (~7 us) between its LSTM pass and its exchange role, every other step
+// (more points -- at entry, inside the pass -- cost the undisturbed path 0.8 us per iteration: every hook is a control-flow join)
+__device__ __forceinline__ void batched_straggle(const DecoderBufs &d, int blk, int step, int at) {
+  if (d.att_slow && blk == d.att_slow - 1 && (step & 1) == (at & 1))
+    for (int i = 0; i < 2; ++i) __builtin_amdgcn_s_sleep(127);
+}
 struct NoHook {
   __device__ __forceinline__ void operator()() const {}
 };
@@ -1278,6 +1284,7 @@ __global__ __launch_bounds__(64 * MFMA_WAVES) void k_lstm_mfma(DecoderBufs d, in
     if (threadIdx.x == 0 && step == 100 && (blk == 0 || blk == 68 || blk == 160 || blk == 250))
       printf("probe D blk %d: entry %llu  pass done %llu (x10ns)\n", blk, t_entry % 100000ull, wall_clock64() % 100000ull);
 #endif
+    batched_straggle(d, blk, step, 2);  // (between its publish of h_dec and its share of the chunk's mel rows)
     if (b < d.B && step < d.nframes[b]) dec_tail_chunk(d, step, b, blk & 3, s_acc, tw.proj_w4, tw.proj_b, tw.W0T, tw.W1T);
     if (blk >= TAIL_PARTS * d.B && blk - TAIL_PARTS * d.B < 2 * d.B)  // free after the pass: one location unit, done well inside the tails' time
       location_chunk_mfma<MFMA_WAVES>(d, i + 1, blk - TAIL_PARTS * d.B, tw.loc_convT, tw.loc_denseT);
@@ -1791,6 +1798,7 @@ __global__ __launch_bounds__(64 * MFMA_WAVES, TWO ? 4 : 2) void k_att_lstm_atten
     default: return;  // (no chunk is active: nothing to attend to either)
   }
   if (!attn) return;
+  batched_straggle(d, blk, step, 2);  // (between its publish of h and its share of the chunk's energies)
   attention_chunk<512, true, !TWO>(d, i, step, b, part, s_acc, L, proj_wc);
 }
 

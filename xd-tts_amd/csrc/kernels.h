@@ -71,6 +71,7 @@ struct DecoderBufs {
   float *dec_part;
   int att_spins, att_fault;  // test hooks: poll limit (0 = default) and a block (index + 1) that never publishes its energies
   int tail_fault;            // test hook, two-launch form: a decoder-LSTM block (index + 1) that never publishes its h_dec granules
+  int att_slow;              // test hook: a block (index + 1) of both batched launches that stalls ~7 us at a different point of every step
 };
 constexpr int ATT_EXCHANGE_BLOCKS = 8;  // granule rows per chunk (CTX_BLOCKS in decoder.hip)
 // [B][T][128] -> [B][32][T][4]
