@@ -800,7 +800,7 @@ __device__ __forceinline__ void lstm_mfma_pass(const DecoderBufs &d, int n0, int
 #define XDTTS_HI_ATT 21  // weights / activations ahead (two digits) from three active tiles on: attention LSTM ...
 #endif
 #ifndef XDTTS_HI_DEC
-#define XDTTS_HI_DEC 21  // ... and decoder LSTM
+#define XDTTS_HI_DEC 11  // ... and decoder LSTM (two-launch engine: 11: 32.8, 21: 33.0, 22: 33.2, 32: 33.4 us per configs[2] iteration)
 #endif
 #ifdef XDTTS_LSTM_DW
   constexpr int DW = XDTTS_LSTM_DW;
@@ -973,7 +973,10 @@ __device__ __forceinline__ void att_early_partial(const DecoderBufs &d, int hcur
     const float4 *sb = KIND ? seg2 + (size_t)(col >> 2) * d.Bpad : (col < EMB ? seg1 + (size_t)(col >> 2) * d.Bpad : seg2 + (size_t)((col - EMB) >> 2) * d.Bpad);
     return sb + (size_t)fg * d.Bpad + fi;
   };
-  constexpr int DW = NTA >= 3 ? 2 : 3, DX = NTA >= 3 ? 1 : 2, RX = DX + 1;  // prefetch depths of lstm_mfma_pass
+#ifndef XDTTS_EARLY_HI
+#define XDTTS_EARLY_HI 11  // weights / activations ahead from three active tiles on (11: 32.7, 21: 33.0, 22: 33.6, 31: 33.3 us per configs[2] iteration)
+#endif
+  constexpr int DW = NTA >= 3 ? XDTTS_EARLY_HI / 10 : 3, DX = NTA >= 3 ? XDTTS_EARLY_HI % 10 : 2, RX = DX + 1;  // prefetch depths of lstm_mfma_pass
   f32x4 acc[NTA];
 #pragma unroll
   for (int t = 0; t < NTA; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
