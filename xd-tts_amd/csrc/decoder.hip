@@ -797,7 +797,10 @@ __device__ __forceinline__ void lstm_mfma_pass(const DecoderBufs &d, int n0, int
   // four tiles in flight per k-step every activation vector queues behind more loads, so they run one k-step shallower.
   // (-DXDTTS_LSTM_DW / -DXDTTS_LSTM_DX override both cases.)
 #ifndef XDTTS_HI_ATT
-#define XDTTS_HI_ATT 21  // weights / activations ahead (two digits) from three active tiles on: attention LSTM ...
+#define XDTTS_HI_ATT 21  // weights / activations ahead (two digits) from two active tiles on: attention LSTM ...
+#endif
+#ifndef XDTTS_LO
+#define XDTTS_LO 32  // ... and with one active tile (both LSTMs, and the early blocks; two tiles with one k-step ahead: 24 / 32 chunks 28.7 / 29.2 -> 27.7 / 28.0 us)
 #endif
 #ifndef XDTTS_HI_DEC
 #define XDTTS_HI_DEC 11  // ... and decoder LSTM (two-launch engine: 11: 32.8, 21: 33.0, 22: 33.2, 32: 33.4 us per configs[2] iteration)
@@ -805,12 +808,12 @@ __device__ __forceinline__ void lstm_mfma_pass(const DecoderBufs &d, int n0, int
 #ifdef XDTTS_LSTM_DW
   constexpr int DW = XDTTS_LSTM_DW;
 #else
-  constexpr int DW = NTA >= 3 ? (KIND == 0 ? XDTTS_HI_ATT : XDTTS_HI_DEC) / 10 : 3;
+  constexpr int DW = NTA >= 2 ? (KIND == 0 ? XDTTS_HI_ATT : XDTTS_HI_DEC) / 10 : XDTTS_LO / 10;
 #endif
 #ifdef XDTTS_LSTM_DX
   constexpr int DX = XDTTS_LSTM_DX;
 #else
-  constexpr int DX = NTA >= 3 ? (KIND == 0 ? XDTTS_HI_ATT : XDTTS_HI_DEC) % 10 : 2;
+  constexpr int DX = NTA >= 2 ? (KIND == 0 ? XDTTS_HI_ATT : XDTTS_HI_DEC) % 10 : XDTTS_LO % 10;
 #endif
   constexpr int RX = DX + 1;
   float4 ring[RX][NTA], wring[8];
@@ -974,9 +977,9 @@ __device__ __forceinline__ void att_early_partial(const DecoderBufs &d, int hcur
     return sb + (size_t)fg * d.Bpad + fi;
   };
 #ifndef XDTTS_EARLY_HI
-#define XDTTS_EARLY_HI 11  // weights / activations ahead from three active tiles on (11: 32.7, 21: 33.0, 22: 33.6, 31: 33.3 us per configs[2] iteration)
+#define XDTTS_EARLY_HI 11  // weights / activations ahead from two active tiles on (11: 32.7, 21: 33.0, 22: 33.6, 31: 33.3 us per configs[2] iteration)
 #endif
-  constexpr int DW = NTA >= 3 ? XDTTS_EARLY_HI / 10 : 3, DX = NTA >= 3 ? XDTTS_EARLY_HI % 10 : 2, RX = DX + 1;  // prefetch depths of lstm_mfma_pass
+  constexpr int DW = NTA >= 2 ? XDTTS_EARLY_HI / 10 : XDTTS_LO / 10, DX = NTA >= 2 ? XDTTS_EARLY_HI % 10 : XDTTS_LO % 10, RX = DX + 1;  // prefetch depths of lstm_mfma_pass
   f32x4 acc[NTA];
 #pragma unroll
   for (int t = 0; t < NTA; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
