@@ -913,6 +913,7 @@ struct xdtts_griffinlim {
   unsigned epoch = 0;              // tag base; tags are never reused while xch lives
   int persist_state = -1;          // -1 unknown, 0 unavailable / demoted, 1 usable
   int n_cu = 0;
+  int per_cu4 = 1;                 // co-resident workgroups of the 4-frame shape per CU (vocoder batch)
   bool last_persistent = false;    // the last run_iterations used the persistent engine
   int demoted_calls = 0;           // calls since a demotion (the engine is probed again after PROBE_AFTER)
   static constexpr int PROBE_AFTER = 64;
@@ -1038,7 +1039,7 @@ struct xdtts_griffinlim {
   bool persistent_usable() {
     const char *e = getenv("XDTTS_GL");
     if (e && std::string(e) == "launch") return false;  // developer comparison aid: launch-per-iteration engine
-    if (persist_state < 0) persist_state = gl_persistent_supported(device, &n_cu) ? 1 : 0;
+    if (persist_state < 0) persist_state = gl_persistent_supported(device, &n_cu, &per_cu4) ? 1 : 0;
     return persist_state == 1;
   }
 
@@ -1931,13 +1932,15 @@ static void gl_batch_from_device(xdtts_griffinlim *g, const float *mel_dev_all, 
       launch_gl_phase_init_batch(all, g->seed, g->frame_local.p, st);
       // pack consecutive utterances into persistent launches of <= one workgroup per CU.  A workgroup owns up to
       // 4 frames (one wave each) or up to 8 (two waves per SIMD): an iteration of the 8-frame shape takes 6.8 us
-      // against 5.35 us (tools/gl_tf_sweep.py), so it wins as soon as it saves launches.
+      // against 5.35 us (tools/gl_tf_sweep.py), so it wins as soon as it saves launches.  Two 4-frame workgroups
+      // per CU (k_gl_persistent<4, 2>: the state in LDS, 256 registers) take 7.1 us for the same eight frames
+      // (tools/vocoder_batch.py) and keep the 4-frame split, i.e. the single call's audio bit for bit.
       const bool pers = g->persistent_usable();
       std::vector<GlSeg> segs;
       struct Launch { int seg0, nblk; std::vector<int> utts; };
       std::vector<Launch> launches;
       std::vector<char> batched(n_utt, 0);
-      auto pack = [&](int tf, bool build) {  // returns the relative cost: launches x time per iteration of the shape
+      auto pack = [&](int tf, int wg, bool build) {  // returns the relative cost: launches x time per iteration of the shape
         // first-fit decreasing over launches of n_cu workgroups (which launch an utterance rides in does not
         // change its audio: its own split into workgroups depends on its frame count alone)
         std::vector<std::pair<int, int>> items;  // (workgroups, utterance)
@@ -1957,7 +1960,7 @@ static void gl_batch_from_device(xdtts_griffinlim *g, const float *mel_dev_all, 
           size_t k = 0;
           while (k < room.size() && room[k] < it.first) ++k;
           if (k == room.size()) {
-            room.push_back(g->n_cu);
+            room.push_back(g->n_cu * wg);
             riders.emplace_back();
           }
           room[k] -= it.first;
@@ -1983,12 +1986,14 @@ static void gl_batch_from_device(xdtts_griffinlim *g, const float *mel_dev_all, 
             }
             launches.push_back({seg0, (int)segs.size() - seg0, riders[k]});
           }
-        return (tf <= 4 ? 5.35 : 6.8) * (double)riders.size() + 6.8 * n_alone;
+        return (tf <= 4 ? (wg > 1 ? 7.1 : 5.35) : 6.8) * (double)riders.size() + 6.8 * n_alone;
       };
-      int TF = 4;
+      int TF = 4, WG = 1;
       if (pers) {
-        if (g->gopts.batch_shape == 0 && pack(GLP_TF_MAX, false) < pack(4, false)) TF = GLP_TF_MAX;
-        pack(TF, true);
+        // (the 4-frame shape splits an utterance the way its own call does, one or two workgroups per CU: batch_shape 4)
+        if (g->per_cu4 >= 2 && pack(4, 2, false) < pack(4, 1, false)) WG = 2;
+        if (g->gopts.batch_shape == 0 && pack(GLP_TF_MAX, 1, false) < pack(4, WG, false)) TF = GLP_TF_MAX, WG = 1;
+        pack(TF, WG, true);
       }
       bool used_persistent = false;
       std::vector<PinnedGuard> out;  // each utterance straight into the buffer the caller receives
@@ -2014,7 +2019,7 @@ static void gl_batch_from_device(xdtts_griffinlim *g, const float *mel_dev_all, 
       if (!segs.empty()) {
         g->segs.upload(segs.data(), segs.size(), st);
         HIP_CHECK(hipStreamSynchronize(st));
-        const size_t words = gl_persistent_xch_words(g->n_cu);
+        const size_t words = gl_persistent_xch_words(g->n_cu * std::max(1, std::min(g->per_cu4, 2)));
         unsigned need = 0;
         for (size_t i = 0; i < launches.size(); ++i) need += (unsigned)g->iters + 2u;
         if (words > g->xch.n || g->epoch > 0x7fff0000u - need) {
@@ -2035,6 +2040,7 @@ static void gl_batch_from_device(xdtts_griffinlim *g, const float *mel_dev_all, 
           p.epoch = g->epoch;
           p.nblk = L.nblk;
           p.TF = TF;
+          p.per_cu = WG;
           g->epoch += (unsigned)g->iters + 2u;
           launch_gl_persistent(all, p, all.ang, all.tprev, g->iters, alpha, g->audio.p, st);
           if (early) fetch_audio(L.utts);

@@ -465,8 +465,9 @@ __device__ __forceinline__ bool glp_give_up(unsigned &spins, int *err, unsigned 
 #define GLP_MARK(i) do { } while (0)
 #endif
 
-template <int W>
-__global__ __launch_bounds__(64 * W) void k_gl_persistent(GlBufs g, GlPersist p, const float2 *__restrict__ ang_in,
+// PC: workgroups per CU the launch is sized for (2: the vocoder batch's shape of two 4-frame workgroups, 256 registers each)
+template <int W, int PC = 1>
+__global__ __launch_bounds__(64 * W, PC) void k_gl_persistent(GlBufs g, GlPersist p, const float2 *__restrict__ ang_in,
                                                          const float2 *__restrict__ tprev_in, int n_iter, float alpha,
                                                          float *__restrict__ audio) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -510,7 +511,7 @@ __global__ __launch_bounds__(64 * W) void k_gl_persistent(GlBufs g, GlPersist p,
   // W == 4 (one wave per SIMD, the whole register file): the previous spectrum and the magnitudes of the
   // nine bins a lane updates (pairs k / 512-k for k = lane + 64 r, and k = 256 on lane 0) stay in REGISTERS
   // for the whole call -- 27 LDS accesses less per iteration in the phase-update chain.
-  constexpr bool REGSTATE = W == 4;
+  constexpr bool REGSTATE = W == 4 && PC == 1;
   float2 rP[9];
   float rS[9];
   if (REGSTATE && own) {
@@ -1034,7 +1035,7 @@ bool gl_persistent_plan(int F, int n_cu, int *TF, int *nblk) {
 size_t gl_persistent_lds_bytes(int TF) { return sizeof(float) * ((size_t)TF * (516 + 2 * 1026 + FBS) + 2 * (size_t)(TF + 3) * HOP + 4); }
 size_t gl_persistent_xch_words(int nblk) { return (size_t)nblk * 4 * GLP_HALO; }
 
-bool gl_persistent_supported(int device, int *n_cu) {
+bool gl_persistent_supported(int device, int *n_cu, int *per_cu4) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) return false;
   const size_t lds4 = gl_persistent_lds_bytes(4), lds8 = gl_persistent_lds_bytes(GLP_TF_MAX);
@@ -1045,6 +1046,12 @@ bool gl_persistent_supported(int device, int *n_cu) {
     return false;
   int per_cu = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gl_persistent<4>, 256, lds4) != hipSuccess || per_cu < 1) return false;
+  // two 4-frame workgroups per CU (73 of 160 KB of LDS each, the state in LDS instead of registers): the vocoder batch
+  *per_cu4 = 1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_gl_persistent<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4) ==
+          hipSuccess &&
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gl_persistent<4, 2>, 256, lds4) == hipSuccess && per_cu >= 2)
+    *per_cu4 = 2;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_gl_persistent<8>, 512, lds8) != hipSuccess || per_cu < 1) return false;
   *n_cu = prop.multiProcessorCount;
   return true;
@@ -1055,7 +1062,9 @@ bool gl_persistent_supported(int device, int *n_cu) {
 // launch-per-iteration path; p.ang_out / p.tprev_out (parity hook) receive the final state.
 void launch_gl_persistent(const GlBufs &g, const GlPersist &p, const float2 *ang_in, const float2 *tprev_in, int n_iter,
                           float alpha, float *audio, hipStream_t s) {
-  const void *fn = p.TF <= 4 ? reinterpret_cast<const void *>(k_gl_persistent<4>) : reinterpret_cast<const void *>(k_gl_persistent<8>);
+  const void *fn = p.TF > 4        ? reinterpret_cast<const void *>(k_gl_persistent<8>)
+                   : p.per_cu > 1 ? reinterpret_cast<const void *>(k_gl_persistent<4, 2>)
+                                  : reinterpret_cast<const void *>(k_gl_persistent<4>);
   HIP_CHECK(launch_coresident(false, fn, dim3(p.nblk), dim3(64 * p.TF), gl_persistent_lds_bytes(p.TF), s, g, p, ang_in, tprev_in, n_iter, alpha,
                               audio));
 }

@@ -201,6 +201,7 @@ struct GlPersist {
   int *err;                 // set when a bounded spin ran out
   unsigned epoch;           // tag base of this call (tags = epoch + iteration + 1; never reused within the buffer's life)
   int nblk, TF;
+  int per_cu;               // 2: the launch holds up to two 4-frame workgroups per CU (vocoder batch), else 0 / 1
   int spins;                // test hook: poll limit (0 = default)
   int slow;                 // test hook: a workgroup (index + 1) that stalls ~7 us at a different point of every iteration
   int gen_phase;            // 1: the kernel draws the seeded initial phase itself (angles = exp(2 pi i u), previous spectrum 0)
@@ -210,7 +211,7 @@ struct GlPersist {
 };
 bool gl_persistent_plan(int F, int n_cu, int *TF, int *nblk);
 size_t gl_persistent_xch_words(int nblk);
-bool gl_persistent_supported(int device, int *n_cu);
+bool gl_persistent_supported(int device, int *n_cu, int *per_cu4);
 void launch_gl_persistent(const GlBufs &g, const GlPersist &p, const float2 *ang_in, const float2 *tprev_in, int n_iter,
                           float alpha, float *audio, hipStream_t s);
 // mode 0: exp (natural-log mel), 1: copy (already linear), 2: 10^x
