@@ -3,6 +3,7 @@
 // device every entry point fails with XDTTS_ERR_NO_DEVICE.
 #include <algorithm>
 #include <cmath>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -204,15 +205,17 @@ struct xdtts_tacotron2 {
   int demoted_calls = 0;    // decoder calls since a demotion (the fast engines are probed again after PROBE_AFTER)
   static constexpr int PROBE_AFTER = 64;
   DevBuf<float> ppA, ppB, mel_dev;
-  int *host_ctl = nullptr;  // pinned: [0..1] ctl, [2..] nframes, [HOST_ENC_ERR] the encoder's error word
-  static constexpr int HOST_ENC_ERR = 2 + 4096;
+  int *host_ctl = nullptr;  // pinned: [0..1] ctl, [2..] nframes, [HOST_ENC_ERR] / [HOST_DEC_ERR] the engines' error words
+  static constexpr int HOST_ENC_ERR = 2 + 4096, HOST_DEC_ERR = HOST_ENC_ERR + 1;
 
   // cached hipGraph of GRAPH_STEPS decoder steps for the current (B, T, buffers)
   static constexpr int GRAPH_STEPS = 20;
   hipGraphExec_t graph = nullptr;
   DecoderBufs graph_key{};
 
+  hipEvent_t fetched = nullptr;  // behind the copies that bring error word and frame counts back (run_decoder)
   ~xdtts_tacotron2() {
+    if (fetched) (void)hipEventDestroy(fetched);
     if (graph) (void)hipGraphExecDestroy(graph);
     if (host_ctl) (void)hipHostFree(host_ctl);
     if (stream) (void)hipStreamDestroy(stream);
@@ -223,7 +226,8 @@ struct xdtts_tacotron2 {
     select_device(dev);
     HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     ev.create();
-    HIP_CHECK(hipHostMalloc((void **)&host_ctl, sizeof(int) * (2 + 4096 + 1), hipHostMallocDefault));
+    HIP_CHECK(hipEventCreateWithFlags(&fetched, hipEventDisableTiming));
+    HIP_CHECK(hipHostMalloc((void **)&host_ctl, sizeof(int) * (2 + 4096 + 2), hipHostMallocDefault));
     int cus = 0;
     HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     coop_group = cus / 8 < 1 ? 1 : cus / 8;
@@ -492,7 +496,13 @@ struct xdtts_tacotron2 {
     return persist_state == 1;
   }
 
-  int run_decoder(const DecoderBufs &d, const std::vector<int> &lim) {
+  // `after` (may be empty): work that only needs the frame COUNTS of a gate-less decode -- known beforehand: every chunk
+  // runs to its cap -- enqueued behind the persistent launches and ahead of the sync that fetches error word and counts,
+  // so the stream does not idle for that round trip (~90 us of the 7.7 ms headline utterance).  `*after_ran` tells the
+  // caller whether what `after` enqueued stands: not when the engine faulted and the request was decoded again.
+  int run_decoder(const DecoderBufs &d, const std::vector<int> &lim, const std::function<void()> &after = {},
+                  bool *after_ran = nullptr) {
+    if (after_ran) *after_ran = false;
     limits.upload(lim.data(), lim.size(), stream);
     launch_decoder_init(d, limits.p, stream);
     launch_decoder_prologue(d, w, stream);
@@ -595,12 +605,26 @@ struct xdtts_tacotron2 {
         }
 #endif
       }
-      int e = 0;
-      HIP_CHECK(hipMemcpyAsync(&e, dec_err.p, sizeof(int), hipMemcpyDeviceToHost, stream));
-      fetch();
+      const bool spec = after && !d.use_gate;
+      HIP_CHECK(hipMemcpyAsync(host_ctl + HOST_DEC_ERR, dec_err.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+      HIP_CHECK(hipMemcpyAsync(host_ctl, d.ctl, sizeof(int) * 2, hipMemcpyDeviceToHost, stream));
+      HIP_CHECK(hipMemcpyAsync(host_ctl + 2, d.nframes, sizeof(int) * d.B, hipMemcpyDeviceToHost, stream));
+      if (spec) {  // the host waits for the copies only; what `after` enqueues runs on
+        HIP_CHECK(hipEventRecord(fetched, stream));
+        after();
+        HIP_CHECK(hipEventSynchronize(fetched));
+      } else {
+        HIP_CHECK(hipStreamSynchronize(stream));
+      }
+      const int e = host_ctl[HOST_DEC_ERR];
       if (!e) {
         int steps = 0;
-        for (int b = 0; b < d.B; ++b) steps = std::max(steps, host_ctl[2 + b]);
+        bool as_planned = true;
+        for (int b = 0; b < d.B; ++b) {
+          steps = std::max(steps, host_ctl[2 + b]);
+          as_planned = as_planned && host_ctl[2 + b] == lim[b];
+        }
+        if (after_ran) *after_ran = spec && as_planned;
         return steps;
       }
       // A bounded spin ran out: the 256-workgroup grid was not co-resident (CUs masked or held by
@@ -789,8 +813,8 @@ struct xdtts_tacotron2 {
     n_valid.upload(lens, B, stream);
     if (B >= BATCH_MFMA_MIN) item_perm.upload(order.data(), B, stream);
     // (no sync here: the three sources are locals of this function -- the sorted copies -- and outlive the stream work,
-    // which run_decoder drains before it returns; a pageable source is staged before hipMemcpyAsync returns anyway)
-    std::lock_guard<std::recursive_mutex> chip(chip_mutex(device));  // released after run_decoder's final sync
+    // which run_decoder waits out before it returns; a pageable source is staged before hipMemcpyAsync returns anyway)
+    std::lock_guard<std::recursive_mutex> chip(chip_mutex(device));  // released after run_decoder's final wait
     run_encoder(B, T);
     HIP_CHECK(hipEventRecord(ev.e[1], stream));
     // the cooperative BiLSTM's error word comes back with the decoder's own final fetch (one stream sync less per call)
@@ -799,8 +823,36 @@ struct xdtts_tacotron2 {
     DecoderBufs d = decoder_bufs(B, T, memory.p, pmem.p, o);
     if (B >= BATCH_MFMA_MIN) d.item_perm = item_perm.p;
     if (fixed_per_item || o.fixed_frames_per_id > 0.f) d.use_gate = 0;
-    last_steps = run_decoder(d, lim);  // (ends with a stream sync)
+    // everything behind the decoder: frame counts -> column offsets -> post-net.  A gate-less decode on the persistent
+    // engine enqueues it BEFORE the sync that fetches the counts (they are the caps), see run_decoder.
+    std::vector<int> Fs(B), F(B);  // frames per slot / per caller index
+    int total = 0;
+    auto postnet_all = [&](const int *frames_per_slot) {
+      HIP_CHECK(hipEventRecord(ev.e[2], stream));
+      total = 0;
+      for (int j = 0; j < B; ++j) {
+        Fs[j] = frames_per_slot[j];
+        F[order[j]] = Fs[j];
+        total += Fs[j];
+      }
+      mel_dev.alloc((size_t)N_MEL * total);
+      std::vector<int> col0(B), col(B);  // the final mel keeps the caller's chunk order on the time axis (mod.rs:430)
+      for (int b = 0, off = 0; b < B; ++b) {
+        col0[b] = off;
+        off += F[b];
+      }
+      for (int j = 0; j < B; ++j) col[j] = col0[order[j]];
+      for (int b = 0; b < B; b += GEMM_RAGGED_MAX) {
+        const int n = std::min(GEMM_RAGGED_MAX, B - b);
+        run_postnet(d.frames + (size_t)b * d.max_steps * N_MEL, (size_t)d.max_steps * N_MEL, Fs.data() + b, col.data() + b, n,
+                    mel_dev.p, total);
+      }
+      HIP_CHECK(hipEventRecord(ev.e[3], stream));
+    };
+    bool postnet_done = false;
+    last_steps = run_decoder(d, lim, [&] { postnet_all(lim.data()); }, &postnet_done);  // (the decoder has finished; the post-net may be running)
     if (host_ctl[HOST_ENC_ERR] != 0) {
+      postnet_done = false;
       HIP_CHECK(hipMemsetAsync(enc_err.p, 0, sizeof(int), stream));
       // the 4-CU cooperative BiLSTM needs its workgroups co-resident too: same policy as the decoder --
       // say so, use the single-workgroup recurrence from now on, and run the request again
@@ -813,27 +865,7 @@ struct xdtts_tacotron2 {
       if (d.pmem_t) launch_dimgroup_transpose(pmem.p, pmem_t.p, B, T, stream);
       last_steps = run_decoder(d, lim);
     }
-    HIP_CHECK(hipEventRecord(ev.e[2], stream));
-    std::vector<int> Fs(B), F(B);  // frames per slot / per caller index
-    int total = 0;
-    for (int j = 0; j < B; ++j) {
-      Fs[j] = host_ctl[2 + j];
-      F[order[j]] = Fs[j];
-      total += Fs[j];
-    }
-    mel_dev.alloc((size_t)N_MEL * total);
-    std::vector<int> col0(B), col(B);  // the final mel keeps the caller's chunk order on the time axis (mod.rs:430)
-    for (int b = 0, off = 0; b < B; ++b) {
-      col0[b] = off;
-      off += F[b];
-    }
-    for (int j = 0; j < B; ++j) col[j] = col0[order[j]];
-    for (int b = 0; b < B; b += GEMM_RAGGED_MAX) {
-      const int n = std::min(GEMM_RAGGED_MAX, B - b);
-      run_postnet(d.frames + (size_t)b * d.max_steps * N_MEL, (size_t)d.max_steps * N_MEL, Fs.data() + b, col.data() + b, n,
-                  mel_dev.p, total);
-    }
-    HIP_CHECK(hipEventRecord(ev.e[3], stream));
+    if (!postnet_done) postnet_all(host_ctl + 2);
     *F_total = total;
     return F;
   }
@@ -1052,6 +1084,7 @@ struct xdtts_griffinlim {
                                const float2 **tprev_fin = nullptr, bool gen_phase = false) {
     int TF = 0, nblk = 0;
     last_persistent = false;
+    err_fetched = false;
     if (tprev_fin) *tprev_fin = g.tprev;
     if (persistent_usable() && gl_persistent_plan(g.F, n_cu, &TF, &nblk)) {
       const size_t words = gl_persistent_xch_words(nblk);
@@ -1114,10 +1147,20 @@ struct xdtts_griffinlim {
   // After the stream has drained: did a bounded spin of the persistent launch run out (grid not
   // co-resident)?  If so the handle is demoted to the launch-per-iteration engine (and probes the
   // persistent one again after PROBE_AFTER calls); the input state is intact, the caller re-runs.
+  // (fetch_error_word() ahead of a sync the caller needs anyway saves persistent_failed() its own round trip)
+  bool err_fetched = false;
+  void fetch_error_word() {
+    if (!last_persistent) return;
+    HIP_CHECK(hipMemcpyAsync(host_err, gl_err.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+    err_fetched = true;
+  }
   bool persistent_failed() {
     if (!last_persistent) return false;
-    HIP_CHECK(hipMemcpyAsync(host_err, gl_err.p, sizeof(int), hipMemcpyDeviceToHost, stream));
-    HIP_CHECK(hipStreamSynchronize(stream));
+    if (!err_fetched) {
+      HIP_CHECK(hipMemcpyAsync(host_err, gl_err.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+      HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    err_fetched = false;
     if (!*host_err) return false;
     HIP_CHECK(hipMemsetAsync(gl_err.p, 0, sizeof(int), stream));
     HIP_CHECK(hipMemsetAsync(xch.p, 0, xch.n * sizeof(unsigned long long), stream));
@@ -1859,7 +1902,8 @@ static void gl_iterate_and_fetch(xdtts_griffinlim *g, const GlBufs &b, const flo
     HIP_CHECK(hipEventRecord(g->ev.e[2], g->stream));
     PinnedGuard host(N);
     HIP_CHECK(hipMemcpyAsync(host.p, g->audio.p, N * sizeof(float), hipMemcpyDeviceToHost, g->stream));
-    g->finish_timings();
+    g->fetch_error_word();
+    g->finish_timings();  // (drains the stream)
     if (g->persistent_failed()) {
       HIP_CHECK(hipEventRecord(g->ev.e[1], g->stream));  // time the run that counts
       continue;
