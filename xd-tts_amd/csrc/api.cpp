@@ -508,10 +508,32 @@ struct xdtts_tacotron2 {
     launch_decoder_prologue(d, w, stream);
     const int max_lim = *std::max_element(lim.begin(), lim.end());
     int launched = 0;
-    auto fetch = [&]() {
+    const bool spec = after && !d.use_gate;
+    bool spec_ran = false;
+    // step counter and frame counts to the host; the last fetch of a decode brings the engines' error word along and,
+    // for a gate-less decode, lets `after` enqueue its work before the host waits (for the copies only)
+    auto fetch = [&](bool last = false) {
       HIP_CHECK(hipMemcpyAsync(host_ctl, d.ctl, sizeof(int) * 2, hipMemcpyDeviceToHost, stream));
       HIP_CHECK(hipMemcpyAsync(host_ctl + 2, d.nframes, sizeof(int) * d.B, hipMemcpyDeviceToHost, stream));
-      HIP_CHECK(hipStreamSynchronize(stream));
+      if (last) HIP_CHECK(hipMemcpyAsync(host_ctl + HOST_DEC_ERR, dec_err.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+      if (last && spec) {
+        HIP_CHECK(hipEventRecord(fetched, stream));
+        after();
+        spec_ran = true;
+        HIP_CHECK(hipEventSynchronize(fetched));
+      } else {
+        HIP_CHECK(hipStreamSynchronize(stream));
+      }
+    };
+    auto finish = [&]() {  // frame counts are on the host: lock-step iterations; does what `after` enqueued stand?
+      int steps = 0;
+      bool as_planned = true;
+      for (int b = 0; b < d.B; ++b) {
+        steps = std::max(steps, host_ctl[2 + b]);
+        as_planned = as_planned && host_ctl[2 + b] == lim[b];
+      }
+      if (after_ran) *after_ran = spec_ran && as_planned;
+      return steps;
     };
     if (use_persistent(d)) try {
       // one launch for the whole loop: the stop rule runs on the device and the kernel ends by itself.
@@ -605,28 +627,9 @@ struct xdtts_tacotron2 {
         }
 #endif
       }
-      const bool spec = after && !d.use_gate;
-      HIP_CHECK(hipMemcpyAsync(host_ctl + HOST_DEC_ERR, dec_err.p, sizeof(int), hipMemcpyDeviceToHost, stream));
-      HIP_CHECK(hipMemcpyAsync(host_ctl, d.ctl, sizeof(int) * 2, hipMemcpyDeviceToHost, stream));
-      HIP_CHECK(hipMemcpyAsync(host_ctl + 2, d.nframes, sizeof(int) * d.B, hipMemcpyDeviceToHost, stream));
-      if (spec) {  // the host waits for the copies only; what `after` enqueues runs on
-        HIP_CHECK(hipEventRecord(fetched, stream));
-        after();
-        HIP_CHECK(hipEventSynchronize(fetched));
-      } else {
-        HIP_CHECK(hipStreamSynchronize(stream));
-      }
-      const int e = host_ctl[HOST_DEC_ERR];
-      if (!e) {
-        int steps = 0;
-        bool as_planned = true;
-        for (int b = 0; b < d.B; ++b) {
-          steps = std::max(steps, host_ctl[2 + b]);
-          as_planned = as_planned && host_ctl[2 + b] == lim[b];
-        }
-        if (after_ran) *after_ran = spec && as_planned;
-        return steps;
-      }
+      fetch(true);
+      if (!host_ctl[HOST_DEC_ERR]) return finish();
+      spec_ran = false;  // (what `after` enqueued ran on a failed decode: it is enqueued again below)
       // A bounded spin ran out: the 256-workgroup grid was not co-resident (CUs masked or held by
       // another process).  Not silent, not fatal: say so, switch this handle to the launch-per-stage
       // engine for good, and decode this request again from the initial state.
@@ -665,7 +668,7 @@ struct xdtts_tacotron2 {
         launched += r;
       }
       launch_decoder_flush(d, w, stream);
-      fetch();
+      fetch(true);
     } else {
       const int check_every = 3 * GRAPH_STEPS;
       for (;;) {
@@ -680,13 +683,10 @@ struct xdtts_tacotron2 {
       }
       // the projection of step s is completed by the first kernel of step s+1: finish the last one
       launch_decoder_flush(d, w, stream);
-      fetch();
+      fetch(true);
     }
     if (d.ep_g) {
-      int e = 0;
-      HIP_CHECK(hipMemcpyAsync(&e, dec_err.p, sizeof(int), hipMemcpyDeviceToHost, stream));
-      HIP_CHECK(hipStreamSynchronize(stream));
-      if (e) {  // a block of the one-launch attention never saw its neighbours' energies: not silent, not fatal
+      if (host_ctl[HOST_DEC_ERR]) {  // a block of the one-launch attention never saw its neighbours' energies: not silent, not fatal
         HIP_CHECK(hipMemsetAsync(dec_err.p, 0, sizeof(int), stream));
         att_fused = 0;
         att_demoted = true;
@@ -699,12 +699,10 @@ struct xdtts_tacotron2 {
         d2.att_part = nullptr;
         d2.hdg = d2.melg = nullptr;
         d2.dec_part = nullptr;
-        return run_decoder(d2, lim);
+        return run_decoder(d2, lim);  // (no `after`: the caller enqueues its work behind this decode)
       }
     }
-    int steps = 0;
-    for (int b = 0; b < d.B; ++b) steps = std::max(steps, host_ctl[2 + b]);
-    return steps;
+    return finish();
   }
 
   // postnet.onnx (mod.rs:345-355) for one chunk: frames_dev [F][80] (row stride 80) ->
