@@ -7,7 +7,6 @@
 #include <map>
 #include <memory>
 #include <mutex>
-#include <thread>
 
 #include "kernels.h"
 
@@ -83,8 +82,25 @@ struct PinnedPool {
     live[p] = cap;
     return (float *)p;
   }
+  // A slab handed out in pieces (the mels of a batch: one copy from the device, no repacking on the host): every piece
+  // is released on its own (xdtts_free), the slab goes back to the pool with the last one.
+  std::map<void *, void *> part_of;  // piece -> slab
+  std::map<void *, int> pieces;      // slab -> pieces outstanding
+  void add_piece(void *slab, void *piece) {
+    std::lock_guard<std::mutex> lk(mu);
+    part_of[piece] = slab;
+    ++pieces[slab];
+  }
   void put(void *p) {
     std::unique_lock<std::mutex> lk(mu);
+    auto pt = part_of.find(p);
+    if (pt != part_of.end()) {
+      void *slab = pt->second;
+      part_of.erase(pt);
+      if (--pieces[slab] > 0) return;
+      pieces.erase(slab);
+      p = slab;
+    }
     auto it = live.find(p);
     if (it == live.end()) return;  // not ours, or already released (a double xdtts_free): nothing to do --
                                    // freeing it here could hand a buffer in `spare` back to the runtime
@@ -123,6 +139,27 @@ struct PinnedGuard {
     float *r = p;
     p = nullptr;
     return r;
+  }
+};
+
+// A pinned slab whose pieces go to the caller one by one (PinnedPool::add_piece).  Until hand_over() the slab is the
+// guard's: an exception on the way returns it whole.
+struct PinnedSlab {
+  float *base = nullptr;
+  std::vector<float *> cut;
+  explicit PinnedSlab(size_t n_floats) : base(pinned_alloc(n_floats)) {}
+  PinnedSlab(const PinnedSlab &) = delete;
+  PinnedSlab &operator=(const PinnedSlab &) = delete;
+  ~PinnedSlab() {
+    if (base) pinned_pool().put(base);
+  }
+  float *piece(size_t offset_floats) {  // (distinct offsets: a piece is identified by its address)
+    cut.push_back(base + offset_floats);
+    return cut.back();
+  }
+  void hand_over() {  // from here on every piece is the caller's; the slab follows the last one
+    for (float *c : cut) pinned_pool().add_piece(base, c);
+    if (!cut.empty()) base = nullptr;
   }
 };
 
@@ -710,8 +747,9 @@ struct xdtts_tacotron2 {
   // postnet.onnx (mod.rs:345-355) for n <= GEMM_RAGGED_MAX chunks in one launch per layer: chunk i has
   // F[i] frames at frames_dev + i * frame_stride ([F][80], row stride 80) and its (80 x F[i]) result
   // goes to out + col_off[i] with row stride ldc (the (80 x F_total) Array2 layout), residual included.
-  void run_postnet(const float *frames_dev, size_t frame_stride, const int *F, const int *col_off, int n, float *out,
-                   long ldc) {
+  // dense_items: chunk i's result is a dense (80 x F[i]) matrix of its own at out + col_off[i] (ldc unused).
+  void run_postnet(const float *frames_dev, size_t frame_stride, const int *F, const long *col_off, int n, float *out,
+                   long ldc, bool dense_items = false) {
     const int pad = (POST_K - 1) / 2;
     int Fmax = 0;
     for (int i = 0; i < n; ++i) Fmax = std::max(Fmax, F[i]);
@@ -750,6 +788,7 @@ struct xdtts_tacotron2 {
         g.C = out;
         g.ldc = ldc;
         g.transpose_out = 1;
+        g.ldc_rows = dense_items ? 1 : 0;
         g.R = frames_dev;
         g.ldr = N_MEL;
         g.strideR = (long)frame_stride;
@@ -765,8 +804,9 @@ struct xdtts_tacotron2 {
 
   // infer_chunk x B (mod.rs:361-393).  ids_host [B][T] already zero-padded.  Leaves the final mel
   // of chunk b at mel_dev + col_off[b] with row stride F_total; returns per-chunk frame counts.
+  // per_chunk: mel_dev receives one dense (80 x F_b) matrix per chunk instead, back to back in the caller's order.
   std::vector<int> infer_batch_device(const int64_t *ids_host, const int *lens, int B, int T,
-                                      const xdtts_infer_opts &o, const int *fixed_per_item, int *F_total) {
+                                      const xdtts_infer_opts &o, const int *fixed_per_item, int *F_total, bool per_chunk = false) {
     if (B <= 0 || B > 4096) fail(XDTTS_ERR_BAD_ARG, "batch %d out of range", B);
     if (T <= 0 || T > T_MAX) fail(XDTTS_ERR_BAD_ARG, "window %d out of range (1..%d)", T, T_MAX);
     if (o.max_steps <= 0 || o.max_steps > 100000) fail(XDTTS_ERR_BAD_ARG, "max_steps %d out of range", o.max_steps);
@@ -834,16 +874,17 @@ struct xdtts_tacotron2 {
         total += Fs[j];
       }
       mel_dev.alloc((size_t)N_MEL * total);
-      std::vector<int> col0(B), col(B);  // the final mel keeps the caller's chunk order on the time axis (mod.rs:430)
-      for (int b = 0, off = 0; b < B; ++b) {
+      std::vector<long> col0(B), col(B);  // the final mel keeps the caller's chunk order on the time axis (mod.rs:430)
+      long off = 0;
+      for (int b = 0; b < B; ++b) {
         col0[b] = off;
         off += F[b];
       }
-      for (int j = 0; j < B; ++j) col[j] = col0[order[j]];
+      for (int j = 0; j < B; ++j) col[j] = (per_chunk ? N_MEL : 1) * col0[order[j]];
       for (int b = 0; b < B; b += GEMM_RAGGED_MAX) {
         const int n = std::min(GEMM_RAGGED_MAX, B - b);
         run_postnet(d.frames + (size_t)b * d.max_steps * N_MEL, (size_t)d.max_steps * N_MEL, Fs.data() + b, col.data() + b, n,
-                    mel_dev.p, total);
+                    mel_dev.p, total, per_chunk);
       }
       HIP_CHECK(hipEventRecord(ev.e[3], stream));
     };
@@ -1487,37 +1528,24 @@ xdtts_status xdtts_tacotron2_infer_batch(xdtts_tacotron2 *h, const int64_t *ids,
       std::copy(ids + (size_t)b * t_stride, ids + (size_t)b * t_stride + lens[b], padded.begin() + (size_t)b * T);
     }
     int total = 0;
-    std::vector<int> F = h->infer_batch_device(padded.data(), lens, B, T, o, fixed_steps_per_item, &total);
-    PinnedGuard all((size_t)N_MEL * total);  // pinned staging: a pageable destination halves the copy rate
-    HIP_CHECK(hipMemcpyAsync(all.p, h->mel_dev.p, (size_t)N_MEL * total * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    // the post-net leaves one dense (80 x F_b) matrix per chunk, back to back: ONE copy into a pinned slab whose pieces
+    // are the buffers the caller receives (the (80 x F_total) layout took 4 160 strided row copies on the host for the
+    // 52-chunk batch -- as long as the post-net on one thread, 0.3 ms on four; 52 pitched copies from the device 0.9 ms)
+    std::vector<int> F = h->infer_batch_device(padded.data(), lens, B, T, o, fixed_steps_per_item, &total, true);
+    PinnedSlab slab((size_t)N_MEL * total);
+    struct Drain {  // the slab does not go back to the pool with the copy in flight
+      hipStream_t s;
+      ~Drain() { (void)hipStreamSynchronize(s); }
+    } drain{h->stream};
+    HIP_CHECK(hipMemcpyAsync(slab.base, h->mel_dev.p, (size_t)N_MEL * total * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     h->finish_timings();
-    std::vector<PinnedGuard> out;  // all B buffers exist before the first one is handed over
-    out.reserve((size_t)B);
-    for (int b = 0; b < B; ++b) out.emplace_back((size_t)N_MEL * F[b]);
-    // (80 x F_total) staging -> one (80 x F_b) matrix per chunk: 4 160 strided row copies for the 52-chunk batch (8 MB), ~1 ms on one
-    // host thread -- as long as the post-net; split over a few threads by chunk
-    std::vector<int> col0((size_t)B, 0);
-    for (int b = 1; b < B; ++b) col0[(size_t)b] = col0[(size_t)b - 1] + F[(size_t)b - 1];
-    auto repack = [&](int b0, int b1) {
-      for (int b = b0; b < b1; ++b) {
-        float *m = out[(size_t)b].p;
-        for (int r = 0; r < N_MEL; ++r)
-          std::memcpy(m + (size_t)r * F[(size_t)b], all.p + (size_t)r * total + col0[(size_t)b], sizeof(float) * F[(size_t)b]);
-      }
-    };
-    const int nthr = (size_t)N_MEL * total >= (1u << 19) ? std::min(4, B) : 1;  // (>= 2 MB)
-    if (nthr > 1) {
-      std::vector<std::thread> thr;
-      for (int k = 1; k < nthr; ++k) thr.emplace_back(repack, B * k / nthr, B * (k + 1) / nthr);
-      repack(0, B / nthr);
-      for (auto &t : thr) t.join();
-    } else {
-      repack(0, B);
-    }
+    size_t off = 0;
     for (int b = 0; b < B; ++b) {
-      mels[b] = out[(size_t)b].release();
+      mels[b] = slab.piece(off);
       n_frames[b] = (size_t)F[b];
+      off += (size_t)N_MEL * F[b];
     }
+    slab.hand_over();
   });
 }
 
@@ -1757,7 +1785,7 @@ xdtts_status xdtts_tacotron2_postnet(xdtts_tacotron2 *h, const float *frames, in
     h->frames.upload(frames, (size_t)F * N_MEL, h->stream);
     HIP_CHECK(hipStreamSynchronize(h->stream));
     h->mel_dev.alloc((size_t)N_MEL * F);
-    const int zero = 0;
+    const long zero = 0;
     h->run_postnet(h->frames.p, 0, &F, &zero, 1, h->mel_dev.p, F);
     HIP_CHECK(hipMemcpyAsync(mel_out, h->mel_dev.p, (size_t)N_MEL * F * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipStreamSynchronize(h->stream));

@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs g) {
         else if (g.act == 2) v = tanhf(v);
         else if (g.act == 3) v = powf(fmaxf(v, 0.f), g.p);
         if (!g.r_before_act) v += rv;
-        if (g.transpose_out) C[(size_t)n * g.ldc + m] = v;
+        if (g.transpose_out) C[(size_t)n * (g.ldc_rows ? (long)M : g.ldc) + m] = v;
         else C[(size_t)m * g.ldc + n] = v;
       }
     }

@@ -144,6 +144,7 @@ struct GemmArgs {
   long Cz[64];
   int act;            // 0 none, 1 relu, 2 tanh, 3 pow(max(x,0), p)
   int transpose_out;  // store C[n*ldc + m]
+  int ldc_rows;       // ragged + transpose_out: item z's row stride is its own Mz[z] -- one dense (N x Mz[z]) matrix per item at C + Cz[z]
   float p;
   // v = alpha * (A W^T) + bias; R is added scaled by beta, before the activation when r_before_act
   // (0 in alpha / beta means 1: zero-initialised args keep the plain form)
