@@ -89,6 +89,43 @@ def test_batch_of_variable_length_chunks(pkg, model, orc, blob):
         assert rms(mels[b], ref) <= 1e-5, b
 
 
+def test_batch_mels_are_pieces_of_one_slab_released_one_by_one(pkg, model):
+    """xdtts_tacotron2_infer_batch hands out pieces of ONE pinned slab (xd-tts_amd/csrc/api.cpp: PinnedSlab): the slab
+    returns to the pool only with the last piece, so a later call never writes into memory a live mel still refers to; a
+    piece released twice is a no-op."""
+    import ctypes as C
+    ids_list = [synth_ids(n, seed=20 + i) for i, n in enumerate((40, 17, 63, 29, 88, 12))]
+    steps = [9, 14, 5, 11, 8, 16]
+    o = pkg.default_opts(dropout_seed=5)
+    first = model.infer_batch(ids_list, opts=o, fixed_steps=steps)
+    keep = [m.copy() for m in first]
+    addr = [m.ctypes.data for m in first]
+    assert all(addr[b + 1] - addr[b] == 4 * 80 * steps[b] for b in range(5))  # back to back in one slab
+    del first[1], first[3]  # release two pieces (the views are the only owners)
+    again = model.infer_batch(ids_list, opts=pkg.default_opts(dropout_seed=6), fixed_steps=steps)  # different masks
+    assert not np.array_equal(again[0], keep[0])
+    for m, k in zip(first, [keep[0], keep[2], keep[3], keep[5]]):
+        assert np.array_equal(m, k)  # untouched by the second call
+    # an explicit double release of a piece must not free anything twice
+    B = len(ids_list)  # (the same engine as above: results bit-identical)
+    lens = np.array([len(x) for x in ids_list[:B]], dtype=np.int32)
+    ids = np.zeros((B, 100), dtype=np.int64)
+    for b in range(B):
+        ids[b, : lens[b]] = ids_list[b]
+    fs = np.array(steps[:B], dtype=np.int32)
+    mels, nf = (pkg._PF * B)(), (C.c_size_t * B)()
+    pkg._check(pkg.lib.xdtts_tacotron2_infer_batch(model._h, pkg._ptr(ids), pkg._ptr(lens), B, 100, C.byref(o), pkg._ptr(fs), mels, nf))
+    got = np.ctypeslib.as_array(mels[1], shape=(80, steps[1])).copy()
+    assert np.array_equal(got, keep[1])
+    pkg.lib.xdtts_free(mels[0])
+    pkg.lib.xdtts_free(mels[0])
+    assert np.array_equal(np.ctypeslib.as_array(mels[1], shape=(80, steps[1])), keep[1])  # the slab is still live
+    for b in range(1, B):
+        pkg.lib.xdtts_free(mels[b])
+    third = model.infer_batch(ids_list, opts=o, fixed_steps=steps)
+    assert all(np.array_equal(a, b) for a, b in zip(third, keep))
+
+
 def test_batch_with_gate_stops_each_chunk_on_its_own(pkg, orc, blob):
     ids_list = [synth_ids(30, seed=5), synth_ids(55, seed=6), synth_ids(18, seed=7)]
     padded = np.zeros(100, dtype=np.int64)
