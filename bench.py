@@ -317,7 +317,8 @@ def main():
         # line is already measured and has to be printed): its share then counts as failed, seconds = -1.
         res, share_err = None, None
         try:
-            shard.run_share(model, vocoder, share, chunks, steps, owner, bo)      # warm-up
+            for _ in range(2):
+                shard.run_share(model, vocoder, share, chunks, steps, owner, bo)      # warm-up
         except Exception as e:  # noqa: BLE001
             share_err = repr(e)
         barrier()
@@ -332,7 +333,8 @@ def main():
         res_f = None
         if share_err is None:
             try:
-                shard.run_share(model, vocoder, share, chunks, steps, owner, bo, fused=pkg.synthesize_batch)  # warm-up
+                for _ in range(2):
+                    shard.run_share(model, vocoder, share, chunks, steps, owner, bo, fused=pkg.synthesize_batch)  # warm-up
             except Exception as e:  # noqa: BLE001
                 share_err = repr(e)
         barrier()
