@@ -21,8 +21,8 @@ for _ in range(2):
     m.infer_batch(ids, opts=o)
 t = m.last_timings()
 print("B=%d: %.2f us/step" % (B, t["decoder_ms"] * 1e3 / steps))
-a = np.loadtxt(path)[:, :11] / 100.0 / steps  # 100 MHz clock -> us per step
-names = ["loop", "wait x", "att tail", "wait h_att", "q+energies/bulk", "wait energies", "softmax", "dec tail+bulk", "wait h_dec", "proj/bulk/loc", "prenet"]
+a = np.loadtxt(path)[:, :16] / 100.0 / steps  # 100 MHz clock -> us per step
+names = ["loop", "wait x", "att tail", "wait h_att", "q+energies/bulk", "wait energies", "softmax", "dec tail+bulk", "wait h_dec", "proj/bulk/loc", "prenet: publish x", "pre: mel gathered", "pre: gate+store+L1", "pre: L1 barrier", "pre: L2", "attn: q rows"]
 roles = {"attn c0": slice(0, 8), "pre c0": slice(8 * B, 8 * B + 16), "plain": slice(24 * B, 256)}
 if B > 1:
     roles["attn c1"] = slice(8, 16)

@@ -54,6 +54,10 @@ constexpr int P_NCU = ATT_RNN / 4;       // 256 workgroups = LSTM slices
 constexpr int TP = PERSIST_T_MAX;        // encoder-step capacity of the attention role
 constexpr int ATTN_CU = 8, PRE_CU = 16;  // role workgroups per chunk
 constexpr int EP_LD = TP, MEL_GL = 96;
+#ifndef XDTTS_MEL_ST
+#define XDTTS_MEL_ST 1
+#endif
+constexpr int MEL_ST = XDTTS_MEL_ST;     // granules between two mel values in the exchange (16 = one 128-byte line each: measured, no gain over 1)
 constexpr int GS = PERSIST_B_MAX;        // chunk stride of the granule arrays: the same for every launch width, so a
                                          // 1-chunk launch can continue a sequence that a 2-chunk launch began
 constexpr unsigned P_SPIN_LIMIT = 1u << 21;
@@ -315,6 +319,14 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       for (int k = 0; k < N_MEL / 2; ++k) rw[ROLE_REGS ? k : 0] = w.pre0T[(unsigned)(((tid >> 8) * (N_MEL / 2) + k) * PRENET + (tid & 255))];
     }
   }
+  // prenet layer 2, columns 16 rk + wave (+8), inputs lane + 64 k: RESIDENT (8 registers).  Re-read every step they
+  // were 4096 line requests per workgroup (a column of the [in][out] matrix is one float per 1 kB) = 1.4 us that
+  // stood in front of the mel poll (in-order return), the longest single piece of the step's critical path.
+  float w1r[2][4];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w1r[r][k] = pre ? w.pre1T[(unsigned)((lane + 64 * k) * PRENET + 16 * rk + wave + NW * r)] : 0.f;
   const uint32_t item = d.item_base + (uint32_t)rb;
   __syncthreads();
 
@@ -398,42 +410,36 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
     }
   };
   // location features of the NEXT step for this workgroup's 16 dims, from s_aw / s_awc:
-  //   loc[t][a] = sum_{c,k} G[a][c][k] pad_c[t + k],  G = dense . conv folded on the host.
-  // 256 threads: (dim pair, 4 consecutive time steps), sliding window in registers.
+  //   loc[t][a] = sum_{c,k} G[a][c][k] pad_c[t + k],  G = dense . conv folded on the host,
+  // as a (TP x 64) . (64 x 16) product on the matrix cores: wave w forms rows t = 16 w .. 16 w + 15 with 16
+  // v_mfma_f32_16x16x4_f32 (exact fp32), the Toeplitz operand A[t][q] = pad_{q / 31}[t + q % 31] read straight from the
+  // padded window (taps 62, 63 multiply zero rows of G).  0.4 us against the 2.8 us of the 496-FMA-per-thread sliding
+  // window it replaces, which had become the step's critical path (the attention workgroups are LSTM slices too: their
+  // h_att is late when this runs long).
   auto location = [&](int tid) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
     for (int i = tid; i < 2 * WPAD; i += PT) {
       const int ch = i / WPAD, t = i % WPAD - (LOC_K - 1) / 2;
       s_wpad[i] = (t >= 0 && t < T) ? (ch ? s_awc[t] : s_aw[t]) : 0.f;
     }
     __syncthreads();
-    if (tid < 256) {
-      const int tq = tid >> 3;  // dims 2dp, 2dp+1; steps 4tq .. 4tq+3
-      const unsigned DP2 = 2u * (tid & 7), Q4 = 4u * (unsigned)tq;
-      float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+    {
+      const unsigned l = (unsigned)tid & 63u, li = l & 15u, lg = l >> 4, t0 = 16u * ((unsigned)tid >> 6);
+      float av[16], bv[16];
 #pragma unroll
-      for (int ch = 0; ch < 2; ++ch) {
-        const float *wp = s_wpad + ch * WPAD + Q4;
-        float w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3];
-#pragma unroll 4
-        for (int k = 0; k < LOC_K; ++k) {
-          const float2 gv = *reinterpret_cast<const float2 *>(s_G + (ch * LOC_K + k) * 16 + DP2);
-          a0[0] = fmaf(gv.x, w0, a0[0]);
-          a1[0] = fmaf(gv.y, w0, a1[0]);
-          a0[1] = fmaf(gv.x, w1, a0[1]);
-          a1[1] = fmaf(gv.y, w1, a1[1]);
-          a0[2] = fmaf(gv.x, w2, a0[2]);
-          a1[2] = fmaf(gv.y, w2, a1[2]);
-          a0[3] = fmaf(gv.x, w3, a0[3]);
-          a1[3] = fmaf(gv.y, w3, a1[3]);
-          w0 = w1;
-          w1 = w2;
-          w2 = w3;
-          w3 = wp[k + 4];
-        }
+      for (int kk = 0; kk < 16; ++kk) {
+        const unsigned q = 4u * kk + lg, qa = q < 2u * LOC_K ? q : 2u * LOC_K - 1u, ch = qa >= (unsigned)LOC_K ? 1u : 0u;
+        av[kk] = s_wpad[ch * WPAD + t0 + li + (qa - ch * LOC_K)];
+        bv[kk] = q < 2u * LOC_K ? s_G[qa * 16u + li] : 0.f;
+      }
+      f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;  // two chains: a dependent MFMA waits ~40 cycles
+#pragma unroll
+      for (int kk = 0; kk < 16; kk += 2) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], bv[kk], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk + 1], bv[kk + 1], acc1, 0, 0, 0);
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        *reinterpret_cast<float2 *>(s_loc + 16 * Q4 + DP2 + 16 * i) = make_float2(a0[i], a1[i]);
+      for (int j = 0; j < 4; ++j) s_loc[(t0 + 4u * lg + j) * 16u + li] = acc0[j] + acc1[j];
     }
     __syncthreads();
   };
@@ -558,6 +564,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
         s_q[wave + NW] = q1;
       }
       __syncthreads();
+      PROF_MARK(15);  // attention role: query rows + barrier
       const int t = tid >> 2, dq = 4 * (tid & 3);
       const float4 q4 = lds4(s_q + dq), l4 = lds4(s_loc + 4 * TID), p4 = lds4(s_pm + 4 * TID), v4 = lds4(s_vv + dq);
       float e = v4.x * fast_tanh(q4.x + l4.x + p4.x);
@@ -654,6 +661,19 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
     straggle(lag, s, 4);
     __builtin_amdgcn_sched_barrier(0);
     // ---- P5: h_dec(s) -> projection rows ---------------------------------------------------------
+    // The projection + prenet role hashes the Bernoulli(0.5) masks of step s+1 (they do not depend on the data) in the
+    // time its first poll of h_dec could not succeed anyway.
+    unsigned drop1 = 0u, drop2 = 0u;
+    if (pre && act_r) {
+      if (d.dropout_mode) {  // (mode 2: the caller's keep bytes of chunk rb -- views of a batch advance d.drop_masks)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          drop1 |= (prenet_dropped(d.dropout_mode, d.dropout_seed, item, d.drop_masks, d.drop_steps, rb, s + 1, 0, lane + 64 * k) ? 1u : 0u) << k;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+          drop2 |= (prenet_dropped(d.dropout_mode, d.dropout_seed, item, d.drop_masks, d.drop_steps, rb, s + 1, 1, 16 * rk + wave + NW * r) ? 1u : 0u) << r;
+      }
+    }
     {
       // both halves of every active chunk's vector in flight together: granule tid + 512 i, i = 2 b + half
       bool need[2 * PB];
@@ -661,7 +681,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       for (int i = 0; i < 2 * PB; ++i) need[i] = act[i >> 1];
       float v[2 * PB];
       unsigned tg[2 * PB];
-      lazy_wait(pre ? g.first : g.lazy);  // only the projection role needs h_dec at once
+      lazy_wait(pre ? g.pfirst : g.lazy);  // only the projection role needs h_dec at once
       gather<2 * PB>(g.hdec, (unsigned)(p * GS * DEC_RNN + tid), PT, want, need, v, tg, pc);
 #pragma unroll
       for (int i = 0; i < 2 * PB; ++i)
@@ -675,7 +695,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       for (int j = 0; j < 4; ++j) a = dot4(lds4(s_pw + 4 * (j * PT + TID)), lds4(s_hdec + rb * DEC_RNN + 256 * j + L4), a);
       a = fmaf(pmp[1], wreg[rb][1], fmaf(pmp[0], wreg[rb][0], a));  // the context columns
       a = wave_sum(a);
-      if (lane == 0) publish(g.mel + (unsigned)((p * GS + rb) * MEL_GL + prow), want, a + s_pb[wave]);
+      if (lane == 0) publish(g.mel + (unsigned)(((p * GS + rb) * MEL_GL + prow) * MEL_ST), want, a + s_pb[wave]);
     }
     dec_bulk_h(L4, false);  // for step s+1
     if (attn && act_r) location(tid);
@@ -685,30 +705,16 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
     // ---- P6 (projection + prenet role): frame s, stop rule, x(s+1) ------------------------------
     if (pre && act_r) {  // a chunk's last x (active bit clear) is published at the step it stops
       bool nxt = false;
-      float w1r[2][4];  // prenet layer 2: columns 16 rk + wave (+8), inputs lane + 64 k
-#pragma unroll
-      for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) w1r[r][k] = w.pre1T[(unsigned)((lane + 64 * k) * PRENET + 16 * rk + wave + NW * r)];
-      // the Bernoulli(0.5) masks of step s+1 do not depend on the data: hash them while the mel is in flight
-      unsigned drop1 = 0u, drop2 = 0u;
-      if (d.dropout_mode) {  // (mode 2: the caller's keep bytes of chunk rb -- views of a batch advance d.drop_masks)
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          drop1 |= (prenet_dropped(d.dropout_mode, d.dropout_seed, item, d.drop_masks, d.drop_steps, rb, s + 1, 0, lane + 64 * k) ? 1u : 0u) << k;
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-          drop2 |= (prenet_dropped(d.dropout_mode, d.dropout_seed, item, d.drop_masks, d.drop_steps, rb, s + 1, 1, 16 * rk + wave + NW * r) ? 1u : 0u) << r;
-      }
       if (act_r) {
         if (tid < N_MEL + 1) {
           const bool need[1] = {true};
           float v[1];
           unsigned tg[1];
-          gather<1>(g.mel, (unsigned)((p * GS + rb) * MEL_GL + tid), 0, want, need, v, tg, pc);
+          gather<1>(g.mel, (unsigned)(((p * GS + rb) * MEL_GL + tid) * MEL_ST), 0, want, need, v, tg, pc);
           s_mel[tid] = v[0];
         }
         __syncthreads();
+        PROF_MARK(11);  // prenet role: mel gathered
         const float gate = s_mel[N_MEL];
         const bool fired = d.use_gate && gate_sigmoid(gate) > d.gate_threshold;  // mod.rs:319-324
         if (rk == 0) {
@@ -739,8 +745,10 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
 #pragma unroll 8
           for (int k = 0; k < N_MEL / 2; ++k) acc = fmaf(s_W0[HW + PRENET * k], s_mel[HM + k], acc);
         }
+        PROF_MARK(12);  // prenet role: gate, frame store, layer-1 products
         s_l1[TID] = acc;
         __syncthreads();
+        PROF_MARK(13);  // prenet role: layer-1 barrier
         // every wave finishes layer 1 for the inputs its lanes consume (ReLU, dropout) -- no second
         // LDS round trip -- and reduces its two layer-2 columns
         float pk[4];
@@ -762,6 +770,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       // writing two granules each into the same 128-byte line cost the x edge ~1 us per step (partial
       // write-through writes to one line serialise at the memory side); stores to different lines
       // (the mel rows, 128 B apart) do not show the effect.
+      PROF_MARK(14);  // prenet role: layer 2
       if (lane < 2) s_mel[MEL_GL - 16 + wave + NW * lane] = lane ? xo[1] : xo[0];  // s_mel[81..95] is unused padding
       __syncthreads();
       if (tid < 16)
@@ -828,7 +837,7 @@ void launch_pb(const DecoderBufs &d, const PersistBufs &g, const PersistWeights 
 
 size_t persist_granule_words(int B) {
   (void)B;
-  return (size_t)2 * GS * (PRENET + ATT_RNN + ATTN_CU * EP_LD + DEC_RNN + MEL_GL);
+  return (size_t)2 * GS * (PRENET + ATT_RNN + ATTN_CU * EP_LD + DEC_RNN + MEL_GL * MEL_ST);
 }
 
 PersistBufs persist_bufs(unsigned long long *base, int *err, int B) {
@@ -847,6 +856,7 @@ PersistBufs persist_bufs(unsigned long long *base, int *err, int B) {
   g.spins = 0;
   g.fault = 0;
   g.slow = 0;
+  g.pfirst = 2;
   g.first = 2;  // ~0.4 us: the first polls of a critical consumer cannot succeed earlier (measured: -0.3 us per step)
   return g;
 }
@@ -857,7 +867,7 @@ PersistBufs persist_view(const PersistBufs &g, int b0) {
   v.hatt += (size_t)b0 * ATT_RNN;
   v.ep += (size_t)b0 * ATTN_CU * EP_LD;
   v.hdec += (size_t)b0 * DEC_RNN;
-  v.mel += (size_t)b0 * MEL_GL;
+  v.mel += (size_t)b0 * MEL_GL * MEL_ST;
   return v;
 }
 
