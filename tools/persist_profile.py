@@ -21,7 +21,8 @@ for _ in range(2):
     m.infer_batch(ids, opts=o)
 t = m.last_timings()
 print("B=%d: %.2f us/step" % (B, t["decoder_ms"] * 1e3 / steps))
-a = np.loadtxt(path)[:, :16] / 100.0 / steps  # 100 MHz clock -> us per step
+raw = np.loadtxt(path)
+a = raw[:, :16] / 100.0 / steps  # 100 MHz clock -> us per step
 names = ["loop", "wait x", "att tail", "wait h_att", "q+energies/bulk", "wait energies", "softmax", "dec tail+bulk", "wait h_dec", "proj/bulk/loc", "prenet: publish x", "pre: mel gathered", "pre: gate+store+L1", "pre: L1 barrier", "pre: L2", "attn: q rows"]
 roles = {"attn c0": slice(0, 8), "pre c0": slice(8 * B, 8 * B + 16), "plain": slice(24 * B, 256)}
 if B > 1:
@@ -31,3 +32,7 @@ print("%-18s" % "phase" + "".join("%14s" % r for r in roles))
 for i, n in enumerate(names):
     print("%-18s" % n + "".join("%14.2f" % a[sl, i].mean() for sl in roles.values()))
 print("%-18s" % "sum" + "".join("%14.2f" % a[sl].sum(axis=1).mean() for sl in roles.values()))
+polls = raw[:, 16:20] / steps / 8.0  # failed poll rounds per step (slowest lane of a wave, mean over the 8 waves)
+print("failed poll rounds per step")
+for i, n in enumerate(["x", "h_att", "energies", "h_dec"]):
+    print("%-18s" % n + "".join("%14.2f" % polls[sl, i].mean() for sl in roles.values()))

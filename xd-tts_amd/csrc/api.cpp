@@ -622,7 +622,7 @@ struct xdtts_tacotron2 {
         g.shrink = (n == 2 && !no_shrink) ? 1 : 0;
 #ifdef XDTTS_PERSIST_PROFILE
         static DevBuf<unsigned long long> prof;
-        prof.alloc(256 * 16);
+        prof.alloc(256 * 24);
         g.prof = prof.p;
 #endif
         if (b0 > 0) HIP_CHECK(hipMemsetAsync(d.ctl, 0, sizeof(int), stream));  // step counter of the new launch
@@ -652,12 +652,12 @@ struct xdtts_tacotron2 {
         }
 #ifdef XDTTS_PERSIST_PROFILE
         if (const char *path = getenv("XDTTS_PERSIST_PROFILE")) {
-          std::vector<unsigned long long> hp(256 * 16);
+          std::vector<unsigned long long> hp(256 * 24);
           HIP_CHECK(hipMemcpyAsync(hp.data(), prof.p, hp.size() * 8, hipMemcpyDeviceToHost, stream));
           HIP_CHECK(hipStreamSynchronize(stream));
           if (FILE *f = fopen(path, "w")) {
             for (int c = 0; c < 256; ++c) {
-              for (int i = 0; i < 16; ++i) fprintf(f, "%llu ", hp[c * 16 + i]);
+              for (int i = 0; i < 24; ++i) fprintf(f, "%llu ", hp[c * 24 + i]);
               fprintf(f, "\n");
             }
             fclose(f);

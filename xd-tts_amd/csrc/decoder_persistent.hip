@@ -89,8 +89,8 @@ __device__ __forceinline__ bool give_up(unsigned &spins, const PollCtl &pc) {
 // offsets are 32-bit so the loads use the SGPR-base addressing form (no 64-bit VGPR addresses kept
 // live across the step loop).  A timed-out slot reads as {tag 0, 0.0f}.
 template <int N>
-__device__ __forceinline__ void gather(const u64 *base, unsigned idx, unsigned stride, unsigned want,
-                                       const bool (&need)[N], float (&out)[N], unsigned (&tag)[N], const PollCtl &err) {
+__device__ __forceinline__ unsigned gather(const u64 *base, unsigned idx, unsigned stride, unsigned want,
+                                           const bool (&need)[N], float (&out)[N], unsigned (&tag)[N], const PollCtl &err) {
   bool done[N];
 #pragma unroll
   for (int i = 0; i < N; ++i) {
@@ -117,7 +117,7 @@ __device__ __forceinline__ void gather(const u64 *base, unsigned idx, unsigned s
           all = false;
         }
       }
-    if (all || give_up(spins, err)) return;
+    if (all || give_up(spins, err)) return spins;
   }
 }
 
@@ -152,7 +152,7 @@ constexpr int persist_lds_floats(int pb) {
 }
 
 // Developer build (-DXDTTS_PERSIST_PROFILE): thread 0 of every workgroup accumulates the 100 MHz
-// wall clock between phase markers into g.prof[workgroup][16] (see tools/persist_profile.py).
+// wall clock between phase markers into g.prof[workgroup][24] (see tools/persist_profile.py).
 #ifdef XDTTS_PERSIST_PROFILE
 #define PROF_MARK(i)                                       \
   do {                                                     \
@@ -162,8 +162,15 @@ constexpr int persist_lds_floats(int pb) {
       prof_last = now_;                                    \
     }                                                      \
   } while (0)
+// failed poll rounds of a gather (the slowest lane of each wave, summed over the 8 waves), into s_prof[16 + e]
+#define PROF_POLLS(e, n)                                                   \
+  do {                                                                     \
+    const float m_ = wave_max((float)(n));                                 \
+    if ((tid & 63) == 0) atomicAdd(&s_prof[16 + (e)], (u64)m_);            \
+  } while (0)
 #else
 #define PROF_MARK(i) do { } while (0)
+#define PROF_POLLS(e, n) do { (void)(n); } while (0)
 #endif
 
 struct PersistWeights {
@@ -204,7 +211,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
   float *s_vv = s_cown + 64;             // [16]      v, own dims
   float *s_qw = s_vv + 16;               // [8][PT] float4: query rows 16 rk + wave (+8), 4 x 16 B per lane each
   // projection + prenet role
-  float *s_W0 = role;                    // [80][256]
+  float *s_W0 = role;                    // [20][256][4]
   float *s_mel = s_W0 + N_MEL * PRENET;  // [96]
   float *s_l1 = s_mel + MEL_GL;          // [2][256]
   float *s_pb = s_l1 + 2 * PRENET;           // [8] projection biases of this workgroup's rows (by wave)
@@ -285,7 +292,9 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
         *reinterpret_cast<float4 *>(s_qw + 4 * ((4 * r + j) * PT + tid)) = w.q_w[(unsigned)((16 * rk + wave + NW * r) * (ATT_RNN / 4) + lane + 64 * j)];
   }
   if (pre) {
-    for (int i = tid; i < N_MEL * PRENET; i += PT) s_W0[i] = w.pre0T[i];
+    // [in / 4][out][in % 4]: a thread's 40 layer-1 weights are ten conflict-free 16-byte reads (two-chunk kernel; the
+    // one-chunk kernel keeps them in registers)
+    for (int i = tid; i < N_MEL * PRENET; i += PT) s_W0[(((i / PRENET) >> 2) * PRENET + i % PRENET) * 4 + ((i / PRENET) & 3)] = w.pre0T[i];
     if (prow_ok) {
       if (lane == 0) s_pb[wave] = w.proj_b[prow];
 #pragma unroll
@@ -448,8 +457,8 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
   if (attn) location(tid);
 
 #ifdef XDTTS_PERSIST_PROFILE
-  __shared__ u64 s_prof[16];
-  if (tid < 16) s_prof[tid] = 0;
+  __shared__ u64 s_prof[24];
+  if (tid < 24) s_prof[tid] = 0;
   u64 prof_last = wall_clock64();
   __syncthreads();
 #endif
@@ -479,7 +488,8 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       float v[2];
       unsigned tg[2];
       lazy_wait(pre ? g.first : g.xlazy);  // x(s+1) cannot arrive before the projection / prenet chain has run
-      gather<2>(g.x, (unsigned)((p * GS + b0) * PRENET + i), 2u * PRENET, want, need, v, tg, pc);
+      const unsigned np_ = gather<2>(g.x, (unsigned)((p * GS + b0) * PRENET + i), 2u * PRENET, want, need, v, tg, pc);
+      PROF_POLLS(0, np_);
 #pragma unroll
       for (int j = 0; j < 2; ++j)
         if (need[j]) {
@@ -536,7 +546,8 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       float v[2 * PB];
       unsigned tg[2 * PB];
       lazy_wait(attn ? g.first : g.lazy);  // only the attention role needs h_att at once
-      gather<2 * PB>(g.hatt, (unsigned)(p * GS * ATT_RNN + tid), PT, want, need, v, tg, pc);
+      const unsigned np_ = gather<2 * PB>(g.hatt, (unsigned)(p * GS * ATT_RNN + tid), PT, want, need, v, tg, pc);
+      PROF_POLLS(1, np_);
 #pragma unroll
       for (int i = 0; i < 2 * PB; ++i)
         if (need[i]) s_hatt[TID + PT * i] = v[i];
@@ -603,7 +614,8 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       float v[2 * PB];
       unsigned tg[2 * PB];
       lazy_wait(attn ? g.first : g.clazy);  // the energies cannot arrive before the attention role has run
-      gather<2 * PB>(g.ep, (unsigned)((p * GS * ATTN_CU + j) * EP_LD + t), 4u * EP_LD, want, need, v, tg, pc);
+      const unsigned np_ = gather<2 * PB>(g.ep, (unsigned)((p * GS * ATTN_CU + j) * EP_LD + t), 4u * EP_LD, want, need, v, tg, pc);
+      PROF_POLLS(2, np_);
 #pragma unroll
       for (int b = 0; b < PB; ++b) {
         float e = v[2 * b] + v[2 * b + 1];
@@ -682,7 +694,8 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       float v[2 * PB];
       unsigned tg[2 * PB];
       lazy_wait(pre ? g.pfirst : g.lazy);  // only the projection role needs h_dec at once
-      gather<2 * PB>(g.hdec, (unsigned)(p * GS * DEC_RNN + tid), PT, want, need, v, tg, pc);
+      const unsigned np_ = gather<2 * PB>(g.hdec, (unsigned)(p * GS * DEC_RNN + tid), PT, want, need, v, tg, pc);
+      PROF_POLLS(3, np_);
 #pragma unroll
       for (int i = 0; i < 2 * PB; ++i)
         if (need[i]) s_hdec[TID + PT * i] = v[i];
@@ -730,7 +743,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       float xo[2] = {0.f, 0.f};
       if (nxt) {
         // layer 1: output tid & 255, inputs [40 hf, 40 hf + 40), hf = tid >> 8
-        const unsigned HW = (unsigned)((tid >> 8) * (N_MEL / 2) * PRENET + (tid & 255)), HM = (unsigned)((tid >> 8) * (N_MEL / 2));
+        const unsigned HM = (unsigned)((tid >> 8) * (N_MEL / 2));
         float acc = 0.f;
         if (ROLE_REGS) {
 #pragma unroll
@@ -742,8 +755,14 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
             acc = fmaf(rw[ROLE_REGS ? k + 3 : 0], m.w, acc);
           }
         } else {
-#pragma unroll 8
-          for (int k = 0; k < N_MEL / 2; ++k) acc = fmaf(s_W0[HW + PRENET * k], s_mel[HM + k], acc);
+#pragma unroll
+          for (int k = 0; k < N_MEL / 2; k += 4) {
+            const float4 w4 = lds4(s_W0 + 4u * (((HM + k) >> 2) * PRENET + (TID & 255u))), m = lds4(s_mel + HM + k);
+            acc = fmaf(w4.x, m.x, acc);
+            acc = fmaf(w4.y, m.y, acc);
+            acc = fmaf(w4.z, m.z, acc);
+            acc = fmaf(w4.w, m.w, acc);
+          }
         }
         PROF_MARK(12);  // prenet role: gate, frame store, layer-1 products
         s_l1[TID] = acc;
@@ -782,7 +801,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
   }
 #ifdef XDTTS_PERSIST_PROFILE
   __syncthreads();
-  if (g.prof && tid < 16) g.prof[c * 16 + tid] = s_prof[tid];
+  if (g.prof && tid < 24) g.prof[c * 24 + tid] = s_prof[tid];
 #endif
 
   // ---- write the state back (a later launch may continue the sequence) -----------------------
