@@ -487,7 +487,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       const bool need[2] = {b0 < PB && s_act[2 + (b0 < PB ? b0 : 0)] != 0, false};  // (PB <= 2: chunk b0 only)
       float v[2];
       unsigned tg[2];
-      lazy_wait(pre ? g.first : g.xlazy);  // x(s+1) cannot arrive before the projection / prenet chain has run
+      lazy_wait(pre ? g.xfirst : g.xlazy);  // x(s+1) cannot arrive before the projection / prenet chain has run
       const unsigned np_ = gather<2>(g.x, (unsigned)((p * GS + b0) * PRENET + i), 2u * PRENET, want, need, v, tg, pc);
       PROF_POLLS(0, np_);
 #pragma unroll
@@ -538,6 +538,14 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
     straggle(lag, s, 1);
     __builtin_amdgcn_sched_barrier(0);
     // ---- P2: h_att(s) ----------------------------------------------------------------------------
+    // attention role: what the energies need besides the query (location features + processed memory of this thread's
+    // (t, 4 dims), v) is in registers before h_att arrives
+    float4 lp4 = make_float4(0.f, 0.f, 0.f, 0.f), v4 = lp4;
+    if (attn && act_r) {
+      const float4 l4 = lds4(s_loc + 4 * TID), p4 = lds4(s_pm + 4 * TID);
+      lp4 = make_float4(l4.x + p4.x, l4.y + p4.y, l4.z + p4.z, l4.w + p4.w);
+      v4 = lds4(s_vv + 4 * (tid & 3));
+    }
     {
       // both halves of every active chunk's vector in flight together: granule tid + 512 i, i = 2 b + half
       bool need[2 * PB];
@@ -577,11 +585,11 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       __syncthreads();
       PROF_MARK(15);  // attention role: query rows + barrier
       const int t = tid >> 2, dq = 4 * (tid & 3);
-      const float4 q4 = lds4(s_q + dq), l4 = lds4(s_loc + 4 * TID), p4 = lds4(s_pm + 4 * TID), v4 = lds4(s_vv + dq);
-      float e = v4.x * fast_tanh(q4.x + l4.x + p4.x);
-      e = fmaf(v4.y, fast_tanh(q4.y + l4.y + p4.y), e);
-      e = fmaf(v4.z, fast_tanh(q4.z + l4.z + p4.z), e);
-      e = fmaf(v4.w, fast_tanh(q4.w + l4.w + p4.w), e);
+      const float4 q4 = lds4(s_q + dq);
+      float e = v4.x * fast_tanh(q4.x + lp4.x);
+      e = fmaf(v4.y, fast_tanh(q4.y + lp4.y), e);
+      e = fmaf(v4.z, fast_tanh(q4.z + lp4.z), e);
+      e = fmaf(v4.w, fast_tanh(q4.w + lp4.w), e);
       e += dpp_move<0xB1, 0xf>(0.f, e);  // quad_perm:[1,0,3,2]
       e += dpp_move<0x4E, 0xf>(0.f, e);  // quad_perm:[2,3,0,1]
       if ((tid & 3) == 0 && t < T) publish(g.ep + (unsigned)(((p * GS + rb) * ATTN_CU + rk) * EP_LD + t), want, e);
@@ -875,7 +883,8 @@ PersistBufs persist_bufs(unsigned long long *base, int *err, int B) {
   g.spins = 0;
   g.fault = 0;
   g.slow = 0;
-  g.pfirst = 2;
+  g.pfirst = 1;  // (behind the mask hashing; 0 / 1 / 2 / 3 -> 8.44 / 8.33 / 8.71 / 8.70 us per 1-chunk step)
+  g.xfirst = 2;
   g.first = 2;  // ~0.4 us: the first polls of a critical consumer cannot succeed earlier (measured: -0.3 us per step)
   return g;
 }
