@@ -36,3 +36,10 @@ polls = raw[:, 16:20] / steps / 8.0  # failed poll rounds per step (slowest lane
 print("failed poll rounds per step")
 for i, n in enumerate(["x", "h_att", "energies", "h_dec"]):
     print("%-18s" % n + "".join("%14.2f" % polls[sl, i].mean() for sl in roles.values()))
+when = raw[:, 20:24] / 100.0 / steps  # mean wall clock (us) of each workgroup at four events
+when = when - when.mean(axis=0, keepdims=True)
+print("mean lateness (us) relative to the average workgroup")
+for i, n in enumerate(["h_att published", "h_dec published(+bulk)", "x gathered", "energies gathered"]):
+    print("%-24s" % n + "".join("%12.2f" % when[sl, i].mean() for sl in roles.values()) + "   max %.2f (wg %d)  min %.2f (wg %d)" % (when[:, i].max(), when[:, i].argmax(), when[:, i].min(), when[:, i].argmin()))
+xcd = np.arange(256) % 8
+print("by XCD (wg % 8), h_att published: " + " ".join("%.2f" % when[xcd == k, 0].mean() for k in range(8)))

@@ -615,6 +615,7 @@ struct xdtts_tacotron2 {
         if (const char *fp = getenv("XDTTS_FIRST_POLL")) g.first = atoi(fp);
         if (const char *pf = getenv("XDTTS_PFIRST")) g.pfirst = atoi(pf);
         if (const char *xf = getenv("XDTTS_XFIRST")) g.xfirst = atoi(xf);
+        if (const char *ef = getenv("XDTTS_EFIRST")) g.efirst = atoi(ef);
         if (const char *xl = getenv("XDTTS_XLAZY")) g.xlazy = atoi(xl);
         if (const char *cl = getenv("XDTTS_CLAZY")) g.clazy = atoi(cl);
         if (const char *sp = getenv("XDTTS_PERSIST_SPINS")) g.spins = atoi(sp);  // test hooks for the

@@ -168,9 +168,16 @@ constexpr int persist_lds_floats(int pb) {
     const float m_ = wave_max((float)(n));                                 \
     if ((tid & 63) == 0) atomicAdd(&s_prof[16 + (e)], (u64)m_);            \
   } while (0)
+// sum over the steps of the wall clock at an event, into s_prof[20 + e]: the host turns the sums into each workgroup's
+// mean lateness at that event relative to the average workgroup
+#define PROF_WHEN(e)                                       \
+  do {                                                     \
+    if (tid == 0) s_prof[20 + (e)] += wall_clock64();      \
+  } while (0)
 #else
 #define PROF_MARK(i) do { } while (0)
 #define PROF_POLLS(e, n) do { (void)(n); } while (0)
+#define PROF_WHEN(e) do { } while (0)
 #endif
 
 struct PersistWeights {
@@ -507,6 +514,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
     }
     if (tid < PB) s_act[2 + tid] = s_act[tid];  // read again only after the barriers of this step
     PROF_MARK(1);  // wait x
+    PROF_WHEN(2);
     // Every chunk has stopped (or the exchange failed): the launch ends by itself.  A 2-chunk launch
     // also ends when one of its chunks stops: the host continues the other with the 1-chunk kernel,
     // which is ~1 us per step faster (state goes through the write-back below, x(s) stays in place).
@@ -535,6 +543,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       s_cell[8 * PB + tid] = hn;
     }
     PROF_MARK(2);  // att tail + cell + publish
+    PROF_WHEN(0);
     straggle(lag, s, 1);
     __builtin_amdgcn_sched_barrier(0);
     // ---- P2: h_att(s) ----------------------------------------------------------------------------
@@ -621,7 +630,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       for (int i = 0; i < 2 * PB; ++i) need[i] = act[i >> 1] && t < T;
       float v[2 * PB];
       unsigned tg[2 * PB];
-      lazy_wait(attn ? g.first : g.clazy);  // the energies cannot arrive before the attention role has run
+      lazy_wait(attn ? g.efirst : g.clazy);  // the energies cannot arrive before the attention role has run
       const unsigned np_ = gather<2 * PB>(g.ep, (unsigned)((p * GS * ATTN_CU + j) * EP_LD + t), 4u * EP_LD, want, need, v, tg, pc);
       PROF_POLLS(2, np_);
 #pragma unroll
@@ -634,6 +643,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
     }
     __syncthreads();
     PROF_MARK(5);  // wait e_part
+    PROF_WHEN(3);
 #pragma unroll
     for (int b = 0; b < PB; ++b)
       if (act[b]) {  // every wave: the softmax in registers, lane <-> steps lane, lane + 64
@@ -678,6 +688,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
     }
     att_bulk(L4, false);  // for step s+1: ctx(s), h_att(s)
     PROF_MARK(7);  // dec tail + cell + publish + att bulk
+    PROF_WHEN(1);
     straggle(lag, s, 4);
     __builtin_amdgcn_sched_barrier(0);
     // ---- P5: h_dec(s) -> projection rows ---------------------------------------------------------
@@ -885,6 +896,7 @@ PersistBufs persist_bufs(unsigned long long *base, int *err, int B) {
   g.slow = 0;
   g.pfirst = 1;  // (behind the mask hashing; 0 / 1 / 2 / 3 -> 8.44 / 8.33 / 8.71 / 8.70 us per 1-chunk step)
   g.xfirst = 2;
+  g.efirst = 2;
   g.first = 2;  // ~0.4 us: the first polls of a critical consumer cannot succeed earlier (measured: -0.3 us per step)
   return g;
 }

@@ -108,6 +108,7 @@ struct PersistBufs {
                      // the two-slot exchange must keep every other workgroup from running more than one step ahead of it)
   int shrink;  // 2-chunk launch: end as soon as one chunk stops (the host continues with a 1-chunk launch)
   int first;  // delay before a critical consumer's first poll, x 512 clocks (developer knob)
+  int efirst;  // the attention role's first poll of the partial energies (it has just published its own slice)
   int xfirst;  // the same for the projection role's first poll of x (it has just published its own 16 columns)
   int pfirst;  // the same for the projection role's first poll of h_dec (behind its weight fetch and mask hashing)
   int xlazy, clazy;  // first-poll delay of the x / ctx consumers that are not their producers, x 512 clocks
