@@ -88,6 +88,38 @@ def test_pair_survivor_continues_on_the_one_chunk_kernel(pkg, orc, blob, steps):
         assert rms(out[b], orc.postnet(blob, rframes)) <= 1e-5
 
 
+def test_context_fold_table_agrees_with_the_in_kernel_fold(pkg, orc, blob):
+    """The persistent kernel needs every LSTM / projection row's context columns folded into the encoder memory
+    (W[row][ctx cols] . memory[t]).  One GEMM per request writes them as a table (views of it serve the launches of
+    chunks 2..3 and the 1-chunk launch that continues a pair's survivor); XDTTS_NO_CTXFOLD (read per handle) makes every
+    launch fold for itself.  Same products, summed in a different order: four ragged chunks (two launches of two, each
+    with a survivor hand-off) within 1e-5 of the oracle and of each other in both forms."""
+    lens = [44, 29, 7, 61]
+    steps = np.asarray([50, 33, 21, 64], dtype=np.int32)
+    ids = [synth_ids(n, seed=31 + i) for i, n in enumerate(lens)]
+    out = {}
+    for table in (True, False):
+        if not table:
+            os.environ["XDTTS_NO_CTXFOLD"] = "1"
+        try:
+            m = pkg.Tacotron2.from_blob(blob)
+        finally:
+            os.environ.pop("XDTTS_NO_CTXFOLD", None)
+        out[table] = m.infer_batch(ids, opts=pkg.default_opts(dropout_seed=19), fixed_steps=steps)
+        assert m.engine_state()["decoder_persistent"] == 1
+        m.close()
+    for b in range(4):
+        padded = np.zeros(100, dtype=np.int64)
+        padded[: lens[b]] = ids[b]
+        mem, pm = orc.encoder(blob, padded)
+        rframes, _ = orc.run_decoder(blob, mem, pm, lens[b], orc.default_opts(fixed_steps=int(steps[b]), dropout_seed=19, item=b))
+        ref = orc.postnet(blob, rframes)
+        for table in out:
+            assert out[table][b].shape == (80, steps[b]) and rms(out[table][b], ref) <= 1e-5, (table, b)
+    assert all(rms(a, c) <= 1e-5 for a, c in zip(out[True], out[False]))
+    assert any(not np.array_equal(a, c) for a, c in zip(out[True], out[False]))  # (the two forms really are different code)
+
+
 def test_three_and_four_chunks_run_as_two_persistent_launches(pkg, orc, blob):
     """B = 3..4: the persistent engine takes the chunks two at a time over views of the state arrays;
     every chunk must still equal its own single-chunk oracle run (item index = dropout stream)."""

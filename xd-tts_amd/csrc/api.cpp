@@ -206,6 +206,7 @@ struct xdtts_tacotron2 {
   DevBuf<unsigned long long> enc_exchange;
   DevBuf<int> enc_err;
   DevBuf<unsigned long long> dec_exchange;  // granule buffers of the persistent decoder
+  DevBuf<float> ctx_fold;                   // [B][CTXF_ROWS][CTXF_LD] context-fold table of the persistent decoder (kernels.h)
   DevBuf<int> dec_err;
   DevBuf<unsigned long long> att_exchange;
   DevBuf<float> att_part;  // early partial pre-activations of the attention LSTM (DecoderBufs::att_part)
@@ -224,6 +225,9 @@ struct xdtts_tacotron2 {
   // XDTTS_NO_EARLY (read when a handle is created): the attention launch multiplies its whole K instead of adding the early
   // partial of the previous decoder-LSTM launch (second form of the same arithmetic for the agreement test; results agree to 1e-5)
   bool early_partial = getenv("XDTTS_NO_EARLY") == nullptr;
+  // XDTTS_NO_CTXFOLD (read when a handle is created): the persistent kernel folds the context columns into the encoder memory
+  // itself, in every launch, instead of reading the table one GEMM per request makes (tests compare the two forms)
+  bool ctx_fold_table = getenv("XDTTS_NO_CTXFOLD") == nullptr;
   bool two_launch = getenv("XDTTS_NO_TAIL") == nullptr;  // (XDTTS_NO_TAIL: keep the prenet launch; read when a handle is created)
   int persist_state = -1;                   // -1 unknown, 0 unavailable on this device / demoted, 1 usable
   bool persist_probe_ok = false;            // the device can host the persistent grid (occupancy probe)
@@ -581,9 +585,31 @@ struct xdtts_tacotron2 {
       // A 2-chunk launch ends when its first chunk stops and the other is continued by the 1-chunk
       // kernel (~1 us per step faster): the state crosses through the kernel's write-back, x(s)
       // stays in the exchange.
+      // The context columns of every LSTM / projection row against the encoder memory, once per request (a GEMM of
+      // 0.85 GFLOP per chunk) instead of a 33 us fold loop per chunk in each of the request's launches.
+      const float *fold = nullptr;
+      if (ctx_fold_table && w.ctx_w.p) {
+        ctx_fold.alloc((size_t)d.B * CTXF_ROWS * CTXF_LD);
+        GemmArgs fg{};
+        fg.A = d.memory;
+        fg.lda = EMB;
+        fg.strideA = (long)d.T * EMB;
+        fg.W = w.ctx_w.p;
+        fg.C = ctx_fold.p;
+        fg.ldc = CTXF_LD;
+        fg.strideC = (long)CTXF_ROWS * CTXF_LD;
+        fg.M = d.T;
+        fg.N = CTXF_ROWS;
+        fg.K = EMB;
+        fg.batch = d.B;
+        fg.transpose_out = 1;
+        launch_gemm_nt(fg, stream);
+        fold = ctx_fold.p;
+      }
       auto view = [&](int b0, int n) {
         DecoderBufs v = d;
         v.B = n;
+        v.ctx_fold = fold ? fold + (size_t)b0 * CTXF_ROWS * CTXF_LD : nullptr;
         v.memory += (size_t)b0 * d.T * EMB;
         v.pmem += (size_t)b0 * d.T * ATT_DIM;
         v.n_valid += b0;

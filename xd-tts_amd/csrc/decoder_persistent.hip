@@ -351,7 +351,23 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
   // pmp [h]: the same for this wave's projection row (projection role, chunk rb).  The ctx column blocks of wa /
   // wd (k = 1, 2 and k = 4, 5) are dead after this loop: 32 weight registers make room for 8 PB + 2 of these.
   float pma[PB][2][2], pmd[PB][2][2], pmp[2] = {0.f, 0.f};
-  {
+  if (d.ctx_fold) {
+    // ... or read from the table one GEMM per request has made of them (api.cpp): 33 us of set-up less per chunk and launch
+#pragma unroll
+    for (int b = 0; b < PB; ++b)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int t = lane + 64 * h;
+        const float *F = d.ctx_fold + (size_t)b * CTXF_ROWS * CTXF_LD + t;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int row = 16 * c + wave + NW * r;
+          pma[b][r][h] = t < T ? F[(size_t)row * CTXF_LD] : 0.f;
+          pmd[b][r][h] = t < T ? F[(size_t)(4 * ATT_RNN + row) * CTXF_LD] : 0.f;
+        }
+        if (prow_ok && b == rb) pmp[h] = t < T ? F[(size_t)(4 * ATT_RNN + 4 * DEC_RNN + prow) * CTXF_LD] : 0.f;
+      }
+  } else {
     float4 pw4 = make_float4(0.f, 0.f, 0.f, 0.f), pw5 = pw4;
     if (prow_ok) {
       pw4 = lds4(s_pw + 4 * (4 * PT + tid));
@@ -866,12 +882,31 @@ __global__ void k_persist_seed_at(PersistBufs g, const int *limits, const float 
   publish(g.x + (size_t)(((step & 1) * GS + b) * PRENET + i), (unsigned)(step + 1) | (limits[b] > step ? ACT_BIT : 0u), x[b * PRENET + i]);
 }
 
+// ctx_w [CTXF_ROWS][512]: row n = the context columns of attention-LSTM row n (packed order), decoder-LSTM row n - 4096,
+// projection row n - 8192; zero rows behind.  One float4 per thread.
+__global__ void k_pack_ctx_rows(const float4 *__restrict__ att_w, const float4 *__restrict__ dec_w, const float4 *__restrict__ proj_w,
+                                float4 *__restrict__ out) {
+  const int n = blockIdx.x, q = threadIdx.x;  // q < 128: columns 4 q .. 4 q + 3
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (n < 4 * ATT_RNN) v = att_w[(size_t)n * (ATT_COLS / 4) + PRENET / 4 + q];
+  else if (n < 4 * ATT_RNN + 4 * DEC_RNN) v = dec_w[(size_t)(n - 4 * ATT_RNN) * (DEC_COLS / 4) + ATT_RNN / 4 + q];
+  else if (n <= 4 * ATT_RNN + 4 * DEC_RNN + N_MEL) v = proj_w[(size_t)(n - 4 * ATT_RNN - 4 * DEC_RNN) * (PROJ_IN / 4) + DEC_RNN / 4 + q];
+  out[(size_t)n * (EMB / 4) + q] = v;
+}
+
 template <int PB>
 void launch_pb(const DecoderBufs &d, const PersistBufs &g, const PersistWeights &pw, int nsteps, hipStream_t s) {
   COOP_CHECK(launch_coresident(true, reinterpret_cast<const void *>(k_decoder_persistent<PB>), dim3(P_NCU), dim3(PT), 0, s, d, g, pw, nsteps));
 }
 
 }  // namespace
+
+void launch_pack_ctx_rows(const float *att_w, const float *dec_w, const float *proj_w, float *ctx_w, hipStream_t s) {
+  static_assert(CTXF_ROWS >= 4 * ATT_RNN + 4 * DEC_RNN + N_MEL + 1 && CTXF_LD >= PERSIST_T_MAX, "context-fold table shape");
+  hipLaunchKernelGGL(k_pack_ctx_rows, dim3(CTXF_ROWS), dim3(EMB / 4), 0, s, reinterpret_cast<const float4 *>(att_w),
+                     reinterpret_cast<const float4 *>(dec_w), reinterpret_cast<const float4 *>(proj_w), reinterpret_cast<float4 *>(ctx_w));
+  HIP_CHECK(hipGetLastError());
+}
 
 size_t persist_granule_words(int B) {
   (void)B;

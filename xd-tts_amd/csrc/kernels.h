@@ -44,6 +44,11 @@ struct DecoderBufs {
   int Bpad;
   float *awc2;           // [B][T] second cumulative-weights buffer (ping-pong by step parity, batched mode)
   const int *item_perm;  // [B] dropout-stream index of chunk b (the batch is sorted by length), or null = b
+  // Persistent engine: the context columns of its LSTM / projection rows folded into the encoder memory,
+  // ctx_fold [B][CTXF_ROWS][CTXF_LD]: row n of chunk b holds W_n[ctx cols] . memory_b[t] for t < T (rows: 4096 attention-LSTM
+  // rows in packed order, 4096 decoder-LSTM rows, 81 projection rows; DeviceWeights::ctx_w) -- one GEMM per request
+  // (api.cpp) instead of a fold loop in every launch.  null = the kernel folds for itself.
+  const float *ctx_fold;
   const float *dec_in;   // parity hook (xdtts_tacotron2_decoder_step): decoder_input [B][80] of this step, or null
   // Batched mode: processed_memory a second time as [B][32 dim groups][T][4] -- the energies kernel reads 4 dims of
   // every time step, 16 bytes out of each 512-byte row of the [T][128] layout; in batched mode `loc` has this layout too
@@ -97,6 +102,9 @@ size_t decoder_pmel_floats(int B);
 void launch_decoder_init(const DecoderBufs &d, const int *limits_dev, hipStream_t s);
 
 // ---- persistent weight-stationary decoder (decoder_persistent.hip), small lock-step batches ------
+constexpr int CTXF_ROWS = 2 * 4096 + 128, CTXF_LD = 128;  // rows of the context-fold table (81 projection rows, padded), its row stride
+// ctx_w [CTXF_ROWS][512]: the context columns of att_w / dec_w (packed row order) and proj_w, zero rows behind
+void launch_pack_ctx_rows(const float *att_w, const float *dec_w, const float *proj_w, float *ctx_w, hipStream_t s);
 constexpr int PERSIST_B_MAX = 2;    // chunks in lock-step (register file + LDS of a CU hold the slices and two chunks' state)
 constexpr int PERSIST_T_MAX = 128;  // encoder steps (the reference's window is 100, mod.rs:363)
 // Granule exchange buffers: 8-byte {tag, value} records, [2 step parities][B][n] each.

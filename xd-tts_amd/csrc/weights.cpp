@@ -4,6 +4,7 @@
 // the NVIDIA Tacotron2 checkpoint tensors (mod.rs:137-138).  This file owns the equivalent
 // parameter set in a flat fp32 container and re-lays it out for the HIP kernels.
 #include "weights.h"
+#include "kernels.h"
 
 #include <cmath>
 #include <fstream>
@@ -337,6 +338,8 @@ void DeviceWeights::upload(const std::vector<float> &blob, hipStream_t s) {
     proj_b.upload(pb.data(), pb.size(), s);
     HIP_CHECK(hipStreamSynchronize(s));
   }
+  ctx_w.alloc((size_t)CTXF_ROWS * EMB);
+  launch_pack_ctx_rows(att_w.p, dec_w.p, proj_w.p, ctx_w.p, s);
   for (int i = 0; i < POST_CONVS; ++i) {
     int ci = i == 0 ? N_MEL : POST_CH;
     int co = i == POST_CONVS - 1 ? N_MEL : POST_CH;

@@ -58,6 +58,7 @@ struct DeviceWeights {
   DevBuf<float> loc_fused;                   // [2*31 taps][128]  location dense . conv folded (persistent decoder)
   DevBuf<float> dec_w, dec_b;                // [1024][4][2560], [1024][4]
   DevBuf<float> proj_w, proj_b;              // [81][1536] (row 80 = gate), [81]
+  DevBuf<float> ctx_w;                       // [CTXF_ROWS][512] context columns of att_w, dec_w, proj_w (persistent decoder's fold GEMM)
   // layouts for the partial-product epilogues of the LSTM kernels (decoder.hip):
   DevBuf<float> q_w4;                        // [256 blk][128 a][4]   = W_q[a][4 blk + i]
   DevBuf<float> proj_wh4;                    // [256 blk][84 m][4]    = W_p[m][4 blk + i]   (m < 81, padded to 84)
