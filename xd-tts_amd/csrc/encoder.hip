@@ -25,6 +25,7 @@ typedef __attribute__((address_space(1))) u64 gu64;
 
 constexpr int CO_BLOCKS = 4, CO_UNITS = ENC_H / CO_BLOCKS;  // 64 hidden units per block
 constexpr unsigned SPIN_LIMIT = 1u << 22;
+constexpr int ENC_FIRST_POLL = 2;  // delay before a gather thread's first poll, x 512 clocks (0 / 1 / 2 / 3 / 4: encoder 0.30 / 0.29 / 0.276 / 0.295 / 0.317 ms of the headline utterance)
 
 // NC chunks per group of four blocks: the blocks' W_hh slices are the same for every chunk, so a batch that needs more than
 // one launch of one-chunk groups (52 chunks: 26 + 26 on 256 CUs) runs as ONE launch of two-chunk groups instead -- a step is
@@ -35,7 +36,7 @@ template <int NC>
 __global__ __launch_bounds__(1024) void k_bilstm_coop(const float *__restrict__ xproj,
                                                       const float *__restrict__ whhT_f,
                                                       const float *__restrict__ whhT_b, float *memory, u64 *exchange,
-                                                      int *err, int B, int T, int b0, int Btot, unsigned spin_limit, int fault) {
+                                                      int *err, int B, int T, int b0, int Btot, unsigned spin_limit, int fault, int first) {
   // (spin_limit / fault: test hooks -- poll limit, and a block (linear index + 1) that never publishes)
   // this launch runs chunks b0 .. b0+B-1 of a batch of Btot (xproj is [2][Btot][T][4H], memory [Btot][T][EMB])
   const int k = blockIdx.x, dir = blockIdx.y, tid = threadIdx.x;
@@ -111,6 +112,9 @@ __global__ __launch_bounds__(1024) void k_bilstm_coop(const float *__restrict__ 
         u64 v = 0;
         unsigned spins = 0;
         const bool skip = dead != 0;
+        // the peers' cell updates and the stores' way through the fabric take ~0.6 us: a poll issued before that
+        // only costs a round trip (x 512 clocks; the decoder's first-poll delay)
+        for (int i = 0; i < first; ++i) __builtin_amdgcn_s_sleep(8);
         while (!skip) {
           v = __hip_atomic_load(ex[j] + (s & 1) * ENC_H + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if ((unsigned)(v >> 32) == (unsigned)(s + 1)) break;
@@ -138,6 +142,8 @@ void launch_bilstm_coop(const float *xproj, const float *whhT_fwd, const float *
   int fault = 0;
   if (const char *e = getenv("XDTTS_ENC_SPINS")) spins = (unsigned)atoi(e);  // test hooks for the lost-workgroup path
   if (const char *e = getenv("XDTTS_ENC_FAULT")) fault = atoi(e);
+  int first = ENC_FIRST_POLL;
+  if (const char *e = getenv("XDTTS_ENC_FIRST")) first = atoi(e);  // developer tuning knob
   // 8 workgroups per group of chunks must be co-resident, so a large batch runs as launches of at most `group` groups each
   // (sized to the CU count by the caller); a batch of more than `group` chunks puts two chunks on a group.  The exchange
   // buffer (bilstm_coop_exchange_words(2 * group) then) is reused between launches.
@@ -148,7 +154,7 @@ void launch_bilstm_coop(const float *xproj, const float *whhT_fwd, const float *
     HIP_CHECK(hipMemsetAsync(exchange, 0, bilstm_coop_exchange_words(n) * sizeof(unsigned long long), s));
     const void *fn = nc == 2 ? reinterpret_cast<const void *>(k_bilstm_coop<2>) : reinterpret_cast<const void *>(k_bilstm_coop<1>);
     COOP_CHECK(launch_coresident(true, fn, dim3(CO_BLOCKS, 2, (n + nc - 1) / nc), dim3(1024), 0, s, xproj, whhT_fwd, whhT_bwd, memory, exchange,
-                                 err, n, T, b0, B, spins, fault));
+                                 err, n, T, b0, B, spins, fault, first));
   }
 }
 
