@@ -227,6 +227,12 @@ __device__ __forceinline__ int reflect_index(int p, int N) {
   return p;
 }
 
+// the same for |overhang| < N (signals longer than the pad): branch-free
+__device__ __forceinline__ int reflect_once(int p, int N) {
+  p = p < 0 ? -p : p;
+  return p >= N ? 2 * (N - 1) - p : p;
+}
+
 // window sum-of-squares divisor per output sample (1 where the sum is below tiny, like librosa)
 __global__ void k_wss_inv(GlBufs g) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -774,7 +780,9 @@ __global__ __launch_bounds__(64 * W, PC) void k_gl_persistent(GlBufs g, GlPersis
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
           const int base = f * HOP + 2 * (lane + 64 * r) - NFFT / 2;
-          const float y0 = yb[reflect_index(base, N) + NFFT / 2 - Q0], y1 = yb[reflect_index(base + 1, N) + NFFT / 2 - Q0];
+          // (one fold suffices: this engine runs from 16 frames on, N >= 3840 > the 512-sample pad -- and the general
+          // loop cost the two edge workgroups 1.1 us per iteration that every other workgroup then waited for)
+          const float y0 = yb[reflect_once(base, N) + NFFT / 2 - Q0], y1 = yb[reflect_once(base + 1, N) + NFFT / 2 - Q0];
           v[r] = make_float2(y0 * wn[r].x, y1 * wn[r].y);
         }
       }
