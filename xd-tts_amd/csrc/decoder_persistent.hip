@@ -62,7 +62,7 @@ constexpr int GS = PERSIST_B_MAX;        // chunk stride of the granule arrays: 
                                          // 1-chunk launch can continue a sequence that a 2-chunk launch began
 constexpr unsigned P_SPIN_LIMIT = 1u << 21;
 constexpr unsigned ACT_BIT = 0x80000000u;
-constexpr int PERSIST_LAZY_DEFAULT = 4;  // ~0.85 us; measured flat from 2 to 12, 1 us per step better than 0
+constexpr int PERSIST_LAZY_DEFAULT = 9;  // x 256 clocks: ~0.95 us (6 / 7 / 8 / 9 / 10 -> 8.53 / 8.45 / 8.38 / 8.26 / 8.35 us per 1-chunk step; 0: +1.3 us)
 
 constexpr int WPAD = TP + 32;            // zero-padded attention-weight window, index t + 15
 static_assert(ATT_RNN == DEC_RNN && P_NCU == 256, "one workgroup per 4 + 4 hidden units");
@@ -121,10 +121,10 @@ __device__ __forceinline__ unsigned gather(const u64 *base, unsigned idx, unsign
   }
 }
 
-// Workgroups that consume a vector only for off-critical-path work start polling it late (n x 512
+// Workgroups that consume a vector only for off-critical-path work start polling it late (n x 256
 // clocks): their polls would otherwise sit in the memory queues the critical consumers wait on.
-__device__ __forceinline__ void lazy_wait(int n) {
-  for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(8);
+__device__ __forceinline__ void lazy_wait(int n) {  // n x 256 clocks
+  for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(4);
 }
 // test hook (PersistBufs::slow): this workgroup is a straggler at point `at` of step s when at == s mod 6
 __device__ __forceinline__ void straggle(bool me, int s, int at) {
@@ -924,15 +924,15 @@ PersistBufs persist_bufs(unsigned long long *base, int *err, int B) {
   g.err = err;
   g.lazy = PERSIST_LAZY_DEFAULT;
   g.xlazy = 0;  // round 3 re-sweep (profiles/r03_lazy_sweep.txt): 0 / 1 / 2 / 3 / 4 -> 9.93 / 10.03 / 10.14 / 10.29 / 10.52 us per 1-chunk step
-  g.clazy = 2;
+  g.clazy = 4;
   g.shrink = 0;
   g.spins = 0;
   g.fault = 0;
   g.slow = 0;
-  g.pfirst = 1;  // (behind the mask hashing; 0 / 1 / 2 / 3 -> 8.44 / 8.33 / 8.71 / 8.70 us per 1-chunk step)
-  g.xfirst = 2;
-  g.efirst = 2;
-  g.first = 2;  // ~0.4 us: the first polls of a critical consumer cannot succeed earlier (measured: -0.3 us per step)
+  g.pfirst = 0;  // x 256 clocks (behind the mask hashing; 0 / 1 / 2 / 3 -> 8.44 / 8.33 / 8.71 / 8.70 us per 1-chunk step)
+  g.xfirst = 4;
+  g.efirst = 3;  // (with pfirst 0 and lazy 9: 8.38 / 11.39 -> 8.19 / 11.19 us per step, 1 / 2 chunks)
+  g.first = 4;  // x 256 clocks, ~0.4 us: the first polls of a critical consumer cannot succeed earlier (measured: -0.3 us per step)
   return g;
 }
 

@@ -115,12 +115,12 @@ struct PersistBufs {
   int slow;          // test hook: a workgroup (index + 1) that stalls ~7 us at a different point of every step (straggler:
                      // the two-slot exchange must keep every other workgroup from running more than one step ahead of it)
   int shrink;  // 2-chunk launch: end as soon as one chunk stops (the host continues with a 1-chunk launch)
-  int first;  // delay before a critical consumer's first poll, x 512 clocks (developer knob)
+  int first;  // delay before a critical consumer's first poll, x 256 clocks (developer knob)
   int efirst;  // the attention role's first poll of the partial energies (it has just published its own slice)
   int xfirst;  // the same for the projection role's first poll of x (it has just published its own 16 columns)
   int pfirst;  // the same for the projection role's first poll of h_dec (behind its weight fetch and mask hashing)
-  int xlazy, clazy;  // first-poll delay of the x / ctx consumers that are not their producers, x 512 clocks
-  int lazy;  // late-poll delay of the off-critical-path consumers, x 512 clocks
+  int xlazy, clazy;  // first-poll delay of the x / ctx consumers that are not their producers, x 256 clocks
+  int lazy;  // late-poll delay of the off-critical-path consumers, x 256 clocks
   unsigned long long *prof;  // developer profile build only: [256][16] phase clocks, else null
 };
 size_t persist_granule_words(int B);
