@@ -120,6 +120,36 @@ def test_context_fold_table_agrees_with_the_in_kernel_fold(pkg, orc, blob):
     assert any(not np.array_equal(a, c) for a, c in zip(out[True], out[False]))  # (the two forms really are different code)
 
 
+def test_skewed_pair_loop_is_bit_identical_to_the_lock_step_loop(pkg, orc, blob):
+    """A pair of chunks runs the persistent kernel's skewed loop (the chunks two phases apart, a workgroup alternating
+    between them, the next phase's first poll issued ahead); XDTTS_NO_SKEW (read per handle) keeps the lock-step loop.
+    The arithmetic of a chunk is the same code in the same order in both, so the mels must be bit-identical -- with the
+    gate deciding (either chunk may stop first: the rigged gate trips chunk 0 at 21 frames; with the chunks swapped it
+    trips chunk 1), with fixed ragged step counts, and for four chunks (two launches of two)."""
+    mem, pm = encode(orc, blob, 33)
+    rig = rigged_gate_blob(orc, blob, mem, pm, 33, 21, 30)
+    a, b = synth_ids(33, seed=1), synth_ids(57, seed=2)
+    cases = [(rig, [a, b], dict(opts=pkg.default_opts(dropout_seed=21, max_steps=48))),
+             (rig, [b, a], dict(opts=pkg.default_opts(dropout_seed=21, max_steps=48))),
+             (blob, [a, b], dict(opts=pkg.default_opts(dropout_seed=5), fixed_steps=np.asarray([37, 52], dtype=np.int32))),
+             (blob, [b, a, synth_ids(12, seed=3), synth_ids(70, seed=4)], dict(opts=pkg.default_opts(dropout_seed=9), fixed_steps=np.asarray([41, 17, 30, 55], dtype=np.int32)))]
+    for wblob, ids, kw in cases:
+        out = {}
+        for skew in (True, False):
+            if not skew:
+                os.environ["XDTTS_NO_SKEW"] = "1"
+            try:
+                m = pkg.Tacotron2.from_blob(wblob)
+            finally:
+                os.environ.pop("XDTTS_NO_SKEW", None)
+            out[skew] = m.infer_batch(ids, **kw)
+            assert m.engine_state()["decoder_persistent"] == 1
+            m.close()
+        assert len(out[True]) == len(out[False]) == len(ids)
+        for x, y in zip(out[True], out[False]):
+            assert x.shape == y.shape and np.array_equal(x, y)
+
+
 def test_three_and_four_chunks_run_as_two_persistent_launches(pkg, orc, blob):
     """B = 3..4: the persistent engine takes the chunks two at a time over views of the state arrays;
     every chunk must still equal its own single-chunk oracle run (item index = dropout stream)."""

@@ -228,6 +228,8 @@ struct xdtts_tacotron2 {
   // XDTTS_NO_CTXFOLD (read when a handle is created): the persistent kernel folds the context columns into the encoder memory
   // itself, in every launch, instead of reading the table one GEMM per request makes (tests compare the two forms)
   bool ctx_fold_table = getenv("XDTTS_NO_CTXFOLD") == nullptr;
+  // XDTTS_NO_SKEW (read when a handle is created): pairs of chunks run the persistent kernel's lock-step loop instead of the skewed one
+  bool pair_skew = getenv("XDTTS_NO_SKEW") == nullptr;
   bool two_launch = getenv("XDTTS_NO_TAIL") == nullptr;  // (XDTTS_NO_TAIL: keep the prenet launch; read when a handle is created)
   int persist_state = -1;                   // -1 unknown, 0 unavailable on this device / demoted, 1 usable
   bool persist_probe_ok = false;            // the device can host the persistent grid (occupancy probe)
@@ -642,6 +644,7 @@ struct xdtts_tacotron2 {
         if (const char *pf = getenv("XDTTS_PFIRST")) g.pfirst = atoi(pf);
         if (const char *xf = getenv("XDTTS_XFIRST")) g.xfirst = atoi(xf);
         if (const char *ef = getenv("XDTTS_EFIRST")) g.efirst = atoi(ef);
+        if (!pair_skew) g.skew = 0;
         if (const char *xl = getenv("XDTTS_XLAZY")) g.xlazy = atoi(xl);
         if (const char *cl = getenv("XDTTS_CLAZY")) g.clazy = atoi(cl);
         if (const char *sp = getenv("XDTTS_PERSIST_SPINS")) g.spins = atoi(sp);  // test hooks for the

@@ -39,6 +39,8 @@
 //
 // Every spin is bounded and watches a global error word: a lost workgroup (grid not co-resident)
 // drains the whole launch in microseconds and surfaces as XDTTS_ERR_HIP on the host.
+#include <type_traits>
+
 #include "device_utils.h"
 #include "kernels.h"
 
@@ -88,15 +90,34 @@ __device__ __forceinline__ bool give_up(unsigned &spins, const PollCtl &pc) {
 // N granules at base[idx + i * stride], all loads in flight together; `base` is uniform and the
 // offsets are 32-bit so the loads use the SGPR-base addressing form (no 64-bit VGPR addresses kept
 // live across the step loop).  A timed-out slot reads as {tag 0, 0.0f}.
-template <int N>
+// PRE: the first poll of every granule was issued earlier (pre[i], by the previous phase of the skewed pair loop); a value
+// whose tag is not this step's -- not there yet, or nothing was issued -- is polled as usual.
+template <int N, bool PRE = false>
 __device__ __forceinline__ unsigned gather(const u64 *base, unsigned idx, unsigned stride, unsigned want,
-                                           const bool (&need)[N], float (&out)[N], unsigned (&tag)[N], const PollCtl &err) {
+                                           const bool (&need)[N], float (&out)[N], unsigned (&tag)[N], const PollCtl &err,
+                                           const u64 *pre = nullptr) {
   bool done[N];
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     done[i] = !need[i];
     out[i] = 0.f;
     tag[i] = 0u;
+  }
+  if (PRE) {
+    bool all = true;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      if (!done[i]) {
+        const unsigned t = (unsigned)(pre[i] >> 32);
+        if ((t & ~ACT_BIT) == want) {
+          out[i] = __uint_as_float((unsigned)pre[i]);
+          tag[i] = t;
+          done[i] = true;
+        } else {
+          all = false;
+        }
+      }
+    if (all) return 0u;
   }
   unsigned spins = 0;
   for (;;) {
@@ -185,7 +206,10 @@ struct PersistWeights {
   const float *att_b, *dec_b, *v_w, *loc_fused, *proj_b, *pre0T, *pre1T;
 };
 
-template <int PB>
+// SKEW (PB = 2 only): the two chunks do not run their steps in lock-step but two phases apart, a workgroup alternating
+// between them -- while one chunk's vector crosses the chip the workgroup runs the other chunk's phase instead of sleeping
+// (see the loop at "skewed pair").
+template <int PB, bool SKEW = false>
 __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, PersistBufs g, PersistWeights w, int nsteps) {
   // static LDS: with compile-time addresses the per-access offsets fold into the ds instructions
   // (a dynamic base made the compiler keep ~100 hoisted addresses live across the step loop)
@@ -487,6 +511,391 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
 #endif
   int s = step0;
   const int s_stop = step0 + nsteps;
+  if constexpr (SKEW) {
+    // ---- skewed pair --------------------------------------------------------------------------------------------------
+    // A step of one chunk is five phases, each a gather (wait for a vector to cross the chip, ~1 us) followed by the
+    // arithmetic that needs it and a publish:  ph1 x -> attention-LSTM tail -> h_att;  ph2 h_att -> (attention role) query,
+    // energies;  ph3 energies -> softmax, decoder-LSTM tail -> h_dec;  ph4 h_dec -> (projection role) mel rows;
+    // ph5 (projection role) mel -> prenet -> x.  In lock-step both chunks wait together and compute one after the other;
+    // here chunk 1 runs two phases behind chunk 0 and a workgroup alternates between the chunks, so that one chunk's
+    // arithmetic fills the other's wait:
+    //     c0.ph1(s) c1.ph4(s-1) | c0.ph2(s) c1.ph5(s-1) | c0.ph3(s) c1.ph1(s) | c0.ph4(s) c1.ph2(s) | c0.ph5(s) c1.ph3(s)
+    // The launch ends when either chunk stops (the host continues the other with the 1-chunk kernel): chunk 0 found
+    // stopped at its ph1(s) -> chunk 1 completes step s-1, both have run s steps; chunk 1 found stopped at its ph1(s) ->
+    // chunk 0 completes step s: it has run s+1 steps, which is what ctl[0] then says (it is the survivor).
+    static_assert(PB == 2, "the skewed loop is the pair kernel");
+    const int tid_k = tid;
+    const bool lag = g.slow && c == g.slow - 1;
+    unsigned drop1 = 0u, drop2 = 0u;  // projection role: masks of step s+1, hashed in ph4, used in ph5
+    // The first poll of a phase's vector is issued by the phase BEFORE it (the other chunk's), at its very end: a phase pays
+    // the poll's round trip (~0.45 us) even when its vector has long arrived, and part of that now runs under the previous
+    // phase's tail.  (Issued earlier -- right behind that phase's publish -- the poll samples the slots before the slowest
+    // producer's store has landed: 10.98 us per step against 10.6-10.7; in the middle of the deferred column blocks: the
+    // same as behind them; lock-step: 11.27.)  The granules validate themselves (tag = step + 1), so a poll that was too
+    // early, or none at all at the ends of the sequence, only means the ordinary poll loop.
+    u64 pf[2] = {0ull, 0ull};
+    auto issue_x = [&](auto B, int s) {
+      constexpr int b = decltype(B)::value;
+      const int tid = tid_k + (int)opaque(0u);
+      pf[0] = tid < 256 ? peek(g.x + (unsigned)(((s & 1) * GS + b) * PRENET + (tid & 255))) : 0ull;
+      pf[1] = 0ull;
+    };
+    auto issue_h = [&](const u64 *base, auto B, int s) {  // h_att / h_dec (both 1024 wide)
+      constexpr int b = decltype(B)::value;
+      const int tid = tid_k + (int)opaque(0u);
+      pf[0] = peek(base + (unsigned)(((s & 1) * GS + b) * ATT_RNN + tid));
+      pf[1] = peek(base + (unsigned)(((s & 1) * GS + b) * ATT_RNN + tid + PT));
+    };
+    auto issue_ep = [&](auto B, int s) {
+      constexpr int b = decltype(B)::value;
+      const int tid = tid_k + (int)opaque(0u), t = tid >> 2, j = tid & 3;
+      pf[0] = t < T ? peek(g.ep + (unsigned)((((s & 1) * GS + b) * ATTN_CU + j) * EP_LD + t)) : 0ull;
+      pf[1] = t < T ? peek(g.ep + (unsigned)((((s & 1) * GS + b) * ATTN_CU + j + 4) * EP_LD + t)) : 0ull;
+    };
+    auto issue_mel = [&](auto B, int s) {
+      constexpr int b = decltype(B)::value;
+      const int tid = tid_k + (int)opaque(0u);
+      pf[0] = (pre && rb == b && tid < N_MEL + 1) ? peek(g.mel + (unsigned)((((s & 1) * GS + b) * MEL_GL + tid) * MEL_ST)) : 0ull;
+      pf[1] = 0ull;
+    };
+    auto I0 = std::integral_constant<int, 0>{};
+    auto I1 = std::integral_constant<int, 1>{};
+    auto att_bulk1 = [&](auto B, unsigned L4) {
+      constexpr int b = decltype(B)::value;
+      const float w0 = wreg[b][0], w1 = wreg[b][1];
+      float a0 = fmaf(pma[b][0][1], w1, pma[b][0][0] * w0), a1 = fmaf(pma[b][1][1], w1, pma[b][1][0] * w0);
+#pragma unroll
+      for (int k = 3; k < 7; ++k) {
+        const float4 v = lds4(s_hatt + b * ATT_RNN + 256 * (k - 3) + L4);
+        a0 = dot4(wa[0][k], v, a0);
+        a1 = dot4(wa[1][k], v, a1);
+      }
+      aacc[b][0] = a0;
+      aacc[b][1] = a1;
+    };
+    auto dec_bulk_h1 = [&](auto B, unsigned L4) {
+      constexpr int b = decltype(B)::value;
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int k = 6; k < 10; ++k) {
+        const float4 v = lds4(s_hdec + b * DEC_RNN + 256 * (k - 6) + L4);
+        a0 = dot4(wd[0][k], v, a0);
+        a1 = dot4(wd[1][k], v, a1);
+      }
+      dacc[b][0] = a0;
+      dacc[b][1] = a1;
+    };
+    // ph1: x(s) -> attention-LSTM tail -> publish h_att(s).  false: the chunk has stopped (or the exchange failed).
+    auto ph1 = [&](auto B, int s, auto nxt) -> bool {
+      constexpr int b = decltype(B)::value;
+      const int tid = tid_k + (int)opaque(0u), lane = tid & 63, wave = tid >> 6;
+      const unsigned L4 = 4u * (unsigned)lane;
+      const int p = s & 1;
+      const unsigned want = (unsigned)(s + 1);
+      if (b == 0) straggle(lag, s, 0);
+      {
+        const int i = tid & 255;
+        const bool need[1] = {tid < 256};
+        float v[1];
+        unsigned tg[1];
+        gather<1, true>(g.x, (unsigned)((p * GS + b) * PRENET + i), 0u, want, need, v, tg, pc, pf);
+        if (need[0]) {
+          s_x[b * PRENET + i] = v[0];
+          if (i == 0) s_act[b] = (tg[0] & ACT_BIT) ? 1 : 0;
+        }
+        if (tid == PT - 1) s_act[4] = __hip_atomic_load(g.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+      const bool on = s_act[b] != 0 && s_act[4] == 0;
+      if (!on) return false;  // (workgroup-uniform)
+      {
+        const float4 v = lds4(s_x + b * PRENET + L4);
+        const float a0 = wave_sum(dot4(wa[0][0], v, aacc[b][0]));
+        const float a1 = wave_sum(dot4(wa[1][0], v, aacc[b][1]));
+        if (lane == 0) {
+          s_g[b * 16 + wave] = a0 + s_bias[wave];
+          s_g[b * 16 + wave + NW] = a1 + s_bias[wave + NW];
+        }
+      }
+      __syncthreads();
+      if (tid < 4 * PB && (tid >> 2) == b) {
+        const int cu = tid & 3;
+        const float *gp = s_g + b * 16 + 4 * cu;
+        const float ig = fast_sigmoid(gp[0]), fg = fast_sigmoid(gp[1]), gg = fast_tanh(gp[2]), og = fast_sigmoid(gp[3]);
+        const float cn = fmaf(fg, s_cell[tid], ig * gg), hn = og * fast_tanh(cn);
+        publish(g.hatt + (unsigned)((p * GS + b) * ATT_RNN + 4 * c + cu), want, hn);
+        s_cell[tid] = cn;
+        s_cell[8 * PB + tid] = hn;
+      }
+      nxt();
+      if (b == 0) straggle(lag, s, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      return true;
+    };
+    // ph2: h_att(s) -> (attention role of this chunk) query rows, partial energies -> publish; decoder LSTM's h_att columns
+    auto ph2 = [&](auto B, int s, auto nxt) {
+      constexpr int b = decltype(B)::value;
+      const int tid = tid_k + (int)opaque(0u), lane = tid & 63, wave = tid >> 6;
+      const unsigned L4 = 4u * (unsigned)lane, TID = (unsigned)tid;
+      const int p = s & 1;
+      const unsigned want = (unsigned)(s + 1);
+      const bool mine = attn && rb == b;
+      float4 lp4 = make_float4(0.f, 0.f, 0.f, 0.f), v4 = lp4;
+      if (mine) {
+        const float4 l4 = lds4(s_loc + 4 * TID), p4 = lds4(s_pm + 4 * TID);
+        lp4 = make_float4(l4.x + p4.x, l4.y + p4.y, l4.z + p4.z, l4.w + p4.w);
+        v4 = lds4(s_vv + 4 * (tid & 3));
+      }
+      {
+        const bool need[2] = {true, true};
+        float v[2];
+        unsigned tg[2];
+        gather<2, true>(g.hatt, (unsigned)((p * GS + b) * ATT_RNN + tid), PT, want, need, v, tg, pc, pf);
+        s_hatt[b * ATT_RNN + TID] = v[0];
+        s_hatt[b * ATT_RNN + TID + PT] = v[1];
+      }
+      __syncthreads();
+      if (mine) {
+        float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 v = lds4(s_hatt + b * ATT_RNN + 256 * j + L4);
+          q0 = dot4(lds4(s_qw + 4 * (j * PT + TID)), v, q0);
+          q1 = dot4(lds4(s_qw + 4 * ((4 + j) * PT + TID)), v, q1);
+        }
+        q0 = wave_sum(q0);
+        q1 = wave_sum(q1);
+        if (lane == 0) {
+          s_q[wave] = q0;
+          s_q[wave + NW] = q1;
+        }
+        __syncthreads();
+        const int t = tid >> 2, dq = 4 * (tid & 3);
+        const float4 q4 = lds4(s_q + dq);
+        float e = v4.x * fast_tanh(q4.x + lp4.x);
+        e = fmaf(v4.y, fast_tanh(q4.y + lp4.y), e);
+        e = fmaf(v4.z, fast_tanh(q4.z + lp4.z), e);
+        e = fmaf(v4.w, fast_tanh(q4.w + lp4.w), e);
+        e += dpp_move<0xB1, 0xf>(0.f, e);  // quad_perm:[1,0,3,2]
+        e += dpp_move<0x4E, 0xf>(0.f, e);  // quad_perm:[2,3,0,1]
+        if ((tid & 3) == 0 && t < T) publish(g.ep + (unsigned)(((p * GS + b) * ATTN_CU + rk) * EP_LD + t), want, e);
+      }
+      {
+        float a0 = dacc[b][0], a1 = dacc[b][1];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float4 v = lds4(s_hatt + b * ATT_RNN + 256 * k + L4);
+          a0 = dot4(wd[0][k], v, a0);
+          a1 = dot4(wd[1][k], v, a1);
+        }
+        dacc[b][0] = a0;
+        dacc[b][1] = a1;
+      }
+      nxt();
+      if (b == 0) straggle(lag, s, 2);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // ph3: partial energies -> softmax -> decoder-LSTM tail -> publish h_dec(s); attention LSTM's [ctx ; h_att] columns of step s+1
+    auto ph3 = [&](auto B, int s, auto nxt) {
+      constexpr int b = decltype(B)::value;
+      const int tid = tid_k + (int)opaque(0u), lane = tid & 63, wave = tid >> 6;
+      const unsigned L4 = 4u * (unsigned)lane;
+      const int p = s & 1;
+      const unsigned want = (unsigned)(s + 1);
+      const bool mine = attn && rb == b;
+      {
+        const int t = tid >> 2, j = tid & 3;
+        const bool need[2] = {t < T, t < T};
+        float v[2];
+        unsigned tg[2];
+        gather<2, true>(g.ep, (unsigned)(((p * GS + b) * ATTN_CU + j) * EP_LD + t), 4u * EP_LD, want, need, v, tg, pc, pf);
+        float e = v[0] + v[1];
+        e += dpp_move<0xB1, 0xf>(0.f, e);  // quad_perm:[1,0,3,2]
+        e += dpp_move<0x4E, 0xf>(0.f, e);  // quad_perm:[2,3,0,1]
+        if (j == 0) s_e[b * TP + t] = (t < T && t < nv[b]) ? e : -INFINITY;  // mask, mod.rs:219-220
+      }
+      __syncthreads();
+      {
+        const float e0 = s_e[b * TP + lane], e1 = s_e[b * TP + lane + 64];
+        const float m = wave_max(fmaxf(e0, e1));
+        const float x0 = fast_exp(e0 - m), x1 = fast_exp(e1 - m);
+        const float rs = __builtin_amdgcn_rcpf(wave_sum(x0 + x1));
+        wreg[b][0] = x0 * rs;
+        wreg[b][1] = x1 * rs;
+      }
+      if (mine && wave == 0) {
+        s_aw[lane] = wreg[b][0];
+        s_awc[lane] += wreg[b][0];
+        s_aw[lane + 64] = wreg[b][1];
+        s_awc[lane + 64] += wreg[b][1];
+      }
+      if (b == 0) straggle(lag, s, 3);
+      {
+        const float w0 = wreg[b][0], w1 = wreg[b][1];
+        float a0 = fmaf(pmd[b][0][1], w1, fmaf(pmd[b][0][0], w0, dacc[b][0]));
+        float a1 = fmaf(pmd[b][1][1], w1, fmaf(pmd[b][1][0], w0, dacc[b][1]));
+        a0 = wave_sum(a0);
+        a1 = wave_sum(a1);
+        if (lane == 0) {
+          s_g[b * 16 + wave] = a0 + s_bias[16 + wave];
+          s_g[b * 16 + wave + NW] = a1 + s_bias[16 + wave + NW];
+        }
+      }
+      __syncthreads();
+      if (tid < 4 * PB && (tid >> 2) == b) {
+        const int cu = tid & 3;
+        const float *gp = s_g + b * 16 + 4 * cu;
+        const float ig = fast_sigmoid(gp[0]), fg = fast_sigmoid(gp[1]), gg = fast_tanh(gp[2]), og = fast_sigmoid(gp[3]);
+        const float cn = fmaf(fg, s_cell[4 * PB + tid], ig * gg), hn = og * fast_tanh(cn);
+        publish(g.hdec + (unsigned)((p * GS + b) * DEC_RNN + 4 * c + cu), want, hn);
+        s_cell[4 * PB + tid] = cn;
+        s_cell[12 * PB + tid] = hn;
+      }
+      att_bulk1(B, L4);  // for step s+1: ctx(s), h_att(s)
+      nxt();
+      if (b == 0) straggle(lag, s, 4);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // ph4: h_dec(s) -> (projection role of this chunk) mel rows -> publish; decoder LSTM's own-state columns of step s+1;
+    // (attention role of this chunk) location features of step s+1
+    auto ph4 = [&](auto B, int s, auto nxt) {
+      constexpr int b = decltype(B)::value;
+      const int tid = tid_k + (int)opaque(0u), lane = tid & 63, wave = tid >> 6;
+      const unsigned L4 = 4u * (unsigned)lane, TID = (unsigned)tid;
+      const int p = s & 1;
+      const unsigned want = (unsigned)(s + 1);
+      const bool mine = pre && rb == b;
+      const int prow = rk + 16 * wave;
+      const bool prow_ok = mine && wave < 6 && prow <= N_MEL;
+      if (mine) {
+        drop1 = 0u;
+        drop2 = 0u;
+        if (d.dropout_mode) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            drop1 |= (prenet_dropped(d.dropout_mode, d.dropout_seed, item, d.drop_masks, d.drop_steps, rb, s + 1, 0, lane + 64 * k) ? 1u : 0u) << k;
+#pragma unroll
+          for (int r = 0; r < 2; ++r)
+            drop2 |= (prenet_dropped(d.dropout_mode, d.dropout_seed, item, d.drop_masks, d.drop_steps, rb, s + 1, 1, 16 * rk + wave + NW * r) ? 1u : 0u) << r;
+        }
+      }
+      {
+        const bool need[2] = {true, true};
+        float v[2];
+        unsigned tg[2];
+        gather<2, true>(g.hdec, (unsigned)((p * GS + b) * DEC_RNN + tid), PT, want, need, v, tg, pc, pf);
+        s_hdec[b * DEC_RNN + TID] = v[0];
+        s_hdec[b * DEC_RNN + TID + PT] = v[1];
+      }
+      __syncthreads();
+      if (prow_ok) {
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a = dot4(lds4(s_pw + 4 * (j * PT + TID)), lds4(s_hdec + b * DEC_RNN + 256 * j + L4), a);
+        a = fmaf(pmp[1], wreg[b][1], fmaf(pmp[0], wreg[b][0], a));  // the context columns
+        a = wave_sum(a);
+        if (lane == 0) publish(g.mel + (unsigned)(((p * GS + b) * MEL_GL + prow) * MEL_ST), want, a + s_pb[wave]);
+      }
+      dec_bulk_h1(B, L4);  // for step s+1
+      nxt();
+      if (attn && rb == b) location(tid);
+      if (b == 0) straggle(lag, s, 5);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // ph5 (projection + prenet role of this chunk): frame s, stop rule, x(s+1)
+    auto ph5 = [&](auto B, int s, auto nxt) {
+      constexpr int b = decltype(B)::value;
+      if (!(pre && rb == b)) {  // (workgroup-uniform)
+        nxt();
+        return;
+      }
+      const int tid = tid_k + (int)opaque(0u), lane = tid & 63, wave = tid >> 6;
+      const unsigned L4 = 4u * (unsigned)lane, TID = (unsigned)tid;
+      const int p = s & 1;
+      const unsigned want = (unsigned)(s + 1);
+      if (tid < N_MEL + 1) {
+        const bool need[1] = {true};
+        float v[1];
+        unsigned tg[1];
+        gather<1, true>(g.mel, (unsigned)(((p * GS + b) * MEL_GL + tid) * MEL_ST), 0, want, need, v, tg, pc, pf);
+        s_mel[tid] = v[0];
+      }
+      __syncthreads();
+      const float gate = s_mel[N_MEL];
+      const bool fired = d.use_gate && gate_sigmoid(gate) > d.gate_threshold;  // mod.rs:319-324
+      if (rk == 0) {
+        if (tid < N_MEL) d.frames[((size_t)b * d.max_steps + s) * N_MEL + tid] = s_mel[tid];
+        if (tid == 0) {
+          d.gates[(size_t)b * d.max_steps + s] = gate;
+          if (fired) d.nframes[b] = s + 1;  // the tripping frame is kept
+        }
+      }
+      if (fired) nf_r = s + 1;
+      const bool more = s + 1 < nf_r;
+      float xo[2] = {0.f, 0.f};
+      if (more) {
+        const unsigned HM = (unsigned)((tid >> 8) * (N_MEL / 2));
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < N_MEL / 2; k += 4) {
+          const float4 w4 = lds4(s_W0 + 4u * (((HM + k) >> 2) * PRENET + (TID & 255u))), m = lds4(s_mel + HM + k);
+          acc = fmaf(w4.x, m.x, acc);
+          acc = fmaf(w4.y, m.y, acc);
+          acc = fmaf(w4.z, m.z, acc);
+          acc = fmaf(w4.w, m.w, acc);
+        }
+        s_l1[TID] = acc;
+        __syncthreads();
+        float pk[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float v = fmaxf(s_l1[(L4 >> 2) + 64 * k] + s_l1[PRENET + (L4 >> 2) + 64 * k], 0.f);
+          pk[k] = (drop1 >> k) & 1u ? 0.f : (d.dropout_mode ? 2.f * v : v);
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          float a = 0.f;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) a = fmaf(w1r[r][k], pk[k], a);
+          a = fmaxf(wave_sum(a), 0.f);
+          xo[r] = (drop2 >> r) & 1u ? 0.f : (d.dropout_mode ? 2.f * a : a);
+        }
+      }
+      if (lane < 2) s_mel[MEL_GL - 16 + wave + NW * lane] = lane ? xo[1] : xo[0];  // s_mel[81..95] is unused padding
+      __syncthreads();
+      if (tid < 16)
+        publish(g.x + (unsigned)(((p ^ 1) * GS + b) * PRENET + 16 * rk + tid), (want + 1u) | (more ? ACT_BIT : 0u),
+                s_mel[MEL_GL - 16 + tid]);
+      nxt();
+    };
+    bool tail1 = false;  // chunk 1 has run ph1..ph3 of step s-1: its ph4 / ph5 come in the first half of this round
+    if (s_act[2] != 0 && s_act[3] != 0) {
+      issue_x(I0, s);
+      for (;; ++s) {
+        bool a0 = s < s_stop;
+        if (a0) a0 = ph1(I0, s, [&] { if (tail1) issue_h(g.hdec, I1, s - 1); else issue_h(g.hatt, I0, s); });
+        if (tail1) ph4(I1, s - 1, [&] { if (a0) issue_h(g.hatt, I0, s); });
+        if (a0) ph2(I0, s, [&] { if (tail1) issue_mel(I1, s - 1); else issue_ep(I0, s); });
+        if (tail1) {
+          ph5(I1, s - 1, [&] { if (a0) issue_ep(I0, s); });
+          tail1 = false;
+        }
+        if (!a0) break;  // chunk 0 has stopped (or the limit / an exchange failure): both chunks have completed s steps
+        ph3(I0, s, [&] { issue_x(I1, s); });
+        const bool a1 = ph1(I1, s, [&] { issue_h(g.hdec, I0, s); });
+        if (!a1) issue_h(g.hdec, I0, s);
+        ph4(I0, s, [&] { if (a1) issue_h(g.hatt, I1, s); else issue_mel(I0, s); });
+        if (a1) ph2(I1, s, [&] { issue_mel(I0, s); });
+        ph5(I0, s, [&] { if (a1) issue_ep(I1, s); });
+        if (!a1) {  // chunk 1 has stopped: chunk 0, the survivor, has completed step s
+          ++s;
+          break;
+        }
+        ph3(I1, s, [&] { issue_x(I0, s + 1); });
+        tail1 = true;
+      }
+    }
+  } else
   for (; s < s_stop; ++s) {
     // Per-iteration opaque copies of the thread indices: nothing derived from them can be hoisted
     // out of the step loop, so addresses are recomputed next to their use (one VALU op each)
@@ -894,9 +1303,9 @@ __global__ void k_pack_ctx_rows(const float4 *__restrict__ att_w, const float4 *
   out[(size_t)n * (EMB / 4) + q] = v;
 }
 
-template <int PB>
+template <int PB, bool SKEW = false>
 void launch_pb(const DecoderBufs &d, const PersistBufs &g, const PersistWeights &pw, int nsteps, hipStream_t s) {
-  COOP_CHECK(launch_coresident(true, reinterpret_cast<const void *>(k_decoder_persistent<PB>), dim3(P_NCU), dim3(PT), 0, s, d, g, pw, nsteps));
+  COOP_CHECK(launch_coresident(true, reinterpret_cast<const void *>(k_decoder_persistent<PB, SKEW>), dim3(P_NCU), dim3(PT), 0, s, d, g, pw, nsteps));
 }
 
 }  // namespace
@@ -932,6 +1341,7 @@ PersistBufs persist_bufs(unsigned long long *base, int *err, int B) {
   g.pfirst = 0;  // x 256 clocks (behind the mask hashing; 0 / 1 / 2 / 3 -> 8.44 / 8.33 / 8.71 / 8.70 us per 1-chunk step)
   g.xfirst = 4;
   g.efirst = 3;  // (with pfirst 0 and lazy 9: 8.38 / 11.39 -> 8.19 / 11.19 us per step, 1 / 2 chunks)
+  g.skew = 1;
   g.first = 4;  // x 256 clocks, ~0.4 us: the first polls of a critical consumer cannot succeed earlier (measured: -0.3 us per step)
   return g;
 }
@@ -986,7 +1396,11 @@ void launch_decoder_persistent(const DecoderBufs &d, const DeviceWeights &w, con
   pw.pre1T = w.pre1T.p;
   switch (d.B) {
     case 1: launch_pb<1>(d, g, pw, nsteps, s); break;
-    case 2: launch_pb<2>(d, g, pw, nsteps, s); break;
+    case 2:
+      // a pair that ends with its first chunk runs the skewed loop (PersistBufs::skew = 0: lock-step, the parity hooks' form)
+      if (g.skew && g.shrink) launch_pb<2, true>(d, g, pw, nsteps, s);
+      else launch_pb<2>(d, g, pw, nsteps, s);
+      break;
     default: fail(XDTTS_ERR_BAD_ARG, "persistent decoder: %d chunks (max %d)", d.B, PERSIST_B_MAX);
   }
 }

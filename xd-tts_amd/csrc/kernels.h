@@ -114,6 +114,7 @@ struct PersistBufs {
   int spins, fault;  // developer/test knobs: poll limit (0 = default) and a workgroup (index + 1) that never runs
   int slow;          // test hook: a workgroup (index + 1) that stalls ~7 us at a different point of every step (straggler:
                      // the two-slot exchange must keep every other workgroup from running more than one step ahead of it)
+  int skew;    // 2-chunk launch that ends with its first chunk: the chunks run two phases apart (decoder_persistent.hip, "skewed pair")
   int shrink;  // 2-chunk launch: end as soon as one chunk stops (the host continues with a 1-chunk launch)
   int first;  // delay before a critical consumer's first poll, x 256 clocks (developer knob)
   int efirst;  // the attention role's first poll of the partial energies (it has just published its own slice)
