@@ -628,6 +628,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
         s_cell[8 * PB + tid] = hn;
       }
       nxt();
+      PROF_MARK(5 * b + 0);
       if (b == 0) straggle(lag, s, 1);
       __builtin_amdgcn_sched_barrier(0);
       return true;
@@ -692,6 +693,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
         dacc[b][1] = a1;
       }
       nxt();
+      PROF_MARK(5 * b + 1);
       if (b == 0) straggle(lag, s, 2);
       __builtin_amdgcn_sched_barrier(0);
     };
@@ -753,6 +755,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       }
       att_bulk1(B, L4);  // for step s+1: ctx(s), h_att(s)
       nxt();
+      PROF_MARK(5 * b + 2);
       if (b == 0) straggle(lag, s, 4);
       __builtin_amdgcn_sched_barrier(0);
     };
@@ -799,6 +802,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       dec_bulk_h1(B, L4);  // for step s+1
       nxt();
       if (attn && rb == b) location(tid);
+      PROF_MARK(5 * b + 3);
       if (b == 0) straggle(lag, s, 5);
       __builtin_amdgcn_sched_barrier(0);
     };
@@ -809,6 +813,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
         nxt();
         return;
       }
+      PROF_MARK(10 + 3 * b);  // (role only: time since the previous phase's end)
       const int tid = tid_k + (int)opaque(0u), lane = tid & 63, wave = tid >> 6;
       const unsigned L4 = 4u * (unsigned)lane, TID = (unsigned)tid;
       const int p = s & 1;
@@ -821,6 +826,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
         s_mel[tid] = v[0];
       }
       __syncthreads();
+      PROF_MARK(11 + 3 * b);  // (role only: mel gathered)
       const float gate = s_mel[N_MEL];
       const bool fired = d.use_gate && gate_sigmoid(gate) > d.gate_threshold;  // mod.rs:319-324
       if (rk == 0) {
@@ -867,6 +873,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
         publish(g.x + (unsigned)(((p ^ 1) * GS + b) * PRENET + 16 * rk + tid), (want + 1u) | (more ? ACT_BIT : 0u),
                 s_mel[MEL_GL - 16 + tid]);
       nxt();
+      PROF_MARK(5 * b + 4);
     };
     bool tail1 = false;  // chunk 1 has run ph1..ph3 of step s-1: its ph4 / ph5 come in the first half of this round
     if (s_act[2] != 0 && s_act[3] != 0) {
