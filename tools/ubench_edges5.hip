@@ -8,7 +8,7 @@
 //   mel    81 values, 16 producers                            -> the same 16, which publish x(s + 1)
 // No arithmetic beyond a checksum: the time per step is the floor these five dependent exchanges impose on the step
 // (bench.py's roofline.latency_floor_us; profiles/r03_edge_floor.txt).  Every value is checked, every spin bounded.
-//   hipcc --offload-arch=gfx950 -O3 -o ubench_edges5 tools/ubench_edges5.hip && ./ubench_edges5 [steps] [T]
+//   hipcc --offload-arch=gfx950 -O3 -o ubench_edges5 tools/ubench_edges5.hip && ./ubench_edges5 [steps] [T] [tuned 0|1] [lazy] [first]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -59,7 +59,15 @@ __device__ __forceinline__ void gather(const u64 *base, int idx, int stride, int
   }
 }
 
-__global__ __launch_bounds__(NT) void k_skeleton5(Gran g, int nsteps, int T) {
+// tuned != 0: the consumers delay their first poll as the real kernel does (x 256 clocks): the ones that need a vector at once
+// by `first` units, the others by `lazy` (their polls would otherwise crowd the fabric), the energies by `clazy`
+struct Delays {
+  int tuned, lazy, first, clazy, efirst, pfirst, xfirst, xlazy;
+};
+__device__ __forceinline__ void pause(int n) {
+  for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(4);
+}
+__global__ __launch_bounds__(NT) void k_skeleton5(Gran g, int nsteps, int T, Delays dl) {
   const int c = blockIdx.x, tid = threadIdx.x;
   __shared__ float s_x[256], s_hatt[1024], s_hdec[1024], s_e[EP_LD], s_mel[96];
   const bool attn = c < NATT, pre = c >= NATT && c < NATT + NPRE;
@@ -68,6 +76,7 @@ __global__ __launch_bounds__(NT) void k_skeleton5(Gran g, int nsteps, int T) {
   for (int s = 0; s < nsteps; ++s) {
     const int p = s & 1;
     // edge 1: x(s) -> everyone (256 threads poll one granule each)
+    if (dl.tuned) pause(pre ? dl.xfirst : dl.xlazy);
     if (tid < 256) {
       float v[1];
       gather<1>(g.x, p * 256 + tid, 0, s, v, g.err);
@@ -77,6 +86,7 @@ __global__ __launch_bounds__(NT) void k_skeleton5(Gran g, int nsteps, int T) {
     __syncthreads();
     if (tid < 4) publish(g.hatt + p * 1024 + 4 * c + tid, s, expect(s, 1, 4 * c + tid) + 0.f * s_x[tid]);
     // edge 2: h_att(s) -> everyone (two granules per thread in flight together)
+    if (dl.tuned) pause(attn ? dl.first : dl.lazy);
     {
       float v[2];
       gather<2>(g.hatt, p * 1024 + tid, NT, s, v, g.err);
@@ -87,6 +97,7 @@ __global__ __launch_bounds__(NT) void k_skeleton5(Gran g, int nsteps, int T) {
     __syncthreads();
     if (attn && tid < T) publish(g.ep + (p * NATT + rk) * EP_LD + tid, s, expect(s, 2, rk * EP_LD + tid) + 0.f * s_hatt[tid]);
     // edge 3: the 8 partial-energy rows -> everyone (thread -> time step tid / 4, rows j and j + 4)
+    if (dl.tuned) pause(attn ? dl.efirst : dl.clazy);
     {
       const int t = tid >> 2, j = tid & 3;
       float v[2] = {0.f, 0.f};
@@ -99,6 +110,7 @@ __global__ __launch_bounds__(NT) void k_skeleton5(Gran g, int nsteps, int T) {
     __syncthreads();
     if (tid < 4) publish(g.hdec + p * 1024 + 4 * c + tid, s, expect(s, 3, 4 * c + tid) + 0.f * s_e[tid]);
     // edge 4: h_dec(s) -> everyone
+    if (dl.tuned) pause(pre ? dl.pfirst : dl.lazy);
     {
       float v[2];
       gather<2>(g.hdec, p * 1024 + tid, NT, s, v, g.err);
@@ -130,6 +142,9 @@ __global__ void k_seed(Gran g) {  // x(0)
 
 int main(int argc, char **argv) {
   const int nsteps = argc > 1 ? atoi(argv[1]) : 633, T = argc > 2 ? atoi(argv[2]) : 100;
+  Delays dl{argc > 3 ? atoi(argv[3]) : 0, 9, 4, 4, 3, 0, 4, 0};  // (the kernel's defaults, csrc/decoder_persistent.hip: persist_bufs)
+  if (argc > 4) dl.lazy = atoi(argv[4]);
+  if (argc > 5) dl.first = atoi(argv[5]);
   hipDeviceProp_t prop;
   CK(hipGetDeviceProperties(&prop, 0));
   int per_cu = 0;
@@ -163,7 +178,7 @@ int main(int argc, char **argv) {
     hipLaunchKernelGGL(k_seed, dim3(1), dim3(256), 0, 0, g);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL(k_skeleton5, dim3(NCU), dim3(NT), 0, 0, g, nsteps, T);
+    hipLaunchKernelGGL(k_skeleton5, dim3(NCU), dim3(NT), 0, 0, g, nsteps, T, dl);
     CK(hipEventRecord(e1));
     CK(hipDeviceSynchronize());
     float ms = 0;
@@ -174,6 +189,6 @@ int main(int argc, char **argv) {
     printf("rep %d: %d steps (T = %d), %.3f ms, %.3f us per step (5 edges: %.3f us per edge), err=%d\n", rep, nsteps, T, ms, us, us / 5, herr);
     if (rep > 0 && !herr && us < best) best = us;
   }
-  printf("FLOOR_US_PER_STEP %.3f\n", best);
+  printf("FLOOR_US_PER_STEP %.3f (%s poll delays)\n", best, dl.tuned ? "tuned" : "no");
   return 0;
 }
