@@ -229,6 +229,30 @@ def test_lost_workgroup_drains_and_falls_back(pkg, orc, blob, capfd):
     m.close()
 
 
+def test_lost_workgroup_in_a_pair_drains_and_falls_back(pkg, orc, blob, capfd):
+    """The same for a PAIR of chunks (the skewed loop: every phase's gather is a bounded spin that watches the error word,
+    and a phase whose vector never comes ends the launch for both chunks): with a workgroup missing the request is decoded
+    again on the launch-per-stage engine, both chunks within 1e-5 of the oracle, one message on stderr, no hang."""
+    lens, steps = [31, 18], np.asarray([34, 22], dtype=np.int32)
+    ids = [synth_ids(n, seed=61 + i) for i, n in enumerate(lens)]
+    os.environ["XDTTS_PERSIST_FAULT"] = "77"   # workgroup 76 returns at once
+    os.environ["XDTTS_PERSIST_SPINS"] = "20000"
+    try:
+        m = pkg.Tacotron2.from_blob(blob)
+        out = m.infer_batch(ids, opts=pkg.default_opts(dropout_seed=23), fixed_steps=steps)
+        assert "persistent decoder exchange timed out" in capfd.readouterr().err
+    finally:
+        del os.environ["XDTTS_PERSIST_FAULT"], os.environ["XDTTS_PERSIST_SPINS"]
+    assert m.engine_state()["decoder_persistent"] == 0
+    m.close()
+    for b in range(2):
+        padded = np.zeros(100, dtype=np.int64)
+        padded[: lens[b]] = ids[b]
+        mem, pm = orc.encoder(blob, padded)
+        rframes, _ = orc.run_decoder(blob, mem, pm, lens[b], orc.default_opts(fixed_steps=int(steps[b]), dropout_seed=23, item=b))
+        assert out[b].shape == (80, steps[b]) and rms(out[b], orc.postnet(blob, rframes)) <= 1e-5
+
+
 def test_teacher_forced_single_step_all_nine_outputs(pkg, model, orc, blob):
     """ONE decoder_iter call (mod.rs:304) from an identical state -- the oracle's own, taken
     at several points of a free-running sequence -- must reproduce all nine outputs (mod.rs:306-307,
