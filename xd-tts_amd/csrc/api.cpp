@@ -662,6 +662,7 @@ struct xdtts_tacotron2 {
           // without the gate the host knows which chunk outlives the other: no round trip in between
           const int first = std::min(lim[b0], lim[b0 + 1]), r = lim[b0] > lim[b0 + 1] ? 0 : 1;
           g.shrink = 0;
+          g.both_run = 1;  // (neither chunk stops inside these `first` steps: the skewed loop may run them)
           launch_decoder_persistent(v, w, g, first, stream);
           launch_decoder_persistent(view(b0 + r, 1), w, persist_view(g, r), lim[b0 + r] - first, stream);
         } else {

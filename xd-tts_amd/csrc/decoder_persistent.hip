@@ -1349,6 +1349,7 @@ PersistBufs persist_bufs(unsigned long long *base, int *err, int B) {
   g.xfirst = 4;
   g.efirst = 3;  // (with pfirst 0 and lazy 9: 8.38 / 11.39 -> 8.19 / 11.19 us per step, 1 / 2 chunks)
   g.skew = 1;
+  g.both_run = 0;
   g.first = 4;  // x 256 clocks, ~0.4 us: the first polls of a critical consumer cannot succeed earlier (measured: -0.3 us per step)
   return g;
 }
@@ -1404,8 +1405,9 @@ void launch_decoder_persistent(const DecoderBufs &d, const DeviceWeights &w, con
   switch (d.B) {
     case 1: launch_pb<1>(d, g, pw, nsteps, s); break;
     case 2:
-      // a pair that ends with its first chunk runs the skewed loop (PersistBufs::skew = 0: lock-step, the parity hooks' form)
-      if (g.skew && g.shrink) launch_pb<2, true>(d, g, pw, nsteps, s);
+      // a pair that ends with its first chunk -- or whose chunks both run every step of the launch -- runs the skewed loop
+      // (PersistBufs::skew = 0: lock-step, the parity hooks' form)
+      if (g.skew && (g.shrink || g.both_run)) launch_pb<2, true>(d, g, pw, nsteps, s);
       else launch_pb<2>(d, g, pw, nsteps, s);
       break;
     default: fail(XDTTS_ERR_BAD_ARG, "persistent decoder: %d chunks (max %d)", d.B, PERSIST_B_MAX);

@@ -115,6 +115,7 @@ struct PersistBufs {
   int slow;          // test hook: a workgroup (index + 1) that stalls ~7 us at a different point of every step (straggler:
                      // the two-slot exchange must keep every other workgroup from running more than one step ahead of it)
   int skew;    // 2-chunk launch that ends with its first chunk: the chunks run two phases apart (decoder_persistent.hip, "skewed pair")
+  int both_run;  // 2-chunk launch without `shrink` whose chunks are both known to run all of its steps (gate-less decode)
   int shrink;  // 2-chunk launch: end as soon as one chunk stops (the host continues with a 1-chunk launch)
   int first;  // delay before a critical consumer's first poll, x 256 clocks (developer knob)
   int efirst;  // the attention role's first poll of the partial energies (it has just published its own slice)
