@@ -8,7 +8,7 @@ python - <<'PY'
 import sqlite3, glob
 db = sqlite3.connect(glob.glob("/tmp/prof_h/**/*.db", recursive=True)[0])
 tabs = [r[0] for r in db.execute("select name from sqlite_master where type in ('table','view')")]
-ev = [(s, e, n.split("(")[0].split("::")[-1][:44]) for n, s, e in db.execute("select name, start, end from kernels")]
+ev = [(s, e, (n.split("(anonymous namespace)::")[-1] if "(anonymous namespace)::" in n else n).split("(")[0][:44]) for n, s, e in db.execute("select name, start, end from kernels")]
 if "memory_copies" in tabs:
     ev += [(s, e, "copy " + str(n)) for n, s, e in db.execute("select name, start, end from memory_copies")]
 ev.sort()
