@@ -226,7 +226,12 @@ xdtts_status xdtts_griffinlim_new(const float *mel_basis, size_t n_mels, size_t 
  *                   1/lambda_max(basis basis^T); the iteration's limit is the NNLS solution)
  *   power_mode      0: S = x^(1/power) (librosa mel_to_stft)   1: S = x^power   2: S = x
  *   mel_decompress  0: m = exp(mel) (Tacotron2's ln compression)   1: m = mel   2: m = 10^mel
- *   peak_normalise  0: audio as is (src/lib.rs:155 scales by i16::MAX directly)   1: audio / max|audio|
+ *   output_normalise  (G6: the last step of GriffinLim::infer before src/lib.rs:155 scales by i16::MAX)
+ *                   0: audio as is   1: audio / max|audio|   2: audio * rms_target / rms(audio)   [default 2]
+ *   rms_target      0.1 = -20 dBFS.  Why 2 / 0.1: the only outputs of this path the reference holds --
+ *                   slides/audio/goodbye.wav and capital_nonsense.wav, both exactly WAV_SPEC (src/lib.rs:25-30) -- sit
+ *                   at RMS 0.099994 and 0.099995 of full scale with peaks 0.82 and 0.61: an RMS-0.1 signal after the
+ *                   truncating `as i16` cast (tests/golden/reference_audio_facts.json, tools/reference_audio_facts.py)
  * and one switch of xdtts_griffinlim_infer_batch only:
  *   batch_shape     0: a workgroup owns up to 4 or up to 8 frames of an utterance, whichever shape needs less time
  *                   for the batch at hand (the overlap-add then sums in a different order than the single call:
@@ -237,8 +242,9 @@ typedef struct {
   int32_t nnls_iters;
   int32_t power_mode;
   int32_t mel_decompress;
-  int32_t peak_normalise;
+  int32_t output_normalise;
   int32_t batch_shape;
+  float rms_target;
 } xdtts_griffinlim_opts;
 void xdtts_griffinlim_opts_default(xdtts_griffinlim_opts *opts);
 xdtts_status xdtts_griffinlim_set_opts(xdtts_griffinlim *g, const xdtts_griffinlim_opts *opts);
@@ -261,7 +267,8 @@ xdtts_status xdtts_griffinlim_infer_batch(xdtts_griffinlim *g, const float *cons
                                           const size_t *n_frames, int32_t n_utt, float **audios,
                                           size_t *n_samples);
 
-/* Same, skipping the mel->linear inversion: S is n_bins x F linear magnitude; phase0 is
+/* The loop alone (G2..G5 and the final ISTFT): no mel->linear inversion before it and no output normalisation
+ * after it -- the bench / parity entry of SURVEY.md section 8(b).  S is n_bins x F linear magnitude; phase0 is
  * n_bins x F x 2 (cos, sin) or NULL for the seeded stream; iters = 0 uses the handle's count. */
 xdtts_status xdtts_griffinlim_infer_linear(xdtts_griffinlim *g, const float *S,
                                            const float *phase0, size_t n_frames, size_t iters,

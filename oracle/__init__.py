@@ -88,6 +88,8 @@ class Oracle:
         L.orc_mel_filter_bank.argtypes = [C.c_double, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p]
         L.orc_mel_to_linear.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, self.ct, C.c_void_p]
         L.orc_griffinlim.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, self.ct, C.c_void_p]
+        L.orc_output_normalise.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_double]
+        L.orc_output_normalise.restype = None
         L.orc_nnls_lipschitz.restype = C.c_double
         L.orc_nnls_lipschitz.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.orc_mel_to_linear_opts.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, self.ct, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -248,6 +250,12 @@ class Oracle:
         r = np.array(rebuilt, dtype=self.dtype, order="C")
         self.lib.orc_griffinlim_step(self._p(S), self._p(a), self._p(r), S.shape[1], n_fft, hop, iters, momentum)
         return a, r
+
+    def output_normalise(self, audio, mode=2, target=0.1):
+        """G6: what GriffinLim::infer does to the final ISTFT's samples (0 none / 1 peak / 2 rms); returns a copy."""
+        y = np.array(audio, dtype=self.dtype, order="C")
+        self.lib.orc_output_normalise(self._p(y), y.size, mode, target)
+        return y
 
     def griffinlim(self, S, phase0=None, seed=0, n_fft=1024, hop=256, iters=30, momentum=0.99):
         S = self._arr(S)

@@ -911,3 +911,27 @@ void orc_griffinlim(const real *S, const real *phase0, uint32_t seed, int F, int
   free(reb);
   free(est);
 }
+
+/* G6 -- the last step of GriffinLim::infer (src/lib.rs:141) before src/lib.rs:155 scales by i16::MAX.
+ * The crate is absent (Cargo.lock:666-668); the reference's own WAV_SPEC files (slides/audio/goodbye.wav,
+ * capital_nonsense.wav: RMS 0.099994 / 0.099995 of full scale, peaks 0.82 / 0.61) say "RMS = 0.1".
+ * mode 0: as is; 1: y / max|y|; 2: y * target / sqrt(mean(y^2)).  Sums in double in both builds. */
+void orc_output_normalise(real *y, size_t n, int mode, double target) {
+  if (mode == 1) {
+    real peak = 0;
+    for (size_t i = 0; i < n; ++i) {
+      real a = y[i] < 0 ? -y[i] : y[i];
+      if (a > peak) peak = a;
+    }
+    if (peak > 0)
+      for (size_t i = 0; i < n; ++i) y[i] = y[i] / peak;
+  } else if (mode == 2 && n > 0) {
+    double ss = 0;
+    for (size_t i = 0; i < n; ++i) ss += (double)y[i] * (double)y[i];
+    double r = sqrt(ss / (double)n);
+    if (r > 0) {
+      real sc = (real)(target / r);
+      for (size_t i = 0; i < n; ++i) y[i] = y[i] * sc;
+    }
+  }
+}

@@ -142,6 +142,9 @@ void orc_istft(const real *spec /* bins x F x 2 */, int F, int n_fft, int hop,
 void orc_griffinlim(const real *S, const real *phase0, uint32_t seed, int F, int n_fft, int hop,
                     int iters, real momentum, real *audio);
 
+/* G6 output normalisation: mode 0 none, 1 peak, 2 rms(target) -- see the definition for the evidence. */
+void orc_output_normalise(real *y, size_t n, int mode, double target);
+
 /* `iters` iterations of the loop inside orc_griffinlim on a caller-held state (teacher-forced
  * parity hook): ang and reb are [bins][F][2], updated in place; no final ISTFT. */
 void orc_griffinlim_step(const real *S, real *ang, real *reb, int F, int n_fft, int hop, int iters,

@@ -44,9 +44,13 @@ def test_full_infer_from_mel(pkg, voc, orc):
     voc.set_seed(5)
     audio = voc.infer(mel)
     S = orc.mel_to_linear(orc.pinv(orc.mel_filter_bank()), mel, power=1.7)
-    ref = orc.griffinlim(S, seed=5, iters=30)
+    raw = orc.griffinlim(S, seed=5, iters=30)
+    ref = orc.output_normalise(raw, mode=2, target=0.1)  # G6: the handle's default (rms 0.1)
+    d = voc.get_opts()
+    assert d.output_normalise == 2 and d.rms_target == np.float32(0.1)
     assert audio.shape == ref.shape == (256 * (F - 1),)
-    assert rms(audio, ref) <= 1e-4
+    assert rms(audio, ref) <= 1e-4 * 0.1 / float(np.sqrt(np.mean(raw.astype(np.float64) ** 2))) and rms(audio, ref) <= 1e-4
+    assert abs(float(np.sqrt(np.mean(audio.astype(np.float64) ** 2))) - 0.1) <= 1e-6
     t = voc.last_timings()
     assert t["total_ms"] > 0 and t["iterations_ms"] > 0
 
@@ -129,12 +133,12 @@ def test_mel_to_linear_options_match_the_oracle(pkg, orc):
     F = 70
     mel = (rng.uniform(-7.0, -1.0, size=(80, F)) + 1.5 * np.sin(np.arange(F) / 4.0)[None, :]).astype(np.float32)
     d = v.get_opts()
-    assert (d.nnls_iters, d.power_mode, d.mel_decompress, d.peak_normalise) == (0, 0, 0, 0)
+    assert (d.nnls_iters, d.power_mode, d.mel_decompress, d.output_normalise) == (0, 0, 0, 2)
     base = v.mel_to_linear(mel)
     scale = float(np.sqrt(np.mean(base.astype(np.float64) ** 2)))
     for kw in (dict(), dict(power_mode=1), dict(power_mode=2), dict(mel_decompress=1), dict(mel_decompress=2),
                dict(nnls_iters=1), dict(nnls_iters=7, power_mode=2), dict(nnls_iters=60)):
-        full = dict(nnls_iters=0, power_mode=0, mel_decompress=0, peak_normalise=0)
+        full = dict(nnls_iters=0, power_mode=0, mel_decompress=0, output_normalise=0)
         full.update(kw)
         v.set_opts(**full)
         S = v.mel_to_linear(mel)
@@ -150,13 +154,14 @@ def test_mel_to_linear_options_match_the_oracle(pkg, orc):
     r0, r1 = np.linalg.norm(A.astype(np.float64) @ x0 - m), np.linalg.norm(A.astype(np.float64) @ x1 - m)
     assert r1 < 0.8 * r0 and x1.min() >= 0
     # defaults restored -> the documented reading again; peak normalisation scales the same audio to |y| <= 1
-    v.set_opts(nnls_iters=0, power_mode=0, mel_decompress=0, peak_normalise=0)
+    v.set_opts(nnls_iters=0, power_mode=0, mel_decompress=0, output_normalise=0)
     assert np.array_equal(v.mel_to_linear(mel), base) and scale > 0
     a0 = v.infer(mel)
-    v.set_opts(peak_normalise=1)
+    v.set_opts(output_normalise=1)
     a1 = v.infer(mel)
     peak = float(np.abs(a0).max())
     assert abs(float(np.abs(a1).max()) - 1.0) <= 1e-6 and rms(a1, a0 / peak) <= 1e-6
+    assert rms(a1, orc.output_normalise(a0, mode=1)) <= 1e-7
     with pytest.raises(pkg.XdttsError) as e:
         v.set_opts(power_mode=7)
     assert e.value.status == pkg.XDTTS_ERR_BAD_ARG
@@ -195,7 +200,7 @@ def test_vocoder_batch_equals_one_by_one(pkg):
     assert all(np.array_equal(a, b) for a, b in zip(v.infer_batch(many), auto))
     v.set_opts(batch_shape=4)
     # options apply per utterance in a batch too
-    v.set_opts(peak_normalise=1, nnls_iters=3)
+    v.set_opts(output_normalise=1, nnls_iters=3)
     single = [v.infer(m) for m in mels[:4]]
     for a, b in zip(v.infer_batch(mels[:4]), single):
         assert np.array_equal(a, b) and abs(float(np.abs(a).max()) - 1.0) <= 1e-6

@@ -40,7 +40,7 @@ class XdttsError(RuntimeError):
 class GriffinLimOpts(C.Structure):
     """xdtts_griffinlim_opts: the conventions of GriffinLim::infer's mel->linear step as switches."""
 
-    _fields_ = [("nnls_iters", C.c_int32), ("power_mode", C.c_int32), ("mel_decompress", C.c_int32), ("peak_normalise", C.c_int32), ("batch_shape", C.c_int32)]
+    _fields_ = [("nnls_iters", C.c_int32), ("power_mode", C.c_int32), ("mel_decompress", C.c_int32), ("output_normalise", C.c_int32), ("batch_shape", C.c_int32), ("rms_target", C.c_float)]
 
 
 class InferOpts(C.Structure):
@@ -497,7 +497,7 @@ class GriffinLim:
 
     def set_opts(self, **kw):
         """nnls_iters, power_mode (0 inverse / 1 direct / 2 none), mel_decompress (0 exp / 1 none / 2 10^x),
-        peak_normalise, batch_shape (0 auto / 4 the single-utterance shape: bit-identical batches); unspecified
+        output_normalise (0 none / 1 peak / 2 rms), rms_target, batch_shape (0 auto / 4 the single-utterance shape: bit-identical batches); unspecified
         fields keep their current value."""
         o = self.get_opts()
         for k, v in kw.items():

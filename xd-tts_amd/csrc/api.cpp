@@ -998,9 +998,10 @@ struct xdtts_griffinlim {
   float last_ms[3] = {0, 0, 0};
   DevBuf<float> pinv, win, S, melT, mel_in, frames, wss_inv, audio, phase0;
   // mel->linear options (xdtts_griffinlim_opts) and the NNLS refinement's operands
-  xdtts_griffinlim_opts gopts{0, 0, 0, 0};
+  xdtts_griffinlim_opts gopts{0, 0, 0, 2, 0, 0.1f};
   static constexpr int NBP = 528;  // bins padded to the GEMM's K granule
-  DevBuf<float> basis_p, basisT_p, nnls_x, nnls_r, peak;
+  DevBuf<float> basis_p, basisT_p, nnls_x, nnls_r, norm_parts;  // norm_parts: GLN_PARTS per utterance
+  DevBuf<int2> norm_tab;  // (first sample, samples) per utterance of a vocoder batch
   float nnls_step = 0.f;   // 1 / lambda_max(A A^T)
   hipGraphExec_t graph = nullptr;  // n_iter x (istft, stft) + final ISTFT for the cached (buffers, F, iterations)
   GlBufs graph_key{};
@@ -1894,7 +1895,7 @@ xdtts_status xdtts_griffinlim_new(const float *mel_basis, size_t n_mels, size_t 
       g->basis_p.upload(bp.data(), bp.size(), g->stream);
       g->basisT_p.upload(bt.data(), bt.size(), g->stream);
       g->nnls_step = (float)(1.0 / host_lipschitz(mel_basis, nm, nbi));
-      g->peak.alloc(1);
+      g->norm_parts.alloc(GLN_PARTS);
     }
     std::vector<float2> tw(n_fft);
     std::vector<float> win(n_fft);
@@ -1915,15 +1916,16 @@ void xdtts_griffinlim_opts_default(xdtts_griffinlim_opts *o) {
   o->nnls_iters = 0;
   o->power_mode = 0;
   o->mel_decompress = 0;
-  o->peak_normalise = 0;
+  o->output_normalise = 2;  // rms: the level of the reference's own WAV_SPEC files
   o->batch_shape = 0;
+  o->rms_target = 0.1f;
 }
 
 xdtts_status xdtts_griffinlim_set_opts(xdtts_griffinlim *g, const xdtts_griffinlim_opts *o) {
   return guard([&] {
     if (!g || !o) fail(XDTTS_ERR_BAD_ARG, "null argument");
     if (o->nnls_iters < 0 || o->nnls_iters > 100000 || o->power_mode < 0 || o->power_mode > 2 || o->mel_decompress < 0 ||
-        o->mel_decompress > 2 || o->peak_normalise < 0 || o->peak_normalise > 1 || (o->batch_shape != 0 && o->batch_shape != 4))
+        o->mel_decompress > 2 || o->output_normalise < 0 || o->output_normalise > 2 || !(o->rms_target > 0.f) || !(o->rms_target <= 1e6f) || (o->batch_shape != 0 && o->batch_shape != 4))
       fail(XDTTS_ERR_BAD_ARG, "griffin-lim option out of range");
     std::lock_guard<std::mutex> lk(g->mu);
     g->gopts = *o;
@@ -1951,13 +1953,13 @@ xdtts_status xdtts_griffinlim_set_seed(xdtts_griffinlim *g, uint32_t seed) {
 // stream has drained; a timed-out exchange demotes the handle and the request runs again on the
 // launch-per-iteration engine (S and the phase seed are intact).
 static void gl_iterate_and_fetch(xdtts_griffinlim *g, const GlBufs &b, const float *phase0_dev, int iters, float **audio,
-                                 size_t *n_samples) {
+                                 size_t *n_samples, bool normalise) {
   const size_t N = (size_t)g->hop * (size_t)(b.F - 1);
   std::lock_guard<std::recursive_mutex> chip(chip_mutex(g->device));
   g->probe_tick();
   for (int attempt = 0; attempt < 2; ++attempt) {
     g->iterate(b, phase0_dev, iters);
-    if (g->gopts.peak_normalise) launch_gl_peak_normalise(g->audio.p, (int)N, g->peak.p, g->stream);
+    if (normalise) launch_gl_output_normalise(g->audio.p, nullptr, 1, 0, (int)N, g->gopts.output_normalise, g->gopts.rms_target, g->norm_parts.p, g->stream);
     HIP_CHECK(hipEventRecord(g->ev.e[2], g->stream));
     PinnedGuard host(N);
     HIP_CHECK(hipMemcpyAsync(host.p, g->audio.p, N * sizeof(float), hipMemcpyDeviceToHost, g->stream));
@@ -1979,7 +1981,7 @@ static void gl_run_from_device_mel(xdtts_griffinlim *g, const float *mel_dev_ptr
   HIP_CHECK(hipEventRecord(g->ev.e[0], g->stream));
   g->mel_to_linear(mel_dev_ptr, F);
   HIP_CHECK(hipEventRecord(g->ev.e[1], g->stream));
-  gl_iterate_and_fetch(g, b, nullptr, g->iters, audio, n_samples);
+  gl_iterate_and_fetch(g, b, nullptr, g->iters, audio, n_samples, true);  // GriffinLim::infer: G1..G6
 }
 
 xdtts_status xdtts_griffinlim_infer(xdtts_griffinlim *g, const float *mel, size_t n_mels, size_t n_frames,
@@ -2108,10 +2110,34 @@ static void gl_batch_from_device(xdtts_griffinlim *g, const float *mel_dev_all, 
           if (s) (void)hipStreamSynchronize(s);
         }
       } drain{g->copy_stream};
-      // (peak normalisation rewrites the audio after the launches: then the copies follow everything)
-      const bool early = !g->gopts.peak_normalise;
+      // Output normalisation (G6): the utterances of one fetch are consecutive rows of `tab` (launch by launch, then the
+      // ones that run alone), so each fetch is preceded by ONE two-launch normalisation of exactly its utterances.
+      const int norm_mode = g->gopts.output_normalise;
+      std::vector<int> tab_pos((size_t)n_utt, 0);
+      if (norm_mode) {
+        std::vector<int2> tab;
+        tab.reserve((size_t)n_utt);
+        auto add = [&](int u) {
+          tab_pos[(size_t)u] = (int)tab.size();
+          tab.push_back(make_int2(abase[u], g->hop * (Fu[u] - 1)));
+        };
+        for (const Launch &L : launches)
+          for (int u : L.utts) add(u);
+        for (int u = 0; u < n_utt; ++u)
+          if (!batched[u]) add(u);
+        g->norm_tab.upload(tab.data(), tab.size(), st);
+        g->norm_parts.alloc((size_t)GLN_PARTS * (size_t)n_utt);
+        HIP_CHECK(hipStreamSynchronize(st));
+      }
       size_t n_ev = 0;
       auto fetch_audio = [&](const std::vector<int> &utts) {  // after the work just enqueued on `st`
+        if (norm_mode && !utts.empty()) {
+          int n_max = 0;
+          for (int u : utts) n_max = std::max(n_max, g->hop * (Fu[u] - 1));
+          const int r0 = tab_pos[(size_t)utts[0]];
+          launch_gl_output_normalise(g->audio.p, g->norm_tab.p + r0, (int)utts.size(), 0, n_max, norm_mode, g->gopts.rms_target,
+                                     g->norm_parts.p + (size_t)r0 * GLN_PARTS, st);
+        }
         hipEvent_t e = g->launch_done(n_ev++);
         HIP_CHECK(hipEventRecord(e, st));
         HIP_CHECK(hipStreamWaitEvent(g->copy_stream, e, 0));
@@ -2146,7 +2172,7 @@ static void gl_batch_from_device(xdtts_griffinlim *g, const float *mel_dev_all, 
           p.per_cu = WG;
           g->epoch += (unsigned)g->iters + 2u;
           launch_gl_persistent(all, p, all.ang, all.tprev, g->iters, alpha, g->audio.p, st);
-          if (early) fetch_audio(L.utts);
+          fetch_audio(L.utts);
         }
         used_persistent = true;
       }
@@ -2163,15 +2189,7 @@ static void gl_batch_from_device(xdtts_griffinlim *g, const float *mel_dev_all, 
         launch_gl_prepare(v, st);
         g->run_iterations(v, g->iters, alpha, g->audio.p + abase[u]);  // the engine the single-utterance call uses
         used_persistent = used_persistent || g->last_persistent;
-        if (early) fetch_audio(std::vector<int>(1, u));
-      }
-      if (!early) {
-        std::vector<int> every((size_t)n_utt);
-        for (int u = 0; u < n_utt; ++u) {
-          launch_gl_peak_normalise(g->audio.p + abase[u], g->hop * (Fu[u] - 1), g->peak.p, st);
-          every[(size_t)u] = u;
-        }
-        fetch_audio(every);
+        fetch_audio(std::vector<int>(1, u));
       }
       HIP_CHECK(hipEventRecord(g->ev.e[2], st));
       g->finish_timings();
@@ -2265,7 +2283,7 @@ xdtts_status xdtts_griffinlim_infer_linear(xdtts_griffinlim *g, const float *S, 
     HIP_CHECK(hipStreamSynchronize(g->stream));
     HIP_CHECK(hipEventRecord(g->ev.e[0], g->stream));
     HIP_CHECK(hipEventRecord(g->ev.e[1], g->stream));
-    gl_iterate_and_fetch(g, b, p0, iters ? (int)iters : g->iters, audio, n_samples);
+    gl_iterate_and_fetch(g, b, p0, iters ? (int)iters : g->iters, audio, n_samples, false);  // G2..G5 + final ISTFT only
   });
 }
 

@@ -944,18 +944,47 @@ __global__ void k_pow_rows(const float *in, int ld, float *out, int nb, int F, f
   out[i] = p == 1.0f ? v : powf(fmaxf(v, 0.f), p);
 }
 
-// peak normalisation: max |y| through an atomic max on the float's bit pattern (non-negative floats
-// order like unsigned integers), then a scale pass
-__global__ void k_absmax(const float *y, int n, unsigned *out) {
-  float m = 0.f;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) m = fmaxf(m, fabsf(y[i]));
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  if ((threadIdx.x & 63) == 0 && m == m) atomicMax(out, __float_as_uint(m));
+// Output normalisation (G6; xdtts_griffinlim_opts.output_normalise): 1 = y / max|y|, 2 = y * target / rms(y).
+// Two launches per group of utterances, no atomics: GLN_PARTS blocks per utterance each reduce a fixed strided share
+// (lane-strided accumulation, xor-shuffle tree, the four waves summed in order), then every scaling block re-reduces the
+// utterance's GLN_PARTS partials in one fixed order -- the result does not depend on scheduling.
+__global__ void __launch_bounds__(256) k_norm_partials(const float *y, const int2 *tab, int2 single, int mode, float *parts) {
+  const int2 t = tab ? tab[blockIdx.y] : single;  // (first sample, samples)
+  const float *p = y + t.x;
+  float acc = 0.f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < t.y; i += GLN_PARTS * 256) {
+    const float v = p[i];
+    acc = mode == 1 ? fmaxf(acc, fabsf(v)) : fmaf(v, v, acc);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const float b = __shfl_xor(acc, o, 64);
+    acc = mode == 1 ? fmaxf(acc, b) : acc + b;
+  }
+  __shared__ float w[4];
+  if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    parts[blockIdx.y * GLN_PARTS + blockIdx.x] = mode == 1 ? fmaxf(fmaxf(w[0], w[1]), fmaxf(w[2], w[3])) : ((w[0] + w[1]) + (w[2] + w[3]));
 }
-__global__ void k_scale_by_peak(float *y, int n, const unsigned *peak) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const float p = __uint_as_float(*peak);
-  if (i < n && p > 0.f) y[i] = y[i] / p;
+__global__ void __launch_bounds__(256) k_norm_scale(float *y, const int2 *tab, int2 single, int mode, float target, const float *parts) {
+  const int2 t = tab ? tab[blockIdx.y] : single;
+  if (blockIdx.x * 1024 >= t.y) return;
+  static_assert(GLN_PARTS == 64, "one lane per partial");
+  float acc = parts[blockIdx.y * GLN_PARTS + (threadIdx.x & 63)];
+  for (int o = 32; o > 0; o >>= 1) {
+    const float b = __shfl_xor(acc, o, 64);
+    acc = mode == 1 ? fmaxf(acc, b) : acc + b;
+  }
+  float *p = y + t.x;
+  if (mode == 1) {
+    if (!(acc > 0.f)) return;
+    for (int i = blockIdx.x * 1024 + threadIdx.x; i < min(t.y, (int)(blockIdx.x + 1) * 1024); i += 256) p[i] = p[i] / acc;
+  } else {
+    const float r = sqrtf(acc / (float)t.y);
+    if (!(r > 0.f)) return;
+    const float sc = target / r;
+    for (int i = blockIdx.x * 1024 + threadIdx.x; i < min(t.y, (int)(blockIdx.x + 1) * 1024); i += 256) p[i] = p[i] * sc;
+  }
 }
 
 // Parity hook (xdtts_griffinlim_step): the iteration state crosses the boundary in the crate's
@@ -994,10 +1023,12 @@ void launch_gl_pow_rows(const float *in, int ld, float *out, int nb, int F, floa
   HIP_CHECK(hipGetLastError());
 }
 
-void launch_gl_peak_normalise(float *y, int n, float *scratch, hipStream_t s) {
-  HIP_CHECK(hipMemsetAsync(scratch, 0, sizeof(float), s));
-  hipLaunchKernelGGL(k_absmax, dim3(std::min(256, (n + 255) / 256)), dim3(256), 0, s, y, n, reinterpret_cast<unsigned *>(scratch));
-  hipLaunchKernelGGL(k_scale_by_peak, dim3((n + 255) / 256), dim3(256), 0, s, y, n, reinterpret_cast<const unsigned *>(scratch));
+void launch_gl_output_normalise(float *y, const int2 *tab_dev, int n_utt, int first, int n_max, int mode, float target,
+                                float *parts, hipStream_t s) {
+  if (mode == 0 || n_utt <= 0 || n_max <= 0) return;
+  const int2 single = make_int2(first, n_max);
+  hipLaunchKernelGGL(k_norm_partials, dim3(GLN_PARTS, n_utt), dim3(256), 0, s, y, tab_dev, single, mode, parts);
+  hipLaunchKernelGGL(k_norm_scale, dim3((n_max + 1023) / 1024, n_utt), dim3(256), 0, s, y, tab_dev, single, mode, target, parts);
   HIP_CHECK(hipGetLastError());
 }
 
