@@ -38,6 +38,7 @@ SAMPLE_RATE = 22050.0
 GL_ITERS = 60                 # BASELINE.json configs[1]
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_F32_PEAK_TF = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak
+VALU_F32_PEAK_TF = 157.3      # MI355X_MICROARCH.md: fp32 vector (packed FMA) peak -- the persistent decoder computes on the VALU
 POSTNET_FLOP_PER_FRAME = 8683520.0  # 5 x conv1d k5 (80->512->512->512->512->80), 2 flops per MAC
 
 # Algorithmic work of one decoder step: the fp32 decoder_iter parameters are
@@ -69,17 +70,17 @@ def pmc_traffic():
     return d.get("decoder_launch_traffic_bytes"), {"file": os.path.relpath(files[-1], ROOT), "profiled_at": d.get("git_head", "round 1")}
 
 
-def edge_floor():
-    """The latency floor of the persistent decoder's step: tools/ubench_edges5.hip runs the step's five dependent
-    all-gather exchanges with no arithmetic in between (same grid, same granule transport); its time per step, measured on
-    the MI355X and committed under profiles/, is what the kernel's step time is a fraction of."""
-    import glob
-
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_edge_floor.json")))
-    if not files:
-        return None, None
-    d = json.load(open(files[-1]))
-    return d.get("floor_us_per_step"), {"file": os.path.relpath(files[-1], ROOT), "tool": "tools/ubench_edges5.hip", "measured_at": d.get("git_head")}
+def edge_floor(pkg, device):
+    """The latency floor of the persistent decoder's step, measured NOW on the benched device: the step's five dependent
+    all-gather exchanges with no arithmetic in between (same grid, same granule transport, the consumers' first-poll
+    delays as in the engine; csrc/edge_floor.hip through xdtts_edge_floor_us, best of five launches of 2000 steps, after
+    the timed region).  The step time is a fraction of this, not of an HBM figure: nothing streams."""
+    try:
+        us = pkg.edge_floor_us(device, 2000, T_ENC, True)
+        return us, {"measured": "live on the benched device in this run (xdtts_edge_floor_us: 2000 steps, T = %d, best of 5)" % T_ENC,
+                    "kernel": "xd-tts_amd/csrc/edge_floor.hip", "without_poll_delays_us": pkg.edge_floor_us(device, 2000, T_ENC, False)}
+    except Exception as e:  # noqa: BLE001
+        return None, {"error": repr(e)}
 
 
 def cpu_baseline():
@@ -132,6 +133,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline only (profiling runs)")
+    ap.add_argument("--check-shared-utterance", action="store_true",
+                    help="every rank also synthesizes utterance 0 (outside the timed region) and the line carries the sha256 of "
+                         "its mel and audio per rank: identical bits on every rank and in a single-process run")
+    ap.add_argument("--load-from-dir", default=None, metavar="DIR",
+                    help="every rank loads through Tacotron2::load(DIR) (mod.rs:242) -- the path a deployment uses -- from a "
+                         "tacotron2.xdtw that rank 0 writes there first (synthetic weights); default: each rank generates them")
     args = ap.parse_args()
 
     import torch   # before the product library: see tests/conftest.py on the load order of the HIP runtime
@@ -145,6 +152,11 @@ def main():
     dev_override = os.environ.get("XDTTS_BENCH_DEVICE")
     if dev_override is not None:
         local_rank = int(dev_override)
+        # several ranks on ONE GPU: their co-resident launches (persistent decoder, cooperative encoder, persistent
+        # Griffin-Lim) must take turns across processes too -- the library's flock next to its per-process lock
+        import tempfile
+
+        os.environ.setdefault("XDTTS_CHIP_LOCK_DIR", tempfile.gettempdir())
     backend = os.environ.get("XDTTS_BENCH_BACKEND", "nccl")
     red_dev = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
@@ -165,7 +177,17 @@ def main():
     if pkg.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: libxdtts_hip has no CPU path")
 
-    model = pkg.Tacotron2.synthetic(seed=wl.WEIGHT_SEED, rec_scale=1.0, device_id=local_rank)
+    if args.load_from_dir:
+        if rank == 0:
+            os.makedirs(args.load_from_dir, exist_ok=True)
+            seedling = pkg.Tacotron2.synthetic(seed=wl.WEIGHT_SEED, rec_scale=1.0, device_id=local_rank)
+            seedling.save(args.load_from_dir)
+            seedling.close()
+        if dist is not None:
+            dist.barrier()
+        model = pkg.Tacotron2.load(args.load_from_dir, device_id=local_rank)
+    else:
+        model = pkg.Tacotron2.synthetic(seed=wl.WEIGHT_SEED, rec_scale=1.0, device_id=local_rank)
     vocoder = pkg.create_griffin_lim(device_id=local_rank, iters=GL_ITERS, seed=0)
 
     def barrier():
@@ -221,7 +243,8 @@ def main():
     bytes_per_utt = steps_per_utt * DECODER_PARAM_BYTES + active * per_item_bytes(T_ENC)
     achieved = bytes_per_utt / (dec_ms / K * 1e-3) / 1e9
     traffic, traffic_src = pmc_traffic()
-    floor_us, floor_src = edge_floor()
+    floor_us, floor_src = edge_floor(pkg, local_rank)
+    flops_per_step = active * per_item_flops(T_ENC) / steps_per_utt           # 37.7 MFLOP per active chunk
     us_per_step = dec_ms / dec_steps * 1e3
     out = {
         "metric": "mel-frames/s per GPU, 120-phoneme utterance (Tacotron2 decoder+postnet + %d-iter Griffin-Lim), end-to-end" % GL_ITERS,
@@ -270,11 +293,13 @@ def main():
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS,
+            "frac": min(1.0, floor_us / us_per_step) if floor_us else None,
             "algorithmic_frac": achieved / HBM_PEAK_GBS,
-            "frac_note": "algorithmic bytes / duration against the HBM peak, as the contract defines it; the weights are resident in "
-                         "registers (traffic < 1 % of the algorithmic bytes), so the figure can pass 1.0 -- the kernel's bound is "
-                         "frac_of_floor",
+            "vector_fma_frac": flops_per_step / (us_per_step * 1e-6) / 1e12 / VALU_F32_PEAK_TF,
+            "frac_note": "frac = frac_of_floor (latency floor / step time): the kernel's real bound.  algorithmic_frac = SURVEY 8(d)'s "
+                         "bookkeeping (achieved / peak: algorithmic bytes per second against 8 TB/s); the weights are resident in "
+                         "registers (traffic < 1 % of the algorithmic bytes), so that figure can pass 1.0 and is no roofline "
+                         "fraction.  vector_fma_frac = SURVEY 8(d)'s flops per step / step time against the fp32 vector peak",
             "traffic": traffic,
             "traffic_source": traffic_src,
             "limiter": "inter-CU exchange latency (5 dependent all-gather edges per step), not HBM bandwidth",
@@ -290,6 +315,18 @@ def main():
 
     log("headline done: %.0f frames/s" % value)
     extra = {}
+    if args.check_shared_utterance:
+        import hashlib
+
+        m0, a0 = pkg.synthesize(model, vocoder, utterances[0], splits=sp, opts=opts)
+        mine_sha = {"rank": rank, "mel_sha256": hashlib.sha256(np.ascontiguousarray(m0).tobytes()).hexdigest(),
+                    "audio_sha256": hashlib.sha256(np.ascontiguousarray(a0).tobytes()).hexdigest(), "frames": int(m0.shape[1]), "samples": int(a0.size)}
+        if dist is not None:
+            every = [None] * world
+            dist.all_gather_object(every, mine_sha)
+        else:
+            every = [mine_sha]
+        extra["shared_utterance"] = {"what": "utterance 0 of the headline set synthesized by every rank", "per_rank": every}
     if not args.no_extras:
         # ---- the same utterances with the REFERENCE's vocoder setting: 30 iterations (GriffinLim::new(.., 30, 0.99),
         # src/tacotron2/mod.rs:456; SURVEY 8(d) "reference default 30 also reported"), outside the timed region above
@@ -311,6 +348,36 @@ def main():
             voc30.close()
         except Exception as e:  # noqa: BLE001  (the headline line must still be printed)
             extra["headline_30_iterations"] = {"error": repr(e)}
+    if not args.no_extras:
+        # ---- the same utterance with the gate ON (the reference's real mode, mod.rs:319-324): gate_layer rigged so that
+        # sigmoid(gate) > 0.6 fires exactly at 633 / 167 frames (xd-tts_amd/gate_rig.py; every frame is unchanged), so the
+        # device-side stop rule, the survivor hand-over of the pair and the frame-count round trip are TIMED, not only tested
+        try:
+            rig = importlib.import_module("xd-tts_amd.gate_rig")
+            gopts = pkg.default_opts(dropout_seed=0, item_base=0)       # gate_threshold 0.6, max_steps 1000, no fixed steps
+            utt_g = utterances[mine[0]]
+            chunks_g = [utt_g[: lens[0]], utt_g[lens[0] :]]
+            rigged, rinfo = rig.rigged_gate_model(pkg, model, chunks_g, chunk_steps, gopts, device_id=local_rank)
+            mel_fix, _a = pkg.synthesize(model, vocoder, utt_g, splits=sp, opts=opts)
+            for _ in range(2):
+                mel_on, a_on = pkg.synthesize(rigged, vocoder, utt_g, splits=sp, opts=gopts)
+            barrier()
+            tg0 = time.perf_counter()
+            dec_on = 0.0
+            for _ in range(K):
+                mel_on, a_on = pkg.synthesize(rigged, vocoder, utt_g, splits=sp, opts=gopts)
+                dec_on += rigged.last_timings()["decoder_ms"]
+            barrier()
+            eg = max_over_ranks(time.perf_counter() - tg0)
+            extra["headline_gate_on"] = {
+                "workload": "configs[1]'s utterance with the stop rule deciding (gate_layer rigged to fire at %s frames; gate_threshold 0.6, max_decoder_steps 1000)" % chunk_steps,
+                "frames": int(mel_on.shape[1]), "frames_equal_fixed_steps_run": bool(mel_on.shape == mel_fix.shape and np.array_equal(mel_on, mel_fix)),
+                "mel_frames_per_s": mel_on.shape[1] * K * world / eg, "ms_per_utterance": eg / K * 1e3, "decoder_loop_ms": dec_on / K,
+                "decoder_us_per_step": dec_on / K * 1e3 / max(chunk_steps), "rig": rinfo}
+            rigged.close()
+            log("gate-on variant done")
+        except Exception as e:  # noqa: BLE001
+            extra["headline_gate_on"] = {"error": repr(e)}
     if not args.no_extras:
         # ---- configs[2] / configs[3]: this rank's share of 32*N utterances as one lock-step batch -------
         all_utts = wl.config4(pkg, n_batches=world)
@@ -413,6 +480,7 @@ def main():
             log("config5 done")
           except Exception as e:  # noqa: BLE001  (the headline line must still be printed)
             extra["config5"] = {"error": repr(e)}
+    if extra:
         out["extra"] = extra
 
     if rank == 0:

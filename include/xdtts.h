@@ -193,6 +193,12 @@ xdtts_status xdtts_tacotron2_engine_state(const xdtts_tacotron2 *h, int32_t *dec
                                           int32_t *encoder_cooperative, int32_t *batched_attention);
 xdtts_status xdtts_tacotron2_engine_reset(xdtts_tacotron2 *h);
 
+/* Measurement aid, not part of the reference's surface: the latency floor of one step of the
+ * persistent decoder engine on this device -- its five dependent inter-CU exchanges (x, h_att, 8 x T partial energies,
+ * h_dec, mel -> x) with no arithmetic between them, best of five launches of `steps` steps.  tuned != 0: the consumers
+ * delay their first polls as the engine does.  bench.py reports it as roofline.latency_floor_us. */
+xdtts_status xdtts_edge_floor_us(int32_t device_id, int32_t steps, int32_t T, int32_t tuned, double *us_per_step);
+
 /* postnet.onnx (mod.rs:345-355): frames (F x 80) -> mel_outputs_postnet (80 x F). */
 xdtts_status xdtts_tacotron2_postnet(xdtts_tacotron2 *h, const float *frames, int32_t F,
                                      float *mel_out);

@@ -110,6 +110,7 @@ SYMBOLS = {
     "xdtts_split_score": (_I32, [C.c_int64]),
     "xdtts_find_splits": (_I32, [_VP, _SZ, _SZ, _VP, _SZ, C.POINTER(_SZ)]),
     "xdtts_audio_to_i16": (_I32, [_VP, _SZ, _VP]),
+    "xdtts_edge_floor_us": (_I32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
     "xdtts_silence_samples": (_SZ, [C.c_double, _U32]),
     "xdtts_silence_samples_duration": (_SZ, [C.c_uint64, _U32, _U32]),
     "xdtts_wav_write": (_I32, [C.c_char_p, _VP, _SZ, _U32]),
@@ -272,6 +273,13 @@ def units_to_ids(tokens, as_character=False):
 
 
 SAMPLE_RATE = 22050  # WAV_SPEC, src/lib.rs:25-30
+
+
+def edge_floor_us(device_id=0, steps=2000, T=100, tuned=True):
+    """Latency floor of one persistent-decoder step on this device now (xdtts_edge_floor_us): us per step."""
+    us = C.c_double()
+    _check(lib.xdtts_edge_floor_us(device_id, steps, T, 1 if tuned else 0, C.byref(us)))
+    return us.value
 
 
 def audio_to_i16(audio):

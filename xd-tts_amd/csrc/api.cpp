@@ -7,6 +7,12 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <string>
+
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
+#include <cerrno>
 
 #include "kernels.h"
 
@@ -36,6 +42,12 @@ static xdtts_status guard(F &&f) {
     return XDTTS_ERR_OOM;
   } catch (const std::exception &e) {
     set_last_error(e.what());
+    return XDTTS_ERR_HIP;
+  } catch (const CoopRefused &) {  // (not a std::exception; the engines catch it where they can fall back)
+    set_last_error("cooperative launch refused by the runtime: the grid does not fit this device");
+    return XDTTS_ERR_HIP;
+  } catch (...) {  // nothing unwinds through the C ABI
+    set_last_error("unexpected exception");
     return XDTTS_ERR_HIP;
   }
 }
@@ -86,10 +98,16 @@ struct PinnedPool {
   // is released on its own (xdtts_free), the slab goes back to the pool with the last one.
   std::map<void *, void *> part_of;  // piece -> slab
   std::map<void *, int> pieces;      // slab -> pieces outstanding
-  void add_piece(void *slab, void *piece) {
+  void add_pieces(void *slab, const std::vector<float *> &cut) {  // all or nothing, under one lock
     std::lock_guard<std::mutex> lk(mu);
-    part_of[piece] = slab;
-    ++pieces[slab];
+    size_t done = 0;
+    try {
+      for (; done < cut.size(); ++done) part_of[cut[done]] = slab;
+      pieces[slab] = (int)cut.size();
+    } catch (...) {
+      for (size_t i = 0; i < done; ++i) part_of.erase(cut[i]);
+      throw;
+    }
   }
   void put(void *p) {
     std::unique_lock<std::mutex> lk(mu);
@@ -101,6 +119,7 @@ struct PinnedPool {
       pieces.erase(slab);
       p = slab;
     }
+    if (pieces.count(p)) return;  // a second xdtts_free of a slab's first piece while others are still out: not the slab's turn
     auto it = live.find(p);
     if (it == live.end()) return;  // not ours, or already released (a double xdtts_free): nothing to do --
                                    // freeing it here could hand a buffer in `spare` back to the runtime
@@ -158,8 +177,9 @@ struct PinnedSlab {
     return cut.back();
   }
   void hand_over() {  // from here on every piece is the caller's; the slab follows the last one
-    for (float *c : cut) pinned_pool().add_piece(base, c);
-    if (!cut.empty()) base = nullptr;
+    if (cut.empty()) return;
+    pinned_pool().add_pieces(base, cut);
+    base = nullptr;
   }
 };
 
@@ -176,14 +196,53 @@ struct Events {
 
 }  // namespace xdtts
 
+#include "edge_floor.hip"
+
 using namespace xdtts;
 
 // The cooperative encoder BiLSTM and the persistent decoder need their whole grid co-resident, so
 // two of them from different handles must never be in flight together (each could hold CUs the
 // other waits for).  Every call that launches one holds this lock from enqueue to completion.
-static std::recursive_mutex &chip_mutex(int device) {
-  static std::recursive_mutex m[64];  // one per GPU of this process
-  return m[(unsigned)device % 64u];
+// Between PROCESSES that share a GPU the same rule holds; XDTTS_CHIP_LOCK_DIR=<dir> (read once) adds an flock on
+// <dir>/xdtts_chip_<pci bus id>.lock to the lock, so that co-resident launches of different processes take turns instead of
+// timing out into the fallback engines (bench.py's two-ranks-on-one-GPU test mode uses it; so can a multi-worker server).
+class ChipLock {
+  std::recursive_mutex m;
+  int depth = 0, fd = -2, device = 0;  // fd -2: not looked at yet, -1: no file lock
+  void open_file() {
+    fd = -1;
+    const char *dir = getenv("XDTTS_CHIP_LOCK_DIR");
+    if (!dir || !*dir) return;
+    char bus[64] = "unknown";
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) std::snprintf(bus, sizeof bus, "dev%d", device);
+    for (char *c = bus; *c; ++c)
+      if (*c == ':' || *c == '/') *c = '_';
+    const std::string path = std::string(dir) + "/xdtts_chip_" + bus + ".lock";
+    fd = ::open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+    if (fd < 0) std::fprintf(stderr, "libxdtts_hip: cannot open %s; co-resident launches are serialised within this process only\n", path.c_str());
+  }
+
+ public:
+  void set_device(int d) { device = d; }
+  void lock() {
+    m.lock();
+    if (depth++ == 0) {
+      if (fd == -2) open_file();
+      if (fd >= 0)
+        while (::flock(fd, LOCK_EX) != 0 && errno == EINTR) {
+        }
+    }
+  }
+  void unlock() {
+    if (--depth == 0 && fd >= 0) (void)::flock(fd, LOCK_UN);
+    m.unlock();
+  }
+};
+static ChipLock &chip_mutex(int device) {
+  static ChipLock m[64];  // one per GPU of this process
+  ChipLock &c = m[(unsigned)device % 64u];
+  c.set_device(device);
+  return c;
 }
 
 // ================================================================================================
@@ -235,6 +294,7 @@ struct xdtts_tacotron2 {
   bool persist_probe_ok = false;            // the device can host the persistent grid (occupancy probe)
   bool coop_ok = true;                      // cooperative encoder BiLSTM usable (cleared after a timed-out exchange)
   bool coop_refused = false;                // the runtime refused its cooperative launch: never probed again
+  bool persist_refused = false;             // the same for the persistent decoder's grid (engine_reset does not undo it)
   int enc_demoted_calls = 0;                // encoder calls since its demotion (own re-probe counter)
   int coop_group = 16;                      // chunks per cooperative BiLSTM launch: 8 workgroups of 1024 threads per
                                             // chunk must be co-resident, one per CU (set from the CU count in init)
@@ -581,7 +641,7 @@ struct xdtts_tacotron2 {
     if (use_persistent(d)) try {
       // one launch for the whole loop: the stop rule runs on the device and the kernel ends by itself.
       // Its grid must own the chip, so persistent launches of different handles never overlap.
-      std::lock_guard<std::recursive_mutex> lk(chip_mutex(device));
+      std::lock_guard<ChipLock> lk(chip_mutex(device));
       // Chunks are independent, so 3 or 4 of them run as two launches of <= 2 over views of the
       // state arrays (measured: 2 x 15.4 us per step-pair against 37 us per step of the launch path).
       // A 2-chunk launch ends when its first chunk stops and the other is continued by the 1-chunk
@@ -714,6 +774,7 @@ struct xdtts_tacotron2 {
       // re-probe); decode the request on the launch-per-stage engine
       persist_state = 0;
       persist_probe_ok = false;
+      persist_refused = true;
       std::fprintf(stderr, "libxdtts_hip: persistent decoder launch refused by the runtime; this handle uses the "
                            "launch-per-stage decoder\n");
       HIP_CHECK(hipStreamSynchronize(stream));
@@ -722,8 +783,8 @@ struct xdtts_tacotron2 {
     }
     // the launch that holds the attention LSTM and the attention needs its 256 blocks resident together: like the
     // persistent engine's, such launches of different handles never overlap
-    std::unique_lock<std::recursive_mutex> chip;
-    if (d.hg) chip = std::unique_lock<std::recursive_mutex>(chip_mutex(device));
+    std::unique_lock<ChipLock> chip;
+    if (d.hg) chip = std::unique_lock<ChipLock>(chip_mutex(device));
     if (!d.use_gate) {  // deterministic work: every chunk runs to its cap
       while (launched + GRAPH_STEPS <= max_lim) {
         replay_steps(d);
@@ -885,7 +946,7 @@ struct xdtts_tacotron2 {
     if (B >= BATCH_MFMA_MIN) item_perm.upload(order.data(), B, stream);
     // (no sync here: the three sources are locals of this function -- the sorted copies -- and outlive the stream work,
     // which run_decoder waits out before it returns; a pageable source is staged before hipMemcpyAsync returns anyway)
-    std::lock_guard<std::recursive_mutex> chip(chip_mutex(device));  // released after run_decoder's final wait
+    std::lock_guard<ChipLock> chip(chip_mutex(device));  // released after run_decoder's final wait
     run_encoder(B, T);
     HIP_CHECK(hipEventRecord(ev.e[1], stream));
     // the cooperative BiLSTM's error word comes back with the decoder's own final fetch (one stream sync less per call)
@@ -1593,7 +1654,7 @@ xdtts_status xdtts_tacotron2_encoder(xdtts_tacotron2 *h, const int64_t *ids, int
     std::lock_guard<std::mutex> lk(h->mu);
     HIP_CHECK(hipSetDevice(h->device));
     h->ids.upload(ids, T, h->stream);
-    std::lock_guard<std::recursive_mutex> chip(chip_mutex(h->device));
+    std::lock_guard<ChipLock> chip(chip_mutex(h->device));
     h->run_encoder(1, T);
     HIP_CHECK(hipMemcpyAsync(memory, h->memory.p, (size_t)T * EMB * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_CHECK(hipMemcpyAsync(processed_memory, h->pmem.p, (size_t)T * ATT_DIM * sizeof(float), hipMemcpyDeviceToHost, h->stream));
@@ -1715,13 +1776,20 @@ xdtts_status xdtts_tacotron2_decoder_steps(xdtts_tacotron2 *h, int32_t engine, i
     d.dec_in = h->dec_in_dev.p;
     int fin = 0;  // ping-pong half that holds the final hidden states
     if (engine == 1) {
-      std::lock_guard<std::recursive_mutex> chip(chip_mutex(h->device));
+      if (!decoder_persistent_supported(h->device, PERSIST_B_MAX, PERSIST_T_MAX))
+        fail(XDTTS_ERR_HIP, "persistent engine not available on this device (its 256-workgroup grid cannot be co-resident)");
+      std::lock_guard<ChipLock> chip(chip_mutex(h->device));
       launch_decoder_prenet(d, h->w, st);  // x(step0) = prenet(decoder_input): the persistent kernel's own prenet produces x(s + 1)
       d.dec_in = nullptr;
       h->dec_exchange.alloc(persist_granule_words(B));
       PersistBufs g = persist_bufs(h->dec_exchange.p, h->dec_err.p, B);
       launch_persist_seed_at(d, g, h->limits.p, s0, st);
-      launch_decoder_persistent(d, h->w, g, n_steps, st);
+      try {
+        launch_decoder_persistent(d, h->w, g, n_steps, st);
+      } catch (const CoopRefused &) {
+        (void)hipStreamSynchronize(st);
+        fail(XDTTS_ERR_HIP, "persistent engine not available on this device (cooperative launch refused)");
+      }
       int e = 0;
       HIP_CHECK(hipMemcpyAsync(&e, h->dec_err.p, sizeof(int), hipMemcpyDeviceToHost, st));
       HIP_CHECK(hipStreamSynchronize(st));
@@ -1730,8 +1798,8 @@ xdtts_status xdtts_tacotron2_decoder_steps(xdtts_tacotron2 *h, int32_t engine, i
         fail(XDTTS_ERR_HIP, "persistent decoder exchange timed out (grid not co-resident)");
       }
     } else {
-      std::unique_lock<std::recursive_mutex> chip;
-      if (d.hg) chip = std::unique_lock<std::recursive_mutex>(chip_mutex(h->device));
+      std::unique_lock<ChipLock> chip;
+      if (d.hg) chip = std::unique_lock<ChipLock>(chip_mutex(h->device));
       if (engine == 0) launch_decoder_location(d, h->w, st);  // (the batched prenet launch computes them itself)
       launch_decoder_early(d, h->w, 0, st);  // (batched engine: the first attention-LSTM pass's early partial, from the imported state)
       launch_decoder_prologue(d, h->w, st);  // (two-launch form: x and location features of the first step; d.dec_in = decoder_input)
@@ -1803,11 +1871,26 @@ xdtts_status xdtts_tacotron2_engine_reset(xdtts_tacotron2 *h) {
   return guard([&] {
     if (!h) fail(XDTTS_ERR_BAD_ARG, "null handle");
     std::lock_guard<std::mutex> lk(h->mu);
-    h->persist_state = -1;
-    h->coop_ok = true;
+    // (a launch the runtime REFUSED is a property of the device, not a transient: those engines stay off)
+    if (!h->persist_refused) h->persist_state = -1;
+    if (!h->coop_refused) h->coop_ok = true;
     h->demoted_calls = 0;
+    h->enc_demoted_calls = 0;
     h->att_fused = xdtts_tacotron2::att_fused_default();
     h->att_demoted = false;
+  });
+}
+
+// Measurement aid (bench.py's roofline.latency_floor_us): the five dependent all-gather exchanges of one persistent-decoder
+// step with no arithmetic between them, timed on THIS device now (csrc/edge_floor.hip).
+xdtts_status xdtts_edge_floor_us(int32_t device_id, int32_t steps, int32_t T, int32_t tuned, double *us_per_step) {
+  return guard([&] {
+    if (!us_per_step || steps < 1 || steps > 1000000 || T < 1 || T > 128) fail(XDTTS_ERR_BAD_ARG, "bad argument");
+    select_device(device_id);
+    std::lock_guard<ChipLock> chip(chip_mutex(device_id));  // its grid must be co-resident, like the engine's
+    const double us = xdtts_edge_floor::measure(device_id, steps, T, xdtts_edge_floor::kernel_delays(tuned ? 1 : 0), 5, false);
+    if (us < 0) fail(XDTTS_ERR_HIP, "edge-floor skeleton: grid not co-resident on this device, or an exchange failed");
+    *us_per_step = us;
   });
 }
 
@@ -1955,7 +2038,7 @@ xdtts_status xdtts_griffinlim_set_seed(xdtts_griffinlim *g, uint32_t seed) {
 static void gl_iterate_and_fetch(xdtts_griffinlim *g, const GlBufs &b, const float *phase0_dev, int iters, float **audio,
                                  size_t *n_samples, bool normalise) {
   const size_t N = (size_t)g->hop * (size_t)(b.F - 1);
-  std::lock_guard<std::recursive_mutex> chip(chip_mutex(g->device));
+  std::lock_guard<ChipLock> chip(chip_mutex(g->device));
   g->probe_tick();
   for (int attempt = 0; attempt < 2; ++attempt) {
     g->iterate(b, phase0_dev, iters);
@@ -2028,7 +2111,7 @@ static void gl_batch_from_device(xdtts_griffinlim *g, const float *mel_dev_all, 
     g->audio.alloc(std::max<size_t>(Ntot, 1));
     HIP_CHECK(hipStreamSynchronize(st));  // the host vector above
     const float alpha = g->momentum / (1.0f + g->momentum);
-    std::lock_guard<std::recursive_mutex> chip(chip_mutex(g->device));
+    std::lock_guard<ChipLock> chip(chip_mutex(g->device));
     g->probe_tick();
     for (int attempt = 0;; ++attempt) {
       HIP_CHECK(hipEventRecord(g->ev.e[0], st));
@@ -2307,7 +2390,7 @@ xdtts_status xdtts_griffinlim_step(xdtts_griffinlim *g, const float *S, float *a
     launch_gl_state_import(b, g->phase0.p, g->phase0.p + ne * 2, g->stream);
     launch_gl_prepare(b, g->stream);
     const float alpha = g->momentum / (1.0f + g->momentum);
-    std::lock_guard<std::recursive_mutex> chip(chip_mutex(g->device));
+    std::lock_guard<ChipLock> chip(chip_mutex(g->device));
     g->probe_tick();
     for (int attempt = 0;; ++attempt) {
       const float2 *tp = nullptr;

@@ -53,8 +53,8 @@ __device__ __forceinline__ float4 ld_stream(const float4 *p) {
 __device__ __forceinline__ bool prenet_dropped(int mode, uint32_t seed, uint32_t item, const unsigned char *masks, int drop_steps, int chunk,
                                                int step, int layer, int j) {
   if (mode == 2) {
-    const int st = step < drop_steps ? step : drop_steps - 1;  // (speculative reads past a chunk's last step stay in bounds)
-    return masks[(((size_t)chunk * drop_steps + st) * 2 + layer) * PRENET + j] == 0;
+    if (step >= drop_steps) return false;  // past the caller's rows: kept, as the oracle's prenet_keep (only speculative steps get here)
+    return masks[(((size_t)chunk * drop_steps + step) * 2 + layer) * PRENET + j] == 0;
   }
   return (rng_u32(seed, 0x1000u + (uint32_t)layer + 2u * item, (uint32_t)step * 256u + (uint32_t)j) >> 31) != 0;
 }
