@@ -193,6 +193,11 @@ xdtts_status xdtts_tacotron2_engine_state(const xdtts_tacotron2 *h, int32_t *dec
                                           int32_t *encoder_cooperative, int32_t *batched_attention);
 xdtts_status xdtts_tacotron2_engine_reset(xdtts_tacotron2 *h);
 
+/* Identity of this build: "src_sha256=<sha256 over the library's sources in name order> arch=gfx950 built_utc=... compiler=...".
+ * The .so files are not in the git history (built by `make -C xd-tts_amd`, __graft_entry__.build()); the hash lets a test tell
+ * whether the library it loaded was built from the sources next to it. */
+const char *xdtts_build_info(void);
+
 /* Measurement aid, not part of the reference's surface: the latency floor of one step of the
  * persistent decoder engine on this device -- its five dependent inter-CU exchanges (x, h_att, 8 x T partial energies,
  * h_dec, mel -> x) with no arithmetic between them, best of five launches of `steps` steps.  tuned != 0: the consumers

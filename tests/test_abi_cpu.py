@@ -279,3 +279,11 @@ def test_real_time_factor_formula(pkg):
     assert pkg.real_time_factor(1.0, 22050) == pytest.approx(1.0)
     assert pkg.real_time_factor(0.0106, 204544) == pytest.approx(0.0106 / (204544 / 22050.0))
     assert pkg.real_time_factor(1.0, 0) == 0.0
+
+
+def test_the_loaded_library_was_built_from_the_sources_in_the_tree(pkg):
+    """The .so files are git-ignored and travel prebuilt: xdtts_build_info() carries the sha256 the Makefile took over
+    csrc/* and include/xdtts.h, and it must equal the hash of the sources next to the library (a stale .so fails here)."""
+    info = pkg.build_info()
+    assert info["arch"] == "gfx950"
+    assert info["src_sha256"] == pkg.source_hash(), "libxdtts_hip.so is stale: run `make -C xd-tts_amd` (or __graft_entry__.build())"

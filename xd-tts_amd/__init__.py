@@ -110,6 +110,7 @@ SYMBOLS = {
     "xdtts_split_score": (_I32, [C.c_int64]),
     "xdtts_find_splits": (_I32, [_VP, _SZ, _SZ, _VP, _SZ, C.POINTER(_SZ)]),
     "xdtts_audio_to_i16": (_I32, [_VP, _SZ, _VP]),
+    "xdtts_build_info": (C.c_char_p, []),
     "xdtts_edge_floor_us": (_I32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
     "xdtts_silence_samples": (_SZ, [C.c_double, _U32]),
     "xdtts_silence_samples_duration": (_SZ, [C.c_uint64, _U32, _U32]),
@@ -273,6 +274,26 @@ def units_to_ids(tokens, as_character=False):
 
 
 SAMPLE_RATE = 22050  # WAV_SPEC, src/lib.rs:25-30
+
+
+def build_info():
+    """xdtts_build_info() as a dict (src_sha256, arch, built_utc, compiler)."""
+    return dict(kv.split("=", 1) for kv in lib.xdtts_build_info().decode().split(" ") if "=" in kv)
+
+
+def source_hash():
+    """The hash the Makefile computes: sha256 over csrc/* and include/xdtts.h in name order."""
+    import glob
+    import hashlib
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, "csrc", "*")) + [os.path.join(here, "..", "include", "xdtts.h")],
+                   key=lambda p: os.path.relpath(p, here))
+    h = hashlib.sha256()
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
 
 
 def edge_floor_us(device_id=0, steps=2000, T=100, tuned=True):

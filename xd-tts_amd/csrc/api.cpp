@@ -1238,8 +1238,10 @@ struct xdtts_griffinlim {
       p.epoch = epoch;
       p.nblk = nblk;
       p.TF = TF;
+      p.poll_delay = -1;  // first poll behind the own overlap-add (tools/gl_poll_sweep.py: 4.76 us per iteration against 4.81-5.0 ahead of it)
       if (const char *sp = getenv("XDTTS_GL_SPINS")) p.spins = atoi(sp);  // test hook
       if (const char *sl = getenv("XDTTS_GL_SLOW")) p.slow = atoi(sl);    // test hook: straggler workgroup
+      if (const char *pd = getenv("XDTTS_GL_POLL_DELAY")) p.poll_delay = atoi(pd);  // developer sweep
       p.gen_phase = gen_phase ? 1 : 0;
       p.seed = seed;
       epoch += (unsigned)n_iter + 2u;
@@ -2253,6 +2255,7 @@ static void gl_batch_from_device(xdtts_griffinlim *g, const float *mel_dev_all, 
           p.nblk = L.nblk;
           p.TF = TF;
           p.per_cu = WG;
+          p.poll_delay = -1;
           g->epoch += (unsigned)g->iters + 2u;
           launch_gl_persistent(all, p, all.ang, all.tprev, g->iters, alpha, g->audio.p, st);
           fetch_audio(L.utts);

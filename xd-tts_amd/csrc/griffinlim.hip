@@ -646,7 +646,7 @@ __global__ __launch_bounds__(64 * W, PC) void k_gl_persistent(GlBufs g, GlPersis
     // What is not there yet is polled again in B2.
     constexpr int U0 = 3;
     u64 ev_l[U0], ev_r[U0];
-    {
+    auto early_poll = [&]() {
       const u64 *gl0 = inL + (size_t)par * 2 * GLP_HALO, *gr0 = gl0 + GLP_HALO;
 #pragma unroll
       for (int u = 0; u < U0; ++u) {
@@ -654,6 +654,10 @@ __global__ __launch_bounds__(64 * W, PC) void k_gl_persistent(GlBufs g, GlPersis
         ev_l[u] = (k < GLP_HALO && !seg_first) ? __hip_atomic_load(gl0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
         ev_r[u] = (k < GLP_HALO && outR != nullptr) ? __hip_atomic_load(gr0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
       }
+    };
+    if (p.poll_delay >= 0) {
+      for (int i = 0; i < p.poll_delay; ++i) __builtin_amdgcn_s_sleep(2);
+      early_poll();
     }
     // ---- B1: overlap-add of the own frames over the block's range (not yet normalised) -> yb.
     // float4 per thread; the 256-sample chunk index is wave-uniform, so the frame loop does not diverge.
@@ -676,6 +680,10 @@ __global__ __launch_bounds__(64 * W, PC) void k_gl_persistent(GlBufs g, GlPersis
         }
         yb4[q4] = a;
       }
+    }
+    if (p.poll_delay < 0) {
+      for (int i = 0; i < -1 - p.poll_delay; ++i) __builtin_amdgcn_s_sleep(2);
+      early_poll();
     }
     __syncthreads();
     GLP_MARK(3);  // own overlap-add

@@ -218,6 +218,7 @@ struct GlPersist {
   int per_cu;               // 2: the launch holds up to two 4-frame workgroups per CU (vocoder batch), else 0 / 1
   int spins;                // test hook: poll limit (0 = default)
   int slow;                 // test hook: a workgroup (index + 1) that stalls ~7 us at a different point of every iteration
+  int poll_delay;           // first poll of the neighbours' granules: n >= 0: n x 128 clocks after the publish, before the own overlap-add; n < 0: behind it (+ (-1 - n) x 128 clocks)
   int gen_phase;            // 1: the kernel draws the seeded initial phase itself (angles = exp(2 pi i u), previous spectrum 0)
   unsigned seed;            //    instead of reading ang_in / tprev_in (saves the phase-init launch and a round trip through HBM)
   float2 *ang_out, *tprev_out;  // parity hook: final state, or null
