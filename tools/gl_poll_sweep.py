@@ -1,5 +1,5 @@
 """Developer sweep: first-poll placement of the persistent Griffin-Lim kernel (XDTTS_GL_POLL_DELAY), us per iteration."""
-import importlib, os, sys
+import hashlib, importlib, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -18,4 +18,4 @@ for rep in range(2):
             best = min(best, voc.last_timings()["iterations_ms"])
         if ref is None:
             ref = a
-        print("poll_delay %3d: %.3f ms, %.3f us per iteration, same bits %s" % (pd, best, best * 1e3 / 61, np.array_equal(a, ref)), flush=True)
+        print("poll_delay %3d: %.3f ms, %.3f us per iteration, same bits %s, sha1 %s" % (pd, best, best * 1e3 / 61, np.array_equal(a, ref), hashlib.sha1(a.tobytes()).hexdigest()[:12]), flush=True)

@@ -117,25 +117,109 @@ __device__ __forceinline__ void fft512(float2 (&v)[8], float2 *buf, const Twiddl
 // positions per 16-lane group, an 8-way conflict) and the stride-64 lane groups of pass 2 become
 // conflict-free; all offsets stay compile-time per r.  Used where one wave per SIMD runs the
 // transform and every LDS cycle is exposed latency (the persistent kernel).
-constexpr int FFT_SWZ_F2 = 544;
-__device__ __forceinline__ void fft512s(float2 (&v)[8], float2 *buf, const Twiddles &t, int lane) {
-  fft8(v);
+constexpr int FFT_SWZ_F2 = 544;  // (the transform itself: fft512sp below)
+
+// ---- the same arithmetic on (re, im) register PAIRS ----------------------------------------------------------------------
+// The persistent kernel runs ONE wave per SIMD, so its iteration is a chain of single-wave VALU issues (4 clocks each): the
+// instruction count is the time.  Left to itself the compiler pairs scalars of DIFFERENT complex numbers into v_pk_* operations
+// and pays for it with register shuffles (288 v_mov in 2 500 instructions).  Here a complex number is one 64-bit register pair
+// and every complex operation is one or two packed instructions whose swaps, conjugations and multiplications by -i are operand
+// modifiers (op_sel / neg_lo / neg_hi).  Each operation is the IEEE operation the float2 forms above spell out (negations and
+// the factors 1/2 are exact); what differs from a build of those forms is only where the compiler contracts a*b+c.  Measured in
+// one session on one box: 4.87 -> 4.61 us per iteration at F = 1000, 251 VGPRs and no AGPR copies instead of 256 + 51.
+typedef float f2 __attribute__((ext_vector_type(2)));
+#define XD_PK2(name, op, mods)                                            \
+  __device__ __forceinline__ f2 name(f2 a, f2 b) {                        \
+    f2 r;                                                                 \
+    asm(op " %0, %1, %2 " mods : "=v"(r) : "v"(a), "v"(b));               \
+    return r;                                                             \
+  }
+XD_PK2(pk_add_mi, "v_pk_add_f32", "op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]")    // a + (-i) b = (a.x + b.y, a.y - b.x)
+XD_PK2(pk_sub_mi, "v_pk_add_f32", "op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]")    // a - (-i) b = (a.x - b.y, a.y + b.x)
+XD_PK2(pk_add_conj, "v_pk_add_f32", "neg_hi:[0,1]")                               // a + conj b = (a.x + b.x, a.y - b.y)
+XD_PK2(pk_sub_conj, "v_pk_add_f32", "neg_lo:[0,1]")                               // a - conj b = (a.x - b.x, a.y + b.y)
+XD_PK2(pk_conj_sub, "v_pk_add_f32", "neg_lo:[0,1] neg_hi:[1,0]")                  // conj(a - b) = (a.x - b.x, b.y - a.y)
+XD_PK2(pk_conj_sub_mi, "v_pk_add_f32", "op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[1,1]")  // conj(a - (-i) b) = (a.x - b.y, -a.y - b.x)
+XD_PK2(pk_odd, "v_pk_add_f32", "op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[1,0]")       // (a.y + b.y, b.x - a.x)
+XD_PK2(pk_mul_conj, "v_pk_mul_f32", "neg_hi:[0,1]")                               // (a.x b.x, -a.y b.y)
+__device__ __forceinline__ f2 pk_rot7(f2 a) {  // (a.y - a.x, -a.x - a.y) = a (-1 - i)
+  f2 r;
+  asm("v_pk_add_f32 %0, %1, %1 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[1,1]" : "=v"(r) : "v"(a));
+  return r;
+}
+__device__ __forceinline__ f2 pk_cmul(f2 a, f2 b) {  // a b:  (fma(a.x, b.x, -(a.y b.y)), fma(a.x, b.y, a.y b.x)) -- cmul()
+  f2 r;  // (one asm statement: between two of them the hazard recogniser puts a wait state it cannot rule out)
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\tv_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]"
+      : "=&v"(r)
+      : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ f2 pk_cmul_conj(f2 a, f2 b) {  // a conj(b) -- cmul(a, cconj(b))
+  f2 r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]\n\tv_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1] neg_hi:[0,1,0]"
+      : "=&v"(r)
+      : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ f2 as_f2(float2 v) { return (f2){v.x, v.y}; }
+
+// fft8 on register pairs: 28 packed instructions (16 + 8 butterflies, 4 for the two odd eighth-turn rotations; the
+// multiplications by -i are folded into the butterflies that consume them)
+__device__ __forceinline__ void fft8p(f2 (&v)[8]) {
+  const float h = 0.70710678118654752440f;
+  const f2 b0 = v[0] + v[4], b4 = v[0] - v[4];
+  const f2 b1 = v[1] + v[5];
+  f2 b5 = v[1] - v[5];
+  const f2 b2 = v[2] + v[6], b6 = v[2] - v[6];  // (b6 enters as -i b6 below)
+  const f2 b3 = v[3] + v[7];
+  f2 b7 = v[3] - v[7];
+  b5 = pk_add_mi(b5, b5) * h;  // (b5.x + b5.y, b5.y - b5.x) h = b5 (1 - i) / sqrt 2
+  b7 = pk_rot7(b7) * h;        // b7 (-1 - i) / sqrt 2
+  f2 d0 = b0 + b2, d1 = b0 - b2, d2 = b1 + b3, t = b1 - b3;
+  v[0] = d0 + d2;
+  v[4] = d0 - d2;
+  v[2] = pk_add_mi(d1, t);
+  v[6] = pk_sub_mi(d1, t);
+  d0 = pk_add_mi(b4, b6);
+  d1 = pk_sub_mi(b4, b6);
+  d2 = b5 + b7;
+  t = b5 - b7;
+  v[1] = d0 + d2;
+  v[5] = d0 - d2;
+  v[3] = pk_add_mi(d1, t);
+  v[7] = pk_sub_mi(d1, t);
+}
+struct TwiddlesP {
+  f2 p8[7], p64[7];
+};
+__device__ __forceinline__ TwiddlesP pack_twiddles(const Twiddles &t) {
+  TwiddlesP q;
+#pragma unroll
+  for (int r = 0; r < 7; ++r) {
+    q.p8[r] = as_f2(t.p8[r]);
+    q.p64[r] = as_f2(t.p64[r]);
+  }
+  return q;
+}
+// fft512 on register pairs, the exchange buffer addressed through phys(i) = i + (i >> 4) as described above
+__device__ __forceinline__ void fft512sp(f2 (&v)[8], f2 *buf, const TwiddlesP &t, int lane) {
+  fft8p(v);
   {
-    float2 *w = buf + 8 * lane + (lane >> 1);
+    f2 *w = buf + 8 * lane + (lane >> 1);
 #pragma unroll
     for (int r = 0; r < 8; ++r) w[r] = v[r];
   }
   wave_lds_sync();
-  const float2 *rd = buf + lane + (lane >> 4);
+  const f2 *rd = buf + lane + (lane >> 4);
   {
 #pragma unroll
     for (int r = 0; r < 8; ++r) v[r] = rd[68 * r];
 #pragma unroll
-    for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], t.p8[r - 1]);
-    fft8(v);
+    for (int r = 1; r < 8; ++r) v[r] = pk_cmul(v[r], t.p8[r - 1]);
+    fft8p(v);
     wave_lds_sync();
     const int j0 = (lane >> 3) * 64 + (lane & 7);
-    float2 *w = buf + j0 + (j0 >> 4);
+    f2 *w = buf + j0 + (j0 >> 4);
 #pragma unroll
     for (int r = 0; r < 8; ++r) w[8 * r + (r >> 1)] = v[r];
   }
@@ -143,8 +227,8 @@ __device__ __forceinline__ void fft512s(float2 (&v)[8], float2 *buf, const Twidd
 #pragma unroll
   for (int r = 0; r < 8; ++r) v[r] = rd[68 * r];
 #pragma unroll
-  for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], t.p64[r - 1]);
-  fft8(v);
+  for (int r = 1; r < 8; ++r) v[r] = pk_cmul(v[r], t.p64[r - 1]);
+  fft8p(v);
 }
 
 constexpr int FRAMES_PER_BLOCK = 4;  // one wave per frame
@@ -478,7 +562,8 @@ __global__ __launch_bounds__(64 * W, PC) void k_gl_persistent(GlBufs g, GlPersis
                                                          float *__restrict__ audio) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int TF = p.TF, nthr = 64 * TF;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+  // (wave index in an SGPR: "own frame?" and every per-wave base address are scalar, branches instead of exec masks)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), b = blockIdx.x;
   // this workgroup's frames: an even split of one utterance, or its row of the segment table (batch)
   int F = g.F, f0 = glp_fstart(b, g.F, p.nblk), nb_own = glp_fstart(b + 1, g.F, p.nblk) - f0, fbase = 0, abase = 0;
   bool seg_first = b == 0, seg_last = b + 1 == p.nblk;
@@ -507,32 +592,34 @@ __global__ __launch_bounds__(64 * W, PC) void k_gl_persistent(GlBufs g, GlPersis
 
   // ---- per-lane constants, once: FFT twiddles, the split/merge twiddles e^{-2 pi i k / 1024} and the
   // window at this lane's 8 packed positions ----
-  const Twiddles tws = load_twiddles(g.tw, lane);
-  float2 twk[8], wn[8];
+  const TwiddlesP tws = pack_twiddles(load_twiddles(g.tw, lane));
+  f2 twk[8], wn[8];
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
-    twk[r] = g.tw[lane + 64 * r];
-    wn[r] = reinterpret_cast<const float2 *>(g.win)[lane + 64 * r];
+    twk[r] = as_f2(g.tw[lane + 64 * r]);
+    // HALF the window: the 1/2 of the real <-> complex split (e, o below) rides on it -- into the inverse transform's output
+    // scale and ahead of the forward transform -- exactly (powers of two), so 24 multiplications per iteration disappear
+    wn[r] = as_f2(reinterpret_cast<const float2 *>(g.win)[lane + 64 * r]) * 0.5f;
   }
   // W == 4 (one wave per SIMD, the whole register file): the previous spectrum and the magnitudes of the
   // nine bins a lane updates (pairs k / 512-k for k = lane + 64 r, and k = 256 on lane 0) stay in REGISTERS
   // for the whole call -- 27 LDS accesses less per iteration in the phase-update chain.
   constexpr bool REGSTATE = W == 4 && PC == 1;
-  float2 rP[9];
+  f2 rP[9];
   float rS[9];
   if (REGSTATE && own) {
     const float *S = g.S + (size_t)(fbase + f) * g.nb;
     const float2 *P = tprev_in + (size_t)(fbase + f) * g.nb;
-    const float2 zero2 = make_float2(0.f, 0.f);
+    const f2 zero2 = (f2){0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int k = lane + 64 * r;
-      rP[2 * r] = p.gen_phase ? zero2 : P[k];
-      rP[2 * r + 1] = p.gen_phase ? zero2 : P[512 - k];
+      rP[2 * r] = p.gen_phase ? zero2 : as_f2(P[k]);
+      rP[2 * r + 1] = p.gen_phase ? zero2 : as_f2(P[512 - k]);
       rS[2 * r] = S[k];
       rS[2 * r + 1] = S[512 - k];
     }
-    rP[8] = p.gen_phase ? zero2 : P[256];
+    rP[8] = p.gen_phase ? zero2 : as_f2(P[256]);
     rS[8] = S[256];
   }
   // ---- state of this block's frames into LDS ----
@@ -572,7 +659,7 @@ __global__ __launch_bounds__(64 * W, PC) void k_gl_persistent(GlBufs g, GlPersis
   u64 *inL = p.xch + (size_t)b * 4 * GLP_HALO, *outL = !seg_first ? p.xch + ((size_t)(b - 1) * 4 + 1) * GLP_HALO : nullptr;
   u64 *outR = !seg_last ? p.xch + (size_t)(b + 1) * 4 * GLP_HALO : nullptr;
   // slot layout per block: [parity][side: 0 = from the left neighbour, 1 = from the right neighbour][768]
-  float2 *buf = reinterpret_cast<float2 *>(fb + wave * FBS);
+  f2 *buf = reinterpret_cast<f2 *>(fb + wave * FBS);
 
 #ifdef XDTTS_GL_PROFILE
   u64 prof_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -588,25 +675,25 @@ __global__ __launch_bounds__(64 * W, PC) void k_gl_persistent(GlBufs g, GlPersis
     GLP_MARK(0);  // loop overhead
     // ---- A: inverse transform of the own frame: irfft(1024) of S * angles, synthesis window -> fb ----
     if (own) {
-      const float2 *X = sA + wave * 513;
-      float2 v[8];
+      const f2 *X = reinterpret_cast<const f2 *>(sA + wave * 513);
+      f2 v[8];
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         const int k = lane + 64 * r, kc = 512 - k;
-        float2 xk = X[k], xc = X[kc];
+        f2 xk = X[k], xc = X[kc];
         if (k == 0) {  // irfft ignores the imaginary part of DC and Nyquist
           xk.y = 0.f;
           xc.y = 0.f;
         }
-        const float2 e = make_float2(0.5f * (xk.x + xc.x), 0.5f * (xk.y - xc.y));
-        const float2 d = make_float2(0.5f * (xk.x - xc.x), 0.5f * (xk.y + xc.y));
-        const float2 o = cmul(d, cconj(twk[r]));
-        v[r] = make_float2(e.x - o.y, -(e.y + o.x));
+        const f2 e = pk_add_conj(xk, xc);   // X[k] + conj X[512-k]   (the 1/2 is in wn)
+        const f2 d = pk_sub_conj(xk, xc);   // X[k] - conj X[512-k]
+        const f2 o = pk_cmul_conj(d, twk[r]);
+        v[r] = pk_conj_sub_mi(e, o);               // conj(e + i o): the forward transform of the conjugate = the inverse's conjugate
       }
-      fft512s(v, buf, tws, lane);
+      fft512sp(v, buf, tws, lane);
       const float sc = 1.0f / 512.0f;
 #pragma unroll
-      for (int r = 0; r < 8; ++r) buf[lane + 64 * r] = make_float2(v[r].x * sc * wn[r].x, -v[r].y * sc * wn[r].y);
+      for (int r = 0; r < 8; ++r) buf[lane + 64 * r] = pk_mul_conj(v[r] * sc, wn[r]);
     }
     GLP_MARK(1);  // A: inverse transform
     __syncthreads();
@@ -776,14 +863,11 @@ __global__ __launch_bounds__(64 * W, PC) void k_gl_persistent(GlBufs g, GlPersis
     }
     // ---- C: forward transform of the own frame from the block's signal, phase update ----
     if (own) {
-      float2 v[8];
+      f2 v[8];
       if (f >= 2 && f <= F - 3) {
-        const float2 *y2 = reinterpret_cast<const float2 *>(yb + HOP * wave);
+        const f2 *y2 = reinterpret_cast<const f2 *>(yb + HOP * wave);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          const float2 y = y2[lane + 64 * r];
-          v[r] = make_float2(y.x * wn[r].x, y.y * wn[r].y);
-        }
+        for (int r = 0; r < 8; ++r) v[r] = y2[lane + 64 * r] * wn[r];
       } else {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -794,11 +878,11 @@ __global__ __launch_bounds__(64 * W, PC) void k_gl_persistent(GlBufs g, GlPersis
           // spills, the 32-utterance vocoder batch 8 % slower)
           const int i0 = REGSTATE ? reflect_once(base, N) : reflect_index(base, N), i1 = REGSTATE ? reflect_once(base + 1, N) : reflect_index(base + 1, N);
           const float y0 = yb[i0 + NFFT / 2 - Q0], y1 = yb[i1 + NFFT / 2 - Q0];
-          v[r] = make_float2(y0 * wn[r].x, y1 * wn[r].y);
+          v[r] = (f2){y0 * wn[r].x, y1 * wn[r].y};
         }
       }
       GLP_MARK(7);  // C: gather + window
-      fft512s(v, buf, tws, lane);
+      fft512sp(v, buf, tws, lane);
       GLP_MARK(8);  // C: forward FFT
       wave_lds_sync();
 #pragma unroll
@@ -815,10 +899,10 @@ __global__ __launch_bounds__(64 * W, PC) void k_gl_persistent(GlBufs g, GlPersis
       // All LDS loads first, all stores last: the compiler cannot tell the state arrays apart (they are
       // carved from one buffer), so interleaved loads and stores would serialise into ~27 dependent LDS
       // round trips per iteration.
-      float2 *X = sA + wave * 513, *P = sP + wave * 513;
+      f2 *X = reinterpret_cast<f2 *>(sA + wave * 513), *P = reinterpret_cast<f2 *>(sP + wave * 513);
       const float *S = sS + wave * 516;
-      float2 *ang_g = (p.ang_out && it == n_iter - 1) ? p.ang_out + (size_t)(fbase + f) * g.nb : nullptr;  // parity hook
-      float2 zk[4], zc[4], pv[9];
+      f2 *ang_g = (p.ang_out && it == n_iter - 1) ? reinterpret_cast<f2 *>(p.ang_out + (size_t)(fbase + f) * g.nb) : nullptr;  // parity hook
+      f2 zk[4], zc[4], pv[9];
       float sk[9];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -830,24 +914,25 @@ __global__ __launch_bounds__(64 * W, PC) void k_gl_persistent(GlBufs g, GlPersis
         sk[2 * r] = REGSTATE ? rS[2 * r] : S[k];
         sk[2 * r + 1] = REGSTATE ? rS[2 * r + 1] : S[512 - k];
       }
-      const float2 z256 = buf[256];
+      const f2 z256 = buf[256];
       pv[8] = REGSTATE ? rP[8] : P[256];
       sk[8] = REGSTATE ? rS[8] : S[256];
-      float2 xs[9], xo[9];
+      f2 xs[9], xo[9];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float2 e = make_float2(0.5f * (zk[r].x + zc[r].x), 0.5f * (zk[r].y - zc[r].y));
-        const float2 o = make_float2(0.5f * (zk[r].y + zc[r].y), 0.5f * (zc[r].x - zk[r].x));
-        const float2 t = cmul(twk[r], o);
-        xs[2 * r] = cadd(e, t);
-        xs[2 * r + 1] = make_float2(e.x - t.x, t.y - e.y);
+        const f2 e = pk_add_conj(zk[r], zc[r]);  // (Z[k] + conj Z[512-k]) / 2   (Z is the transform of the half-windowed frame)
+        const f2 o = pk_odd(zk[r], zc[r]);       // (Z[k] - conj Z[512-k]) / 2i
+        const f2 t = pk_cmul(twk[r], o);
+        xs[2 * r] = e + t;
+        xs[2 * r + 1] = pk_conj_sub(e, t);
       }
-      xs[8] = make_float2(z256.x, -z256.y);
+      xs[8] = (f2){2.f * z256.x, -2.f * z256.y};  // X[256] = conj Z[256] of the full-window frame
+      const f2 malpha = (f2){-alpha, -alpha};
 #pragma unroll
       for (int i = 0; i < 9; ++i) {
-        const float2 a = make_float2(fmaf(-alpha, pv[i].x, xs[i].x), fmaf(-alpha, pv[i].y, xs[i].y));
+        const f2 a = __builtin_elementwise_fma(malpha, pv[i], xs[i]);
         const float inv = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(fmaf(a.x, a.x, a.y * a.y)) + 1e-16f);
-        xo[i] = make_float2(a.x * inv, a.y * inv);  // the unit-modulus angle
+        xo[i] = a * inv;  // the unit-modulus angle
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -863,14 +948,14 @@ __global__ __launch_bounds__(64 * W, PC) void k_gl_persistent(GlBufs g, GlPersis
           P[k] = xs[2 * r];
           P[512 - k] = xs[2 * r + 1];
         }
-        X[k] = make_float2(xo[2 * r].x * sk[2 * r], xo[2 * r].y * sk[2 * r]);
-        X[512 - k] = make_float2(xo[2 * r + 1].x * sk[2 * r + 1], xo[2 * r + 1].y * sk[2 * r + 1]);
+        X[k] = xo[2 * r] * sk[2 * r];
+        X[512 - k] = xo[2 * r + 1] * sk[2 * r + 1];
       }
       if (REGSTATE) rP[8] = xs[8];
       if (lane == 0) {
         if (ang_g) ang_g[256] = xo[8];
         if (!REGSTATE) P[256] = xs[8];
-        X[256] = make_float2(xo[8].x * sk[8], xo[8].y * sk[8]);
+        X[256] = xo[8] * sk[8];
       }
       wave_lds_sync();
     }
@@ -886,10 +971,10 @@ __global__ __launch_bounds__(64 * W, PC) void k_gl_persistent(GlBufs g, GlPersis
     if (REGSTATE) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        P[lane + 64 * r] = rP[2 * r];
-        P[512 - (lane + 64 * r)] = rP[2 * r + 1];
+        P[lane + 64 * r] = make_float2(rP[2 * r].x, rP[2 * r].y);
+        P[512 - (lane + 64 * r)] = make_float2(rP[2 * r + 1].x, rP[2 * r + 1].y);
       }
-      if (lane == 0) P[256] = rP[8];
+      if (lane == 0) P[256] = make_float2(rP[8].x, rP[8].y);
     } else {
       for (int k = lane; k < 513; k += 64) P[k] = sP[wave * 513 + k];
     }
