@@ -1238,7 +1238,7 @@ struct xdtts_griffinlim {
       p.epoch = epoch;
       p.nblk = nblk;
       p.TF = TF;
-      p.poll_delay = -1;  // first poll behind the own overlap-add (tools/gl_poll_sweep.py: 4.76 us per iteration against 4.81-5.0 ahead of it)
+      p.poll_delay = 6;  // first poll 6 x 128 clocks after the publish (tools/gl_poll_sweep.py, F = 1000: 4.31-4.36 us per iteration at 5..7, 4.39 behind the overlap-add, 4.45-4.53 at 2 or 10..12)
       if (const char *sp = getenv("XDTTS_GL_SPINS")) p.spins = atoi(sp);  // test hook
       if (const char *sl = getenv("XDTTS_GL_SLOW")) p.slow = atoi(sl);    // test hook: straggler workgroup
       if (const char *pd = getenv("XDTTS_GL_POLL_DELAY")) p.poll_delay = atoi(pd);  // developer sweep
@@ -2255,7 +2255,7 @@ static void gl_batch_from_device(xdtts_griffinlim *g, const float *mel_dev_all, 
           p.nblk = L.nblk;
           p.TF = TF;
           p.per_cu = WG;
-          p.poll_delay = -1;
+          p.poll_delay = 6;
           g->epoch += (unsigned)g->iters + 2u;
           launch_gl_persistent(all, p, all.ang, all.tprev, g->iters, alpha, g->audio.p, st);
           fetch_audio(L.utts);

@@ -698,30 +698,33 @@ __global__ __launch_bounds__(64 * W, PC) void k_gl_persistent(GlBufs g, GlPersis
     GLP_MARK(1);  // A: inverse transform
     __syncthreads();
     GLP_MARK(2);  // barrier after A
-    // ---- B0: what the neighbours lack, straight from the frames and before anything else so that the
-    // granules travel while the own range is summed: the first 768 samples of the range get own frames
-    // 0..2, the last 768 own frames n-3..n-1 (ascending; bitwise the same sums as B1 forms below) ----
+    // ---- B0: the own frames' sums over the first and the last 768 samples of the range (own frames 0..2 / n-3..n-1,
+    // ascending), straight from the frames and before anything else: they are what the neighbours lack -- so the granules
+    // travel while the middle of the range is summed -- and what B2 adds the neighbours' sums to, kept in registers ----
+    constexpr int U = 3;  // ceil(768 / threads) for 256..512 threads
+    float pl[U], pr[U];
     {
       const bool has_l = !seg_first, has_r = outR != nullptr;
 #pragma unroll
-      for (int u = 0; u < 3; ++u) {
+      for (int u = 0; u < U; ++u) {
         const int k = tid + u * nthr;
+        pl[u] = pr[u] = 0.f;
         if (k < GLP_HALO) {
-          if (has_l) {
-            float v = fb[k];
-            if (W == 4 ? u >= 1 : k >= HOP) v += fb[FBS + k - HOP];           // W == 4: 256 threads, u = the 256-sample third
-            if (W == 4 ? u >= 2 : k >= 2 * HOP) v += fb[2 * FBS + k - 2 * HOP];
+          float v = fb[k];
+          if (W == 4 ? u >= 1 : k >= HOP) v += fb[FBS + k - HOP];           // W == 4: 256 threads, u = the 256-sample third
+          if (W == 4 ? u >= 2 : k >= 2 * HOP) v += fb[2 * FBS + k - 2 * HOP];
+          pl[u] = v;
+          if (has_l)
             __hip_atomic_store(outL + (size_t)par * 2 * GLP_HALO + k, ((u64)want << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
-          }
-          if (has_r) {
-            const float l1 = fb[(nb_own - 1) * FBS + HOP + k];
-            float v = l1;
-            if (W == 4 ? u == 0 : k < HOP) v = (fb[(nb_own - 3) * FBS + 3 * HOP + k] + fb[(nb_own - 2) * FBS + 2 * HOP + k]) + l1;
-            else if (W == 4 ? u == 1 : k < 2 * HOP) v = fb[(nb_own - 2) * FBS + 2 * HOP + k] + l1;
+          const float l1 = fb[(nb_own - 1) * FBS + HOP + k];
+          v = l1;
+          if (W == 4 ? u == 0 : k < HOP) v = (fb[(nb_own - 3) * FBS + 3 * HOP + k] + fb[(nb_own - 2) * FBS + 2 * HOP + k]) + l1;
+          else if (W == 4 ? u == 1 : k < 2 * HOP) v = fb[(nb_own - 2) * FBS + 2 * HOP + k] + l1;
+          pr[u] = v;
+          if (has_r)
             __hip_atomic_store(outR + (size_t)par * 2 * GLP_HALO + k, ((u64)want << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
-          }
         }
       }
     }
@@ -746,46 +749,40 @@ __global__ __launch_bounds__(64 * W, PC) void k_gl_persistent(GlBufs g, GlPersis
       for (int i = 0; i < p.poll_delay; ++i) __builtin_amdgcn_s_sleep(2);
       early_poll();
     }
-    // ---- B1: overlap-add of the own frames over the block's range (not yet normalised) -> yb.
-    // float4 per thread; the 256-sample chunk index is wave-uniform, so the frame loop does not diverge.
+    // ---- B1: overlap-add and normalisation of the samples no neighbour reaches, [768, 256 n): four own frames each -> yb.
+    // float4 per thread; the 256-sample chunk index is wave-uniform.  (The edges of the range are B0's sums + B2.)
     {
       const float4 *fb4 = reinterpret_cast<const float4 *>(fb);
       float4 *yb4 = reinterpret_cast<float4 *>(yb);
-      for (int q4 = tid; q4 < (nb_own + 3) * (HOP / 4); q4 += nthr) {
-        const int c = q4 >> 6, lo = max(0, c - 3), hi = min(nb_own - 1, c);
-        float4 a = fb4[lo * (FBS / 4) + q4 - (HOP / 4) * lo];
-        for (int i = lo + 1; i <= hi; ++i) {  // ascending frame order
-          const float4 t = fb4[i * (FBS / 4) + q4 - (HOP / 4) * i];
+      for (int q4 = 3 * (HOP / 4) + tid; q4 < nb_own * (HOP / 4); q4 += nthr) {
+        const int c = q4 >> 6;
+        float4 a = fb4[(c - 3) * (FBS / 4) + q4 - (HOP / 4) * (c - 3)];
+#pragma unroll
+        for (int i = 2; i >= 0; --i) {  // ascending frame order
+          const float4 t = fb4[(c - i) * (FBS / 4) + q4 - (HOP / 4) * (c - i)];
           a.x += t.x;
           a.y += t.y;
           a.z += t.z;
           a.w += t.w;
         }
-        if (c >= 3 && c < nb_own) {  // samples no neighbour reaches ([768, 256 n)): normalise now
-          const float4 w = reinterpret_cast<const float4 *>(ws)[q4];
-          a = make_float4(a.x * w.x, a.y * w.y, a.z * w.z, a.w * w.w);
-        }
-        yb4[q4] = a;
+        const float4 w = reinterpret_cast<const float4 *>(ws)[q4];
+        yb4[q4] = make_float4(a.x * w.x, a.y * w.y, a.z * w.z, a.w * w.w);
       }
     }
     if (p.poll_delay < 0) {
       for (int i = 0; i < -1 - p.poll_delay; ++i) __builtin_amdgcn_s_sleep(2);
       early_poll();
     }
-    __syncthreads();
     GLP_MARK(3);  // own overlap-add
     // ---- B2: take the neighbours' contributions to the first / last 768 samples, normalise ----
     {
-      constexpr int U = 3;  // ceil(768 / threads) for 256..512 threads
-      float pl[U], pr[U], hl[U], hr[U];
+      float hl[U], hr[U];
       bool dl[U], dr[U];
       const bool has_l = !seg_first, has_r = outR != nullptr;
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int k = tid + u * nthr;
         const bool in = k < GLP_HALO;
-        pl[u] = in ? yb[k] : 0.f;
-        pr[u] = in ? yb[HOP * nb_own + k] : 0.f;
         hl[u] = hr[u] = 0.f;
         dl[u] = !(in && has_l);
         dr[u] = !(in && has_r);
