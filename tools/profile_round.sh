@@ -7,7 +7,7 @@ R=${1:-02}; HEAD=${2:-unknown}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/r$R; mkdir -p $OUT
 make -C xd-tts_amd prof -j16 > $OUT/make_prof.log 2>&1
-CMD="python bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+CMD="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras"   # (rocprofv3 dumps core at exit of this process, after its databases are written: harmless)
 rm -rf /tmp/prof_k /tmp/prof_f /tmp/prof_w
 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_k -o k -- $CMD > $OUT/prof_kernel.log 2>&1
 python tools/rocprof_summary.py $(find /tmp/prof_k -name "*.db" | head -1) > $OUT/kernel_stats.txt

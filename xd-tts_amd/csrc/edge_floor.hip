@@ -156,10 +156,11 @@ inline double measure(int device, int nsteps, int T, Delays dl, int reps, bool v
   int *err = nullptr;
   float *sink = nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipStream_t st = nullptr;  // (its own stream: nothing of this library touches the legacy default stream)
   double best = 1e30;
-  bool ok = hipMalloc(&buf, words * 8) == hipSuccess && hipMalloc(&err, 4) == hipSuccess &&
-            hipMalloc(&sink, sizeof(float) * NCU * NT) == hipSuccess && hipEventCreate(&e0) == hipSuccess &&
-            hipEventCreate(&e1) == hipSuccess;
+  bool ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipMalloc(&buf, words * 8) == hipSuccess &&
+            hipMalloc(&err, 4) == hipSuccess && hipMalloc(&sink, sizeof(float) * NCU * NT) == hipSuccess &&
+            hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
   Gran g{};
   if (ok) {
     g.x = buf;
@@ -171,16 +172,16 @@ inline double measure(int device, int nsteps, int T, Delays dl, int reps, bool v
     g.sink = sink;
   }
   for (int rep = 0; ok && rep < reps + 1; ++rep) {  // (the first launch is a warm-up)
-    ok = hipMemset(buf, 0, words * 8) == hipSuccess && hipMemset(err, 0, 4) == hipSuccess;
+    ok = hipMemsetAsync(buf, 0, words * 8, st) == hipSuccess && hipMemsetAsync(err, 0, 4, st) == hipSuccess;
     if (!ok) break;
-    hipLaunchKernelGGL(k_seed, dim3(1), dim3(256), 0, 0, g);
-    ok = hipDeviceSynchronize() == hipSuccess && hipEventRecord(e0) == hipSuccess;
+    hipLaunchKernelGGL(k_seed, dim3(1), dim3(256), 0, st, g);
+    ok = hipStreamSynchronize(st) == hipSuccess && hipEventRecord(e0, st) == hipSuccess;
     if (!ok) break;
-    hipLaunchKernelGGL(k_skeleton5, dim3(NCU), dim3(NT), 0, 0, g, nsteps, T, dl);
+    hipLaunchKernelGGL(k_skeleton5, dim3(NCU), dim3(NT), 0, st, g, nsteps, T, dl);
     float ms = 0;
     int herr = 0;
-    ok = hipEventRecord(e1) == hipSuccess && hipDeviceSynchronize() == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess &&
-         hipMemcpy(&herr, err, 4, hipMemcpyDeviceToHost) == hipSuccess;
+    ok = hipEventRecord(e1, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess &&
+         hipMemcpyAsync(&herr, err, 4, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
     if (!ok) break;
     const double us = ms * 1e3 / nsteps;
     if (verbose)
@@ -193,6 +194,7 @@ inline double measure(int device, int nsteps, int T, Delays dl, int reps, bool v
   if (sink) (void)hipFree(sink);
   if (e0) (void)hipEventDestroy(e0);
   if (e1) (void)hipEventDestroy(e1);
+  if (st) (void)hipStreamDestroy(st);
 #undef EF_CK
   return ok && best < 1e29 ? best : -1.0;
 }
