@@ -2183,6 +2183,12 @@ static void gl_batch_from_device(xdtts_griffinlim *g, const float *mel_dev_all, 
         // (the 4-frame shape splits an utterance the way its own call does, one or two workgroups per CU: batch_shape 4)
         if (g->per_cu4 >= 2 && pack(4, 2, false) < pack(4, 1, false)) WG = 2;
         if (g->gopts.batch_shape == 0 && pack(GLP_TF_MAX, 1, false) < pack(4, WG, false)) TF = GLP_TF_MAX, WG = 1;
+        if (const char *fs = getenv("XDTTS_GL_BATCH_FORCE")) {  // developer: "8" = 8-frame workgroups, "41" / "42" = 4-frame, one / two per CU
+          const int v = atoi(fs);
+          if (v == 8) TF = GLP_TF_MAX, WG = 1;
+          if (v == 41) TF = 4, WG = 1;
+          if (v == 42 && g->per_cu4 >= 2) TF = 4, WG = 2;
+        }
         pack(TF, WG, true);
       }
       bool used_persistent = false;
