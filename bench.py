@@ -136,6 +136,9 @@ def main():
     ap.add_argument("--check-shared-utterance", action="store_true",
                     help="every rank also synthesizes utterance 0 (outside the timed region) and the line carries the sha256 of "
                          "its mel and audio per rank: identical bits on every rank and in a single-process run")
+    ap.add_argument("--broadcast-weights", action="store_true",
+                    help="SURVEY 8(e)'s load-time collective: rank 0 builds the weight blob (113 MB) and broadcasts it (RCCL over xGMI, "
+                         "GPU 0 -> all); every rank loads from the received blob.  Default: each rank generates the same seeded weights")
     ap.add_argument("--load-from-dir", default=None, metavar="DIR",
                     help="every rank loads through Tacotron2::load(DIR) (mod.rs:242) -- the path a deployment uses -- from a "
                          "tacotron2.xdtw that rank 0 writes there first (synthetic weights); default: each rank generates them")
@@ -177,7 +180,19 @@ def main():
     if pkg.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: libxdtts_hip has no CPU path")
 
-    if args.load_from_dir:
+    if args.broadcast_weights:
+        n_floats = int(pkg.lib.xdtts_tensor_total())
+        if rank == 0:
+            seedling = pkg.Tacotron2.synthetic(seed=wl.WEIGHT_SEED, rec_scale=1.0, device_id=local_rank)
+            blob_t = torch.from_numpy(seedling.blob()).to(red_dev)
+            seedling.close()
+        else:
+            blob_t = torch.empty(n_floats, dtype=torch.float32, device=red_dev)
+        if dist is not None:
+            dist.broadcast(blob_t, src=0)          # the one load-time collective (no data-path collective follows)
+        model = pkg.Tacotron2.from_blob(blob_t.cpu().numpy(), device_id=local_rank)
+        del blob_t
+    elif args.load_from_dir:
         if rank == 0:
             os.makedirs(args.load_from_dir, exist_ok=True)
             seedling = pkg.Tacotron2.synthetic(seed=wl.WEIGHT_SEED, rec_scale=1.0, device_id=local_rank)

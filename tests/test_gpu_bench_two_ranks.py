@@ -84,3 +84,30 @@ def test_bench_two_ranks_on_one_gpu(pkg, tmp_path):
     assert "error" not in g and g["frames"] == 800 and g["frames_equal_fixed_steps_run"]
     voc.close()
     model.close()
+
+
+def test_bench_two_ranks_with_broadcast_weights(pkg):
+    """SURVEY 8(e)'s one load-time collective: rank 0 builds the 113 MB weight blob and broadcasts it, every rank loads from what it
+    received (gloo here; RCCL GPU 0 -> all on a multi-GPU node).  The shared utterance must come out with the bits of a handle
+    that generated the weights itself."""
+    import importlib
+
+    wl = importlib.import_module("xd-tts_amd.workloads")
+    env = dict(os.environ, XDTTS_BENCH_DEVICE="0", XDTTS_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--no-cpu-baseline", "--no-extras", "--check-shared-utterance", "--broadcast-weights"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    sh = out["extra"]["shared_utterance"]["per_rank"]
+    assert out["n_gpus"] == 2 and len(sh) == 2 and sh[0]["audio_sha256"] == sh[1]["audio_sha256"] and sh[0]["mel_sha256"] == sh[1]["mel_sha256"]
+    model = pkg.Tacotron2.synthetic(seed=wl.WEIGHT_SEED, rec_scale=1.0)
+    voc = pkg.create_griffin_lim(iters=60, seed=0)
+    sp = np.cumsum([len(c) for c in wl.config2(pkg)[1]]).astype(np.int64)
+    mel, audio = pkg.synthesize(model, voc, wl.synth_ids(120, seed=1), splits=sp, opts=pkg.default_opts(fixed_frames_per_id=wl.FRAMES_PER_ID, dropout_seed=0, item_base=0))
+    assert hashlib.sha256(np.ascontiguousarray(mel).tobytes()).hexdigest() == sh[0]["mel_sha256"]
+    assert hashlib.sha256(np.ascontiguousarray(audio).tobytes()).hexdigest() == sh[0]["audio_sha256"]
+    assert np.array_equal(model.blob(), pkg.Tacotron2.from_blob(model.blob()).blob())
+    voc.close()
+    model.close()

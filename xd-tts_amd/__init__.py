@@ -387,6 +387,15 @@ class Tacotron2:
     def save(self, path):
         _check(lib.xdtts_tacotron2_save(self._h, os.fsencode(path)))
 
+    def blob(self):
+        """The canonical flat fp32 weight blob of this handle (what from_blob / xdtts_tacotron2_load_blob take)."""
+        out = np.zeros(lib.xdtts_tensor_total(), dtype=np.float32)
+        for i, (_n, shape, off) in enumerate(tensor_table()):
+            t = np.empty(shape, dtype=np.float32)
+            _check(lib.xdtts_tacotron2_get_tensor(self._h, i, _ptr(t)))
+            out[off : off + t.size] = t.ravel()
+        return out
+
     def get_tensor(self, name):
         for i, (n, shape, _off) in enumerate(tensor_table()):
             if n == name:

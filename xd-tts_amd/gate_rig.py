@@ -63,12 +63,8 @@ def rigged_gate_model(pkg, model, chunks, steps, opts, device_id=0):
     frames under `opts`' dropout stream; returns (handle, info dict)."""
     X = record_gate_inputs(pkg, model, chunks, steps, opts)
     w, b, slack, wmax = solve_gate(X, steps)
-    table = pkg.tensor_table()
-    blob = np.zeros(pkg.lib.xdtts_tensor_total(), dtype=np.float32)
-    for name, shape, off in table:
-        t = model.get_tensor(name)
-        blob[off : off + t.size] = t.ravel()
-    tab = {n: (shape, off) for n, shape, off in table}
+    blob = model.blob()
+    tab = {n: (shape, off) for n, shape, off in pkg.tensor_table()}
     woff, boff = tab["gate_layer.weight"][1], tab["gate_layer.bias"][1]
     blob[woff : woff + 1536] = w.astype(np.float32)
     blob[boff] = np.float32(b)
