@@ -59,7 +59,7 @@ def chunks_for(orc, blob, B):
     return lens, mem, pm
 
 
-@pytest.mark.parametrize("engine,B", [("persistent", 1), ("persistent", 2), ("batched", 6), ("launch", 3)])
+@pytest.mark.parametrize("engine,B", [("persistent", 1), ("persistent", 2), ("batched", 6), ("launch", 3), ("persistent8", 3), ("persistent8", 4), ("persistent8", 8)])
 def test_teacher_forced_step_all_nine_outputs_per_engine(pkg, model, orc, blob, engine, B):
     lens, mem, pm = chunks_for(orc, blob, B)
     T = mem.shape[1]
@@ -83,7 +83,7 @@ def test_teacher_forced_step_all_nine_outputs_per_engine(pkg, model, orc, blob, 
     assert worst > 0  # two different implementations really were compared
 
 
-@pytest.mark.parametrize("engine,B", [("persistent", 1), ("persistent", 2), ("batched", 6), ("batched", 1), ("launch", 2)])
+@pytest.mark.parametrize("engine,B", [("persistent", 1), ("persistent", 2), ("batched", 6), ("batched", 1), ("launch", 2), ("persistent8", 3), ("persistent8", 8), ("persistent8", 1)])
 def test_written_back_state_after_a_60_step_run(pkg, model, orc, blob, engine, B):
     """n_steps = 60 from DecoderState::new (mod.rs:202-233): every frame, every gate logit and the seven state
     tensors the engine leaves behind against the oracle's after the same 60 calls."""
@@ -105,7 +105,7 @@ def test_written_back_state_after_a_60_step_run(pkg, model, orc, blob, engine, B
         assert np.abs(gst[k] - after[k]).max() <= 1e-5, (engine, k, float(np.abs(gst[k] - after[k]).max()))
 
 
-@pytest.mark.parametrize("engine,B", [("persistent", 2), ("batched", 5), ("launch", 1)])
+@pytest.mark.parametrize("engine,B", [("persistent", 2), ("batched", 5), ("launch", 1), ("persistent8", 5)])
 def test_step_hook_with_a_short_encoder_window_and_an_odd_step_count(pkg, model, orc, blob, engine, B):
     """T = 64 rows of encoder memory (not the reference's 100), 7 steps from step 3 of the oracle's run: odd counts end on the
     other ping-pong half of the launch-per-stage and batched engines."""

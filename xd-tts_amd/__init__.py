@@ -472,7 +472,7 @@ class Tacotron2:
                                                 _ptr(din), *[_ptr(st[k]) for k in names], _ptr(out), _ptr(gate)))
         return out, float(gate[0]), st
 
-    ENGINES = {"launch": 0, "persistent": 1, "batched": 2}
+    ENGINES = {"launch": 0, "persistent": 1, "batched": 2, "persistent8": 3}
 
     def decoder_steps(self, engine, memory, pmem, n_valid, states, decoder_input, step0, n_steps=1, opts=None):
         """n_steps decoder_iter calls for B chunks through the named engine ("launch" / "persistent" / "batched").

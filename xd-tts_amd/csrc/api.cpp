@@ -582,6 +582,20 @@ struct xdtts_tacotron2 {
   // Small lock-step batches run the persistent weight-stationary kernel (decoder_persistent.hip)
   // when its 256-workgroup grid can be co-resident; XDTTS_DECODER=launch forces the
   // launch-per-stage path (developer comparison aid).
+  // 3..8 chunks: the persistent MFMA engine (decoder_persistent8.hip), one launch for the whole loop.  It shares the persistent
+  // engine's fate: a timed-out exchange or a refused launch demotes both (persist_state), the request runs again on the
+  // launch-per-stage engine.
+  int p8_state = -1;  // -1 unknown, 0 off (XDTTS_P8=0, or the device cannot host the grid), 1 usable
+  bool small_batch_engine(int B, int T) {
+    if (B < 3 || B > P8_B_MAX || T > PERSIST_T_MAX) return false;
+    const char *e = getenv("XDTTS_DECODER");
+    if (e && std::string(e) == "launch") return false;
+    if (p8_state < 0) {
+      const char *p = getenv("XDTTS_P8");
+      p8_state = (p && p[0] == '1' && decoder_p8_supported(device, P8_B_MAX, PERSIST_T_MAX)) ? 1 : 0;
+    }
+    return p8_state == 1 && persist_state != 0;
+  }
   bool use_persistent(const DecoderBufs &d) {
     if (d.xf || d.B > 2 * PERSIST_B_MAX || d.T > PERSIST_T_MAX) return false;  // 3..4 chunks: two launches of <= 2
     const char *e = getenv("XDTTS_DECODER");
@@ -638,6 +652,30 @@ struct xdtts_tacotron2 {
       if (after_ran) *after_ran = spec_ran && as_planned;
       return steps;
     };
+    if (!d.xf && small_batch_engine(d.B, d.T)) try {
+      std::lock_guard<ChipLock> lk(chip_mutex(device));
+      dec_exchange.alloc(p8_granule_words());
+      P8Bufs g8 = p8_bufs(dec_exchange.p, dec_err.p);
+      if (const char *sp = getenv("XDTTS_PERSIST_SPINS")) g8.spins = atoi(sp);  // test hooks for the lost-workgroup path
+      if (const char *ft = getenv("XDTTS_PERSIST_FAULT")) g8.fault = atoi(ft);
+      launch_p8_seed(d, g8, limits.p, stream);
+      launch_decoder_p8(d, w, g8, max_lim, stream);
+      fetch(true);
+      if (!host_ctl[HOST_DEC_ERR]) return finish();
+      spec_ran = false;
+      HIP_CHECK(hipMemsetAsync(dec_err.p, 0, sizeof(int), stream));
+      p8_state = 0;
+      std::fprintf(stderr, "libxdtts_hip: persistent MFMA decoder exchange timed out (grid not co-resident); this handle now "
+                           "decodes small batches with its other engines\n");
+      launch_decoder_init(d, limits.p, stream);
+    } catch (const CoopRefused &) {
+      p8_state = 0;
+      std::fprintf(stderr, "libxdtts_hip: persistent MFMA decoder launch refused by the runtime; this handle decodes small batches "
+                           "with its other engines\n");
+      HIP_CHECK(hipStreamSynchronize(stream));
+      HIP_CHECK(hipMemsetAsync(dec_err.p, 0, sizeof(int), stream));
+      launch_decoder_init(d, limits.p, stream);
+    }
     if (use_persistent(d)) try {
       // one launch for the whole loop: the stop rule runs on the device and the kernel ends by itself.
       // Its grid must own the chip, so persistent launches of different handles never overlap.
@@ -928,7 +966,9 @@ struct xdtts_tacotron2 {
     }
     upload_dropout_masks(o, B, lim0.data());  // (caller's chunk order: a sorted batch finds its masks through item_perm)
     const bool gate_off = fixed_per_item || o.fixed_steps > 0 || o.fixed_frames_per_id > 0.f;
-    if (B >= BATCH_MFMA_MIN)
+    // (3..8 chunks on the persistent MFMA engine keep the row-major state of the small-batch engines and the caller's order)
+    const bool batched_mode = B >= BATCH_MFMA_MIN && !small_batch_engine(B, T);
+    if (batched_mode)
       std::stable_sort(order.begin(), order.end(), [&](int a, int c) {
         return gate_off ? lim0[a] > lim0[c] : lens[a] > lens[c];  // with the gate on, length is the proxy for duration
       });
@@ -943,7 +983,7 @@ struct xdtts_tacotron2 {
     lens = lens_sorted.data();
     ids.upload(ids_host, (size_t)B * T, stream);
     n_valid.upload(lens, B, stream);
-    if (B >= BATCH_MFMA_MIN) item_perm.upload(order.data(), B, stream);
+    if (batched_mode) item_perm.upload(order.data(), B, stream);
     // (no sync here: the three sources are locals of this function -- the sorted copies -- and outlive the stream work,
     // which run_decoder waits out before it returns; a pageable source is staged before hipMemcpyAsync returns anyway)
     std::lock_guard<ChipLock> chip(chip_mutex(device));  // released after run_decoder's final wait
@@ -951,9 +991,9 @@ struct xdtts_tacotron2 {
     HIP_CHECK(hipEventRecord(ev.e[1], stream));
     // the cooperative BiLSTM's error word comes back with the decoder's own final fetch (one stream sync less per call)
     HIP_CHECK(hipMemcpyAsync(host_ctl + HOST_ENC_ERR, enc_err.p, sizeof(int), hipMemcpyDeviceToHost, stream));
-    if (B >= BATCH_MFMA_MIN) w.ensure_batched_layout(blob, stream);
-    DecoderBufs d = decoder_bufs(B, T, memory.p, pmem.p, o);
-    if (B >= BATCH_MFMA_MIN) d.item_perm = item_perm.p;
+    if (batched_mode) w.ensure_batched_layout(blob, stream);
+    DecoderBufs d = decoder_bufs(B, T, memory.p, pmem.p, o, batched_mode ? 1 : 0);
+    if (batched_mode) d.item_perm = item_perm.p;
     if (fixed_per_item || o.fixed_frames_per_id > 0.f) d.use_gate = 0;
     // everything behind the decoder: frame counts -> column offsets -> post-net.  A gate-less decode on the persistent
     // engine enqueues it BEFORE the sync that fetches the counts (they are the caps), see run_decoder.
@@ -1706,7 +1746,10 @@ xdtts_status xdtts_tacotron2_decoder_steps(xdtts_tacotron2 *h, int32_t engine, i
     if (!h || !memory || !processed_memory || !n_valid || !decoder_input || !attention_hidden || !attention_cell || !decoder_hidden ||
         !decoder_cell || !attention_weights || !attention_weights_cum || !attention_context || !decoder_output || !gate_prediction)
       fail(XDTTS_ERR_BAD_ARG, "null argument");
-    if (engine < 0 || engine > 2) fail(XDTTS_ERR_BAD_ARG, "engine %d out of range (0 launch-per-stage, 1 persistent, 2 batched MFMA)", engine);
+    if (engine < 0 || engine > 3)
+      fail(XDTTS_ERR_BAD_ARG, "engine %d out of range (0 launch-per-stage, 1 persistent, 2 batched MFMA, 3 persistent MFMA)", engine);
+    if (engine == 3 && (B > P8_B_MAX || T > PERSIST_T_MAX))
+      fail(XDTTS_ERR_BAD_ARG, "the persistent MFMA engine takes at most %d chunks of at most %d encoder steps", P8_B_MAX, PERSIST_T_MAX);
     if (B <= 0 || B > 64) fail(XDTTS_ERR_BAD_ARG, "batch %d out of range (1..64)", B);
     if (T <= 0 || T > T_MAX) fail(XDTTS_ERR_BAD_ARG, "T %d out of range", T);
     if (n_steps <= 0 || n_steps > 100000 || (uint64_t)step0 + (uint64_t)n_steps > (1u << 30)) fail(XDTTS_ERR_BAD_ARG, "bad step range");
@@ -1798,6 +1841,28 @@ xdtts_status xdtts_tacotron2_decoder_steps(xdtts_tacotron2 *h, int32_t engine, i
       if (e) {
         HIP_CHECK(hipMemsetAsync(h->dec_err.p, 0, sizeof(int), st));
         fail(XDTTS_ERR_HIP, "persistent decoder exchange timed out (grid not co-resident)");
+      }
+    } else if (engine == 3) {
+      if (!decoder_p8_supported(h->device, P8_B_MAX, PERSIST_T_MAX))
+        fail(XDTTS_ERR_HIP, "persistent MFMA engine not available on this device (its 256-workgroup grid cannot be co-resident)");
+      std::lock_guard<ChipLock> chip(chip_mutex(h->device));
+      launch_decoder_prenet(d, h->w, st);  // x(step0) = prenet(decoder_input)
+      d.dec_in = nullptr;
+      h->dec_exchange.alloc(p8_granule_words());
+      P8Bufs g = p8_bufs(h->dec_exchange.p, h->dec_err.p);
+      launch_p8_seed_at(d, g, h->limits.p, s0, st);
+      try {
+        launch_decoder_p8(d, h->w, g, n_steps, st);
+      } catch (const CoopRefused &) {
+        (void)hipStreamSynchronize(st);
+        fail(XDTTS_ERR_HIP, "persistent MFMA engine not available on this device (cooperative launch refused)");
+      }
+      int e = 0;
+      HIP_CHECK(hipMemcpyAsync(&e, h->dec_err.p, sizeof(int), hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipStreamSynchronize(st));
+      if (e) {
+        HIP_CHECK(hipMemsetAsync(h->dec_err.p, 0, sizeof(int), st));
+        fail(XDTTS_ERR_HIP, "persistent MFMA decoder exchange timed out (grid not co-resident)");
       }
     } else {
       std::unique_lock<ChipLock> chip;

@@ -139,6 +139,23 @@ void launch_persist_seed_at(const DecoderBufs &d, const PersistBufs &g, const in
 void launch_decoder_persistent(const DecoderBufs &d, const DeviceWeights &w, const PersistBufs &g, int nsteps,
                                hipStream_t s);
 
+// ---- persistent weight-stationary decoder for 3..8 chunks (decoder_persistent8.hip): the LSTMs of all chunks as one MFMA
+// stream per wave, the context as a sixth exchange ------------------------------------------------------------------------
+constexpr int P8_B_MAX = 8;
+struct P8Bufs {
+  unsigned long long *x, *hatt, *ep, *ctx, *hdec, *mel;  // granules, [2 step parities][P8_B_MAX][n] each
+  int *err;          // set by a workgroup whose bounded spin ran out
+  int spins, fault;  // test hooks: poll limit (0 = default) and a workgroup (index + 1) that never runs
+};
+size_t p8_granule_words();
+P8Bufs p8_bufs(unsigned long long *base, int *err);
+bool decoder_p8_supported(int device, int B, int T);
+void launch_p8_seed(const DecoderBufs &d, const P8Bufs &g, const int *limits_dev, hipStream_t s);
+void launch_p8_seed_at(const DecoderBufs &d, const P8Bufs &g, const int *limits_dev, int step, hipStream_t s);
+// Runs up to `nsteps` decoder steps of d.B <= 8 chunks in one launch (ends early when every chunk has stopped); frames / gates /
+// nframes are complete on return, the state is written back, ctl[0] = steps executed.
+void launch_decoder_p8(const DecoderBufs &d, const DeviceWeights &w, const P8Bufs &g, int nsteps, hipStream_t s);
+
 // ---- NT GEMM on the f32 MFMA: C = act(A W^T + bias) (+R) ---------------------------------------
 struct GemmArgs {
   const float *A;
