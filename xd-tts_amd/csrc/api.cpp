@@ -654,8 +654,8 @@ struct xdtts_tacotron2 {
     };
     if (!d.xf && small_batch_engine(d.B, d.T)) try {
       std::lock_guard<ChipLock> lk(chip_mutex(device));
-      dec_exchange.alloc(p8_granule_words());
-      P8Bufs g8 = p8_bufs(dec_exchange.p, dec_err.p);
+      dec_exchange.alloc(p8_exchange_words(d.B, max_lim));
+      P8Bufs g8 = p8_bufs(dec_exchange.p, dec_err.p, d.B, max_lim);
       if (const char *sp = getenv("XDTTS_PERSIST_SPINS")) g8.spins = atoi(sp);  // test hooks for the lost-workgroup path
       if (const char *ft = getenv("XDTTS_PERSIST_FAULT")) g8.fault = atoi(ft);
       launch_p8_seed(d, g8, limits.p, stream);
@@ -1848,8 +1848,8 @@ xdtts_status xdtts_tacotron2_decoder_steps(xdtts_tacotron2 *h, int32_t engine, i
       std::lock_guard<ChipLock> chip(chip_mutex(h->device));
       launch_decoder_prenet(d, h->w, st);  // x(step0) = prenet(decoder_input)
       d.dec_in = nullptr;
-      h->dec_exchange.alloc(p8_granule_words());
-      P8Bufs g = p8_bufs(h->dec_exchange.p, h->dec_err.p);
+      h->dec_exchange.alloc(p8_exchange_words(B, n_steps));
+      P8Bufs g = p8_bufs(h->dec_exchange.p, h->dec_err.p, B, n_steps);
       launch_p8_seed_at(d, g, h->limits.p, s0, st);
       try {
         launch_decoder_p8(d, h->w, g, n_steps, st);

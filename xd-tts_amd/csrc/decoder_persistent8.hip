@@ -5,23 +5,34 @@
 // Between the two engines that existed (decoder_persistent.hip: <= 2 chunks per launch, its per-chunk arithmetic on the VALU,
 // 10.6 us per pair step; decoder.hip: two launches per lock-step iteration of up to 64 chunks, 26-30 us whatever the batch)
 // a batch of 3..16 chunks paid either two pair launches one after the other or the whole latency chain of the big engine.
-// This kernel keeps decoder_persistent.hip's skeleton -- 256 workgroups x 512 threads, one per CU; workgroup c owns the 16
-// gate rows of attention-LSTM units 4c..4c+3 and of decoder-LSTM units 4c..4c+3 with their weights in REGISTERS for the
-// whole loop; the state crosses CUs as data-tagged 8-byte granules {tag = step + 1, value}; roles per chunk on top of the
-// LSTM slices -- and changes the two things that do not scale with the chunk count there:
+// This kernel keeps decoder_persistent.hip's skeleton -- 256 workgroups (x 256 threads here), one per CU; workgroup c owns the
+// 16 gate rows of attention-LSTM units 4c..4c+3 and of decoder-LSTM units 4c..4c+3 with their weights in REGISTERS for the
+// whole loop; the state crosses CUs through memory that every workgroup polls; roles per chunk on top of the LSTM slices -- and
+// changes the three things that do not scale with the chunk count there:
 //   * the LSTM pre-activations of ALL chunks are one v_mfma_f32_16x16x4_f32 stream per wave: the wave's 16 x (K/8) weight
 //     slab is the A operand (136 VGPRs per lane, the same budget as the dot-product form), the chunks' state vectors in LDS
 //     in [k/4][8 chunks][4] order are the B operand (one ds_read_b128 feeds four MFMAs; columns 8..15 of the tile carry
 //     don't-care values that nothing reads), the 16 x 16 D tile holds unit u = lane / 16, chunk n = lane % 16, gates i,f,g,o
 //     in a lane's four registers -- so the eight K-slices meet in LDS and wave 0 does every cell update in registers.
-//     136 MFMAs per wave and step (1.8 us of a SIMD's matrix pipe, two waves per SIMD) whatever the number of chunks;
+//     272 MFMAs per wave and step (3.6 us of a SIMD's matrix pipe, one wave per SIMD with 512 registers: the 272 weights sit in
+//     AGPRs) whatever the number of chunks;
 //   * the attention context crosses as a SIXTH edge (512 values per chunk, from the chunk's 8 attention workgroups) instead
 //     of being folded into the encoder memory: the fold tables cost 20 registers or 16 kB of LDS per chunk.  In exchange the
 //     partial energies only travel among a chunk's own 8 attention workgroups, which are the only ones that need the softmax.
+//   * the four vectors that EVERY workgroup gathers (x, h_att, ctx, h_dec: 11 kB per chunk and step) cross as plain 4-byte values
+//     in a WRITE-ONCE ring, one slab per step, filled with 0xFFFFFFFF (a NaN no arithmetic here produces) before the launch: a
+//     value is its own arrival flag, a 16-byte load brings four of them (one producer's units), and no address is ever
+//     written twice in a launch.  Measured on the edge alone (tools/ubench_allgather.hip, 256 workgroups, 1024 values per
+//     chunk): 1.45 / 1.73 us per all-gather at 4 / 8 chunks against 2.5-3.2 / 4.4-4.8 us for {tag, value} granules.  x carries
+//     the chunk's active bit in its sign (x >= 0: it leaves a ReLU).  The two narrow edges (partial energies among a chunk's
+//     8 attention workgroups, mel rows among its 16 projection workgroups) stay data-tagged 8-byte granules.
 // Per step:  x -> [attention LSTM] -> h_att -> [query, energies] -> e -> [softmax, context] -> ctx -> [decoder LSTM] -> h_dec
 //            -> [projection rows] -> mel -> [stop rule, prenet] -> x(s+1)
 // Only the columns of the newest vector are multiplied on the critical path (8 / 16 MFMAs per wave); the others are
 // accumulated while the next vector's producers are busy.  Every spin is bounded and watches a global error word.
+#include <cstdio>
+#include <cstdlib>
+
 #include "device_utils.h"
 #include "kernels.h"
 
@@ -32,10 +43,14 @@ namespace {
 typedef unsigned long long u64;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int PT = 512, NW = PT / 64, NB = P8_B_MAX, P_NCU = ATT_RNN / 4, TP = PERSIST_T_MAX;
+constexpr int PT = 256, NW = PT / 64, NBMAX = P8_B_MAX, P_NCU = ATT_RNN / 4, TP = PERSIST_T_MAX;
 constexpr int ATTN_CU = 8, PRE_CU = 16, EP_LD = TP, MEL_GL = 96, WPAD = TP + 32;
 constexpr unsigned P_SPIN_LIMIT = 1u << 21, ACT_BIT = 0x80000000u;
-static_assert(NB == 8 && ATT_RNN == DEC_RNN && P_NCU == 256 && (ATTN_CU + PRE_CU) * NB <= P_NCU, "role workgroups of 8 chunks fit the grid");
+static_assert(NBMAX == 8 && ATT_RNN == DEC_RNN && P_NCU == 256 && (ATTN_CU + PRE_CU) * NBMAX <= P_NCU, "role workgroups of 8 chunks fit the grid");
+static_assert(TP == 128 && PRENET == PT && EMB == 2 * PT && ATT_RNN == 4 * PT, "thread <-> granule maps below");
+
+// chunk slots of the kernel instance that serves a batch of B
+__host__ __device__ constexpr int p8_slots(int B) { return B <= 4 ? 4 : NBMAX; }
 
 __device__ __forceinline__ void publish(u64 *slot, unsigned tag, float v) {
   __hip_atomic_store(slot, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -53,20 +68,27 @@ __device__ __forceinline__ bool give_up(unsigned &spins, const PollCtl &pc) {
   __builtin_amdgcn_s_sleep(1);
   return false;
 }
-// N granules at base[idx + i * stride] (those of the bit mask `need`), all loads in flight together; every value is handed to
+// N granules at base[at(i)] (those of the bit mask `need`), all loads in flight together; every value is handed to
 // sink(i, value, tag) the moment its tag matches -- nothing is kept in registers behind the loads themselves.  A timed-out slot
 // is never delivered.  EVERY round issues all N loads (a granule that is not wanted, or has been delivered, is asked for again --
-// or slot 0 in its place): with the loads themselves under per-lane conditions, lanes were handed the value of ANOTHER granule of
-// the same round now and then (four neighbouring lanes = one 32-byte sector at a time, caught by comparing the LDS copy with the
-// granule it came from: the chunk-1 value in chunk 0's place) -- the wait counts of a round assume its loads were all issued.
-template <int N, class Sink>
-__device__ __forceinline__ void gather(const u64 *base, unsigned idx, unsigned stride, unsigned want, unsigned need, const PollCtl &pc,
-                                       Sink sink) {
-  unsigned pending = need & ((1u << N) - 1u), spins = 0;
+// or the first wanted one in its place): with the loads themselves under per-lane conditions, lanes were handed the value of
+// ANOTHER granule of the same round now and then (four neighbouring lanes = one 32-byte sector at a time, caught by comparing
+// the LDS copy with the granule it came from: the chunk-1 value in chunk 0's place) -- the wait counts of a round assume its
+// loads were all issued.
+__device__ __forceinline__ void nap(int n) {
+#pragma unroll 1
+  for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
+}
+template <int N, class At, class Sink>
+__device__ __forceinline__ unsigned gather(const u64 *base, unsigned want, unsigned need, const PollCtl &pc, At at, Sink sink) {
+  unsigned pending = N < 32 ? need & ((1u << (N & 31)) - 1u) : need, spins = 0;
+  const int first = pending ? __ffs(pending) - 1 : 0;
   while (pending) {
     u64 v[N];
+    unsigned zero = 0u;
+    asm volatile("" : "+v"(zero));  // (opaque: the N addresses are formed next to their loads, not kept in 2 N registers across the loop)
 #pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = peek(base + (idx + (unsigned)(((need >> i) & 1u) ? i : 0) * stride));  // (see the note above)
+    for (int i = 0; i < N; ++i) v[i] = peek(base + (zero + at(((need >> i) & 1u) ? i : first)));
 #pragma unroll
     for (int i = 0; i < N; ++i)
       if ((pending >> i) & 1u) {
@@ -76,24 +98,60 @@ __device__ __forceinline__ void gather(const u64 *base, unsigned idx, unsigned s
           pending &= ~(1u << i);
         }
       }
-    if (pending && give_up(spins, pc)) return;
+    if (pending && give_up(spins, pc)) return spins;
   }
+  return spins;  // failed rounds
 }
+// The same for a write-once slab of plain values: N 16-byte loads at byte offsets at(i) of `slab`, a quad is delivered once none
+// of its four words is the fill pattern (they are four dword stores of one producer, or one 16-byte store).  First round sc1,
+// retries sc0 sc1.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned UNWRITTEN = 0xffffffffu;
+__device__ __forceinline__ unsigned value_bits(float v) {  // what a producer stores: never the fill pattern
+  const unsigned b = __float_as_uint(v);
+  return b == UNWRITTEN ? 0x7fc00000u : b;
+}
+__device__ __forceinline__ void put(unsigned *slot, unsigned bits) { __hip_atomic_store(slot, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <int N, class At, class Sink>
+__device__ __forceinline__ unsigned gather16(const unsigned *slab, unsigned need, const PollCtl &pc, At at, Sink sink) {
+  unsigned pending = need & ((1u << N) - 1u), spins = 0;
+  const int first = pending ? __ffs(pending) - 1 : 0;
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)slab, 0, 0x7fffffff, 0x00020000);
+  while (pending) {
+    u32x4 v[N];
+    unsigned zero = 0u;
+    asm volatile("" : "+v"(zero));
+    if (spins == 0) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(zero + at(((need >> i) & 1u) ? i : first)), 0, 16);
+    } else {
+#pragma unroll
+      for (int i = 0; i < N; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(zero + at(((need >> i) & 1u) ? i : first)), 0, 17);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      if (((pending >> i) & 1u) && v[i].x != UNWRITTEN && v[i].y != UNWRITTEN && v[i].z != UNWRITTEN && v[i].w != UNWRITTEN) {
+        sink(i, v[i]);
+        pending &= ~(1u << i);
+      }
+    if (pending && give_up(spins, pc)) return spins;
+    asm volatile("" ::: "memory");
+  }
+  return spins;  // failed rounds
+}
+__device__ __forceinline__ float4 as_f4(u32x4 v) { return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)); }
 __device__ __forceinline__ float4 lds4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
-// index of element (k, chunk n) of a state vector kept in MFMA B-operand order [k/4][NB][4]
-__device__ __forceinline__ int bidx(int k, int n) { return ((k >> 2) * NB + n) * 4 + (k & 3); }
 
 struct P8Weights {
   const float4 *att_w, *dec_w, *q_w, *proj_w;
   const float *att_b, *dec_b, *v_w, *loc_fused, *proj_b, *pre0T, *pre1T;
 };
 
-// NQ b128 loads of the wave's slice of one state segment (seg: LDS base of the segment in B order; q0: the wave's first
-// column quad-of-quads), 4 MFMAs each, into acc.  A[q] = the lane's four weights of columns 16 (q0 + q) + 4 kk .. + 3.
-template <int NQ>
+// NQ b128 loads of the wave's slice of one state segment (seg: LDS base of the segment in B order [k/4][NB][4]; q0: the wave's
+// first column quad-of-quads), 4 MFMAs each, into acc.  A[q] = the lane's four weights of columns 16 (q0 + q) + 4 kk .. + 3.
+template <int NB, int NQ>
 __device__ __forceinline__ void mfma_segment(f32x4 &acc, const float4 (&A)[NQ], const float *seg, int q0, int kk, int n) {
-  // one B vector ahead of the MFMAs that consume it, and no further: left alone the scheduler hoists every load of a segment
-  // (and of the next) above the first MFMA -- 64 registers that this kernel does not have (its weights went to scratch)
+  // one B vector ahead of the MFMAs that consume it, and no further
   const float *bp = seg + ((4 * q0 + kk) * NB + n) * 4;
   float4 b = lds4(bp);
 #pragma unroll
@@ -109,13 +167,30 @@ __device__ __forceinline__ void mfma_segment(f32x4 &acc, const float4 (&A)[NQ], 
   }
 }
 
+// Developer build (-DXDTTS_P8_PROFILE): thread 0 of three workgroups (one per role) accumulates the 100 MHz wall clock between
+// phase markers and prints the sums at exit.
+#ifdef XDTTS_P8_PROFILE
+#define P8_MARK(i)                                        \
+  do {                                                    \
+    if (tid == 0) {                                       \
+      const u64 now_ = wall_clock64();                    \
+      s_prof[i] += now_ - prof_last;                      \
+      prof_last = now_;                                   \
+    }                                                     \
+  } while (0)
+#else
+#define P8_MARK(i) do { } while (0)
+#endif
+
+// NB = chunk slots compiled in (4 or 8): the width of the state vectors in LDS and of every gather
+template <int NB>
 __global__ __launch_bounds__(PT) void k_decoder_persistent8(DecoderBufs d, P8Bufs g, P8Weights w, int nsteps) {
-  // LDS (154 of 160 kB).  The state vectors of all chunks in MFMA B-operand order; x and ctx share a buffer and so do h_att
-  // and h_dec: each is consumed (by the MFMAs that follow its gather) before the other is gathered, barriers in between.
-  constexpr int ATTN_FLOATS = 2 * TP * 16 + 3 * TP + 16 + NW * 64 + 2 * WPAD + 62 * 16 + 16 + 8 * PT * 4;
-  constexpr int PRE_FLOATS = N_MEL * PRENET + MEL_GL + 2 * PRENET + 8;
+  // LDS (148 of 160 kB at NB = 8).  The state vectors of all chunks in MFMA B-operand order; x and ctx share a buffer and so do
+  // h_att and h_dec: each is consumed (by the MFMAs that follow its gather) before the other is gathered, barriers in between.
+  constexpr int ATTN_FLOATS = 2 * TP * 16 + 3 * TP + 16 + PT + 2 * WPAD + 62 * 16 + 16 + 16 * PT * 4;
+  constexpr int PRE_FLOATS = N_MEL * PRENET + MEL_GL + 8;
   __shared__ __attribute__((aligned(16))) float s_xc[EMB * NB], s_h[ATT_RNN * NB];
-  __shared__ __attribute__((aligned(16))) float s_acc[NW * 64 * 4];  // the eight K-slices' partial D tiles
+  __shared__ __attribute__((aligned(16))) float s_acc[NW * 64 * 4];  // the four K-slices' partial D tiles
   __shared__ __attribute__((aligned(16))) float s_hrow[ATT_RNN];     // the role's own chunk, row-major: h_att (attention) / h_dec (projection)
   __shared__ __attribute__((aligned(16))) float s_crow[EMB];         // projection role: ctx of its chunk, row-major
   __shared__ __attribute__((aligned(16))) float s_role[ATTN_FLOATS > PRE_FLOATS ? ATTN_FLOATS : PRE_FLOATS];
@@ -123,16 +198,18 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent8(DecoderBufs d, P8Buf
   float *const s_x = s_xc, *const s_ctx = s_xc, *const s_hatt = s_h, *const s_hdec = s_h;
   // attention role
   float *s_pm = s_role, *s_loc = s_pm + TP * 16, *s_aw = s_loc + TP * 16, *s_awc = s_aw + TP, *s_e = s_awc + TP, *s_q = s_e + TP,
-        *s_part = s_q + 16, *s_wpad = s_part + NW * 64, *s_G = s_wpad + 2 * WPAD, *s_vv = s_G + 62 * 16,
-        *s_qw = s_vv + 16;  // [8][PT] float4: query rows 16 rk + wave (+8), 4 x 16 B per lane each
+        *s_part = s_q + 16, *s_wpad = s_part + PT, *s_G = s_wpad + 2 * WPAD, *s_vv = s_G + 62 * 16,
+        *s_qw = s_vv + 16;  // [16][PT] float4: query rows 16 rk + wave + 4 r, 4 x 16 B per lane each
   // projection + prenet role
-  float *s_W0 = s_role, *s_mel = s_W0 + N_MEL * PRENET, *s_l1 = s_mel + MEL_GL, *s_pb = s_l1 + 2 * PRENET;  // s_W0 [20][256][4]
+  float *s_W0 = s_role, *s_mel = s_W0 + N_MEL * PRENET, *s_pb = s_mel + MEL_GL;  // s_W0 [20][256][4]
 
   const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int B = d.B, T = d.T;
   const PollCtl pc{g.err, g.spins > 0 ? (unsigned)g.spins : P_SPIN_LIMIT};
   if (g.fault && c == g.fault - 1) return;  // test hook: this workgroup never shows up
   const int kk = lane >> 4, n16 = lane & 15, n = n16 & (NB - 1);  // MFMA lane coordinates: k-quad / chunk column
+  // index of element (k, chunk b) of a state vector kept in MFMA B-operand order [k/4][NB][4]
+  auto bidx = [](int k, int b) { return ((k >> 2) * NB + b) * 4 + (k & 3); };
 
   // wave 0 finalises both cells: lane = (unit u = lane / 16, chunk n16); its four registers of a D tile are the gates i,f,g,o
   const int cu = lane >> 4;
@@ -154,8 +231,6 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent8(DecoderBufs d, P8Buf
   const bool attn = c < ATTN_CU * B, pre = !attn && c < (ATTN_CU + PRE_CU) * B;
   const int rb = attn ? c / ATTN_CU : (pre ? (c - ATTN_CU * B) / PRE_CU : 0);
   const int rk = attn ? c % ATTN_CU : (c - ATTN_CU * B) % PRE_CU;
-  const int prow = rk + 16 * wave;
-  const bool prow_ok = pre && wave < 6 && prow <= N_MEL;
   const int step0 = d.ctl[0];
   if (tid < NB) {
     s_act[tid] = 0;
@@ -167,22 +242,21 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent8(DecoderBufs d, P8Buf
   // ctx first (the attention LSTM's partial), h_dec behind the barrier below
 #pragma unroll 1
   for (int i = tid; i < ATT_RNN * NB; i += PT) {
-    const int k = i >> 3, b = i & (NB - 1);
+    const int k = i / NB, b = i & (NB - 1);
     s_hatt[bidx(k, b)] = b < B ? d.att_h[0][b * ATT_RNN + k] : 0.f;
   }
 #pragma unroll 1
   for (int i = tid; i < EMB * NB; i += PT) {
-    const int k = i >> 3, b = i & (NB - 1);
+    const int k = i / NB, b = i & (NB - 1);
     s_ctx[bidx(k, b)] = b < B ? d.ctx[b * EMB + k] : 0.f;
   }
-  // attention role: processed memory of its 16 dims, the memory columns of its context slice (registers), location filter
-  // role registers (one array, two uses): attention role [0, 16): memory[t = q + 8 j][64 rk + col], q = tid / 64, col = tid % 64
-  //   (projection + prenet role: [0, 8) its two layer-2 columns, [8, 32) the wave's row of [W_p ; w_gate].  The roles are disjoint
-  //   workgroups, so one array serves both.  The query rows and the prenet's layer-1 weights live in LDS.)
-  float rreg[32];
-  static_assert(TP / NW <= 16, "the attention role's memory columns fit their share of the role registers");
+  // role registers (one array, two uses; the roles are disjoint workgroups):
+  //   attention role [0, 32): memory[t = wave + 4 j][64 rk + lane]: the steps this wave sums into the context column `lane`
+  //   projection + prenet role [0, 16): layer-2 columns 16 rk + wave + 4 r, inputs lane + 64 k (at [4 r + k]);
+  //     [16, 64): rows rk + 16 (wave + 4 r) of [W_p ; w_gate], r < 2, 24 weights per lane each
+  float rreg[64];
 #pragma unroll
-  for (int j = 0; j < 32; ++j) rreg[j] = 0.f;
+  for (int j = 0; j < 64; ++j) rreg[j] = 0.f;
   if (attn) {
 #pragma unroll 1
     for (int i = tid; i < TP * 16; i += PT) {
@@ -198,40 +272,47 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent8(DecoderBufs d, P8Buf
     if (tid < 16) s_vv[tid] = w.v_w[16 * rk + tid];
 #pragma unroll
     for (int j = 0; j < TP / NW; ++j) {
-      const int t = (tid >> 6) + NW * j;
-      rreg[j] = t < T ? d.memory[((size_t)rb * T + t) * EMB + 64 * rk + (tid & 63)] : 0.f;
+      const int t = wave + NW * j;
+      rreg[j] = t < T ? d.memory[((size_t)rb * T + t) * EMB + 64 * rk + lane] : 0.f;
     }
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         *reinterpret_cast<float4 *>(s_qw + 4 * ((4 * r + j) * PT + tid)) = w.q_w[(unsigned)((16 * rk + wave + NW * r) * (ATT_RNN / 4) + lane + 64 * j)];
   }
   if (pre) {
-    // layer 1 [in / 4][out][in % 4]: a thread's 40 weights are ten conflict-free 16-byte reads
+    // layer 1 [in / 4][out][in % 4]: a thread's 80 weights are twenty conflict-free 16-byte reads
 #pragma unroll 1
     for (int i = tid; i < N_MEL * PRENET; i += PT) s_W0[(((i / PRENET) >> 2) * PRENET + i % PRENET) * 4 + ((i / PRENET) & 3)] = w.pre0T[i];
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
       for (int k = 0; k < 4; ++k) rreg[4 * r + k] = w.pre1T[(unsigned)((lane + 64 * k) * PRENET + 16 * rk + wave + NW * r)];
-    if (prow_ok) {
 #pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        const float4 q = w.proj_w[(unsigned)(prow * (PROJ_IN / 4) + lane + 64 * j)];
-        rreg[8 + 4 * j + 0] = q.x;
-        rreg[8 + 4 * j + 1] = q.y;
-        rreg[8 + 4 * j + 2] = q.z;
-        rreg[8 + 4 * j + 3] = q.w;
+    for (int r = 0; r < 2; ++r) {
+      const int prow = rk + 16 * (wave + NW * r);
+      if (prow <= N_MEL) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const float4 q = w.proj_w[(unsigned)(prow * (PROJ_IN / 4) + lane + 64 * j)];
+          rreg[16 + 24 * r + 4 * j + 0] = q.x;
+          rreg[16 + 24 * r + 4 * j + 1] = q.y;
+          rreg[16 + 24 * r + 4 * j + 2] = q.z;
+          rreg[16 + 24 * r + 4 * j + 3] = q.w;
+        }
       }
     }
   }
   int nf_r = pre ? d.nframes[rb] : 0;
   const int nv_r = attn ? d.n_valid[rb] : 0;
   bool ctx_valid = false;
-  if (prow_ok && lane == 0) s_pb[wave] = w.proj_b[prow];  // (behind the s_W0 fill: s_pb follows it in the role area)
-  const uint32_t item = d.item_base + (uint32_t)rb;
   __syncthreads();
+  if (pre && tid < 8) {  // (behind the s_W0 fill: s_pb follows it in the role area)
+    const int prow = rk + 16 * tid;
+    s_pb[tid] = prow <= N_MEL ? w.proj_b[prow] : 0.f;
+  }
+  const uint32_t item = d.item_base + (uint32_t)rb;
 
   // location features of the NEXT step for the attention role's 16 dims (decoder_persistent.hip: a Toeplitz product on the matrix cores)
   auto location = [&]() {
@@ -241,8 +322,9 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent8(DecoderBufs d, P8Buf
       s_wpad[i] = (t >= 0 && t < T) ? (ch ? s_awc[t] : s_aw[t]) : 0.f;
     }
     __syncthreads();
-    {
-      const unsigned l = (unsigned)lane, li = l & 15u, lg = l >> 4, t0 = 16u * (unsigned)wave;
+#pragma unroll
+    for (int hh = 0; hh < TP / (16 * NW); ++hh) {
+      const unsigned l = (unsigned)lane, li = l & 15u, lg = l >> 4, t0 = 16u * (unsigned)(wave + NW * hh);
       f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
 #pragma unroll
       for (int k2 = 0; k2 < 16; k2 += 2) {
@@ -264,38 +346,38 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent8(DecoderBufs d, P8Buf
 
   // ---- resident weights: the wave's K-slice of the workgroup's 16 + 16 gate rows, as MFMA A operands -----------------------
   // row 16c + i (packed [unit][gate] order) is unit 4c + i/4, gate i%4; A lane = (row i = lane % 16, k-quad kk = lane / 16)
-  float4 ax[2], ac[4], ah[8];   // attention LSTM: x 256 | ctx 512 | h_att 1024 columns, 1/8 of each
-  float4 dh[8], dc[4], dd[8];   // decoder LSTM:   h_att 1024 | ctx 512 | h_dec 1024
+  float4 ax[4], ac[8], ah[16];   // attention LSTM: x 256 | ctx 512 | h_att 1024 columns, 1/4 of each
+  float4 dh[16], dc[8], dd[16];  // decoder LSTM:   h_att 1024 | ctx 512 | h_dec 1024
   {
     const float4 *ra = w.att_w + (size_t)(16 * c + n16) * (ATT_COLS / 4), *rd = w.dec_w + (size_t)(16 * c + n16) * (DEC_COLS / 4);
 #pragma unroll
-    for (int q = 0; q < 2; ++q) ax[q] = ld_stream(ra + (0 + 32 * wave) / 4 + 4 * q + kk);
+    for (int q = 0; q < 4; ++q) ax[q] = ld_stream(ra + (0 + 64 * wave) / 4 + 4 * q + kk);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) ac[q] = ld_stream(ra + (PRENET + 64 * wave) / 4 + 4 * q + kk);
+    for (int q = 0; q < 8; ++q) ac[q] = ld_stream(ra + (PRENET + 128 * wave) / 4 + 4 * q + kk);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) ah[q] = ld_stream(ra + (ATT_IN + 128 * wave) / 4 + 4 * q + kk);
+    for (int q = 0; q < 16; ++q) ah[q] = ld_stream(ra + (ATT_IN + 256 * wave) / 4 + 4 * q + kk);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) dh[q] = ld_stream(rd + (0 + 128 * wave) / 4 + 4 * q + kk);
+    for (int q = 0; q < 16; ++q) dh[q] = ld_stream(rd + (0 + 256 * wave) / 4 + 4 * q + kk);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) dc[q] = ld_stream(rd + (ATT_RNN + 64 * wave) / 4 + 4 * q + kk);
+    for (int q = 0; q < 8; ++q) dc[q] = ld_stream(rd + (ATT_RNN + 128 * wave) / 4 + 4 * q + kk);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) dd[q] = ld_stream(rd + (DEC_IN + 128 * wave) / 4 + 4 * q + kk);
+    for (int q = 0; q < 16; ++q) dd[q] = ld_stream(rd + (DEC_IN + 256 * wave) / 4 + 4 * q + kk);
   }
   // the partial pre-activations that do not depend on the newest vector
   f32x4 accA = (f32x4){0.f, 0.f, 0.f, 0.f}, accD = accA;
-  mfma_segment<4>(accA, ac, s_ctx, 4 * wave, kk, n);    // attention LSTM: ctx(s-1) ...
-  mfma_segment<8>(accA, ah, s_hatt, 8 * wave, kk, n);   // ... and h_att(s-1)
+  mfma_segment<NB, 8>(accA, ac, s_ctx, 8 * wave, kk, n);     // attention LSTM: ctx(s-1) ...
+  mfma_segment<NB, 16>(accA, ah, s_hatt, 16 * wave, kk, n);  // ... and h_att(s-1)
   __syncthreads();
 #pragma unroll 1
   for (int i = tid; i < DEC_RNN * NB; i += PT) {
-    const int k = i >> 3, b = i & (NB - 1);
+    const int k = i / NB, b = i & (NB - 1);
     s_hdec[bidx(k, b)] = b < B ? d.dec_h[0][b * DEC_RNN + k] : 0.f;
   }
   __syncthreads();
-  mfma_segment<8>(accD, dd, s_hdec, 8 * wave, kk, n);   // decoder LSTM: h_dec(s-1)
+  mfma_segment<NB, 16>(accD, dd, s_hdec, 16 * wave, kk, n);  // decoder LSTM: h_dec(s-1)
   __syncthreads();  // (x(s) is gathered into the buffer ctx(s-1) was read from)
 
-  // wave 0: sum of the eight K-slices of a D tile (the caller has put a barrier behind the s_acc stores)
+  // wave 0: sum of the K-slices of a D tile (the caller has put a barrier behind the s_acc stores)
   auto reduce_tile = [&]() {
     f32x4 gsum = *reinterpret_cast<const f32x4 *>(s_acc + lane * 4);
 #pragma unroll
@@ -303,6 +385,11 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent8(DecoderBufs d, P8Buf
     return gsum;
   };
 
+#ifdef XDTTS_P8_PROFILE
+  __shared__ u64 s_prof[20];
+  if (tid < 20) s_prof[tid] = 0;
+  u64 prof_last = wall_clock64();
+#endif
   int s = step0;
   const int s_stop = step0 + nsteps;
   float cown = 0.f;  // attention role, tid < 64: the chunk's context column 64 rk + tid of the last step (write-back)
@@ -311,25 +398,34 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent8(DecoderBufs d, P8Buf
     const unsigned want = (unsigned)(s + 1);
     // ---- P1: x(s) and the chunks' active bits ---------------------------------------------------------------------------------
     {
-      const int i = tid & 255, b0 = tid >> 8;  // chunks b0, b0 + 2, b0 + 4, b0 + 6
       unsigned need = 0u;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) need |= (s_alive[b0 + 2 * j] != 0 ? 1u : 0u) << j;
-      gather<4>(g.x, (unsigned)((p * NB + b0) * PRENET + i), 2u * PRENET, want, need, pc, [&](int j, float v, unsigned tg) {
-        s_x[bidx(i, b0 + 2 * j)] = v;
-        if (i == 0) s_act[b0 + 2 * j] = (tg & ACT_BIT) ? 1 : 0;
-      });
+      for (int b = 0; b < NB; ++b) need |= (s_alive[b] != 0 ? 1u : 0u) << b;
+      // quad tid + 256 i of the slab: chunk 4 i + wave, columns 4 lane .. + 3; the sign bit of a column = chunk not active
+      unsigned needx = 0u;
+#pragma unroll
+      for (int i = 0; i < (NB + 3) / 4; ++i) needx |= ((need >> (4 * i + wave)) & 1u) << i;
+      nap(g.delay[3]);
+      gather16<(NB + 3) / 4>(g.rx + (size_t)(s - step0) * NB * PRENET, needx, pc, [&](int i) { return 16u * (unsigned)(tid + PT * i); },
+                             [&](int i, u32x4 v) {
+                               const int b = 4 * i + wave;
+                               if (lane == 0) s_act[b] = (v.x >> 31) ? 0 : 1;
+                               v &= 0x7fffffffu;
+                               *reinterpret_cast<float4 *>(s_x + bidx(4 * lane, b)) = as_f4(v);
+                             });
       if (tid == PT - 1) s_err = __hip_atomic_load(g.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    P8_MARK(0);
     __syncthreads();
+    P8_MARK(1);
     unsigned actm = 0u;
 #pragma unroll
     for (int b = 0; b < NB; ++b) actm |= (s_act[b] != 0 ? 1u : 0u) << b;
     if (!actm || s_err != 0) break;  // every chunk has stopped (or an exchange failed): the launch ends by itself
     const bool act_r = (actm >> rb) & 1u;
-    const bool act_n = (actm >> n16) & 1u;  // (lanes n16 >= 8: false)
+    const bool act_n = (actm >> n16) & 1u;  // (lanes n16 >= NB: false)
     // attention LSTM: close the rows with the x columns
-    mfma_segment<2>(accA, ax, s_x, 2 * wave, kk, n);
+    mfma_segment<NB, 4>(accA, ax, s_x, 4 * wave, kk, n);
     *reinterpret_cast<f32x4 *>(s_acc + (wave * 64 + lane) * 4) = accA;
     __syncthreads();
     if (tid < NB) s_alive[tid] = s_act[tid];  // (read again only at the next P1, behind this step's barriers)
@@ -340,69 +436,87 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent8(DecoderBufs d, P8Buf
                     og = fast_sigmoid(gs[3] + bias_a.w);
         c_att = fmaf(fg, c_att, ig * gg);
         h_att_last = og * fast_tanh(c_att);
-        publish(g.hatt + (unsigned)((p * NB + n16) * ATT_RNN + 4 * c + cu), want, h_att_last);
+        put(g.rhatt + ((size_t)(s - step0) * NB + n16) * ATT_RNN + 4 * c + cu, value_bits(h_att_last));
       }
     }
     accA = (f32x4){0.f, 0.f, 0.f, 0.f};
+    P8_MARK(2);
     // ---- P2: h_att(s) of every active chunk ------------------------------------------------------------------------------------
-    // attention role: what the energies need besides the query is in registers before h_att arrives
-    // (and its two query rows, 8 kB per wave from L2, are requested ahead of the gather they follow)
-    float4 lp4 = make_float4(0.f, 0.f, 0.f, 0.f), v4 = lp4;
+    // attention role: what the energies need besides the query is in registers before h_att arrives; thread = (encoder steps
+    // t = tid / 4 and t + 64, dims 4 (tid % 4) .. + 3 of the workgroup's 16)
+    float4 lp0 = make_float4(0.f, 0.f, 0.f, 0.f), lp1 = lp0, v4 = lp0;
     if (attn && act_r) {
-      const float4 l4 = lds4(s_loc + 4 * tid), p4 = lds4(s_pm + 4 * tid);
-      lp4 = make_float4(l4.x + p4.x, l4.y + p4.y, l4.z + p4.z, l4.w + p4.w);
+      const float4 l0 = lds4(s_loc + 4 * tid), p0 = lds4(s_pm + 4 * tid), l1 = lds4(s_loc + 4 * (tid + PT)), p1 = lds4(s_pm + 4 * (tid + PT));
+      lp0 = make_float4(l0.x + p0.x, l0.y + p0.y, l0.z + p0.z, l0.w + p0.w);
+      lp1 = make_float4(l1.x + p1.x, l1.y + p1.y, l1.z + p1.z, l1.w + p1.w);
       v4 = lds4(s_vv + 4 * (tid & 3));
     }
-    // granule tid + 512 i: i = 2 b + half of the vector
-    unsigned need2 = 0u;
-#pragma unroll
-    for (int i = 0; i < 2 * NB; ++i) need2 |= ((actm >> (i >> 1)) & 1u) << i;
-    gather<2 * NB>(g.hatt, (unsigned)(p * NB * ATT_RNN + tid), PT, want, need2, pc, [&](int i, float v, unsigned) {
-      const int k = tid + PT * (i & 1), b = i >> 1;
-      s_hatt[bidx(k, b)] = v;
-      if (attn && b == rb) s_hrow[k] = v;
-    });
+    // quad tid of chunk i's slab row: units 4 tid .. + 3 (workgroup tid's)
+    nap(g.delay[0]);
+    const unsigned fr0 = gather16<NB>(g.rhatt + (size_t)(s - step0) * NB * ATT_RNN, actm, pc, [&](int i) { return 16u * (unsigned)(tid + PT * i); },
+                                      [&](int i, u32x4 v) {
+                                        *reinterpret_cast<float4 *>(s_hatt + bidx(4 * tid, i)) = as_f4(v);
+                                        if (attn && i == rb) *reinterpret_cast<float4 *>(s_hrow + 4 * tid) = as_f4(v);
+                                      });
+    P8_MARK(3);
     __syncthreads();
+    P8_MARK(4);
     if (attn && act_r) {
-      // query rows 16 rk + wave (+8) (re-read from L2: 8 kB per wave and step), then this workgroup's share of the energies
-      float q0 = 0.f, q1 = 0.f;
+      // query rows 16 rk + wave + 4 r, then this workgroup's share of the energies
+      float qv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) qv[r] = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float4 hv = lds4(s_hrow + 256 * j + 4 * lane);
-        q0 = dot4(lds4(s_qw + 4 * (j * PT + tid)), hv, q0);
-        q1 = dot4(lds4(s_qw + 4 * ((4 + j) * PT + tid)), hv, q1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) qv[r] = dot4(lds4(s_qw + 4 * ((4 * r + j) * PT + tid)), hv, qv[r]);
       }
-      q0 = wave_sum(q0);
-      q1 = wave_sum(q1);
-      if (lane == 0) {
-        s_q[wave] = q0;
-        s_q[wave + NW] = q1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        qv[r] = wave_sum(qv[r]);
+        if (lane == 0) s_q[wave + NW * r] = qv[r];
       }
       __syncthreads();
       const int t = tid >> 2, dq = 4 * (tid & 3);
       const float4 q4 = lds4(s_q + dq);
-      float e = v4.x * fast_tanh(q4.x + lp4.x);
-      e = fmaf(v4.y, fast_tanh(q4.y + lp4.y), e);
-      e = fmaf(v4.z, fast_tanh(q4.z + lp4.z), e);
-      e = fmaf(v4.w, fast_tanh(q4.w + lp4.w), e);
-      e += dpp_move<0xB1, 0xf>(0.f, e);  // quad_perm:[1,0,3,2]
-      e += dpp_move<0x4E, 0xf>(0.f, e);  // quad_perm:[2,3,0,1]
-      if ((tid & 3) == 0 && t < T) publish(g.ep + (unsigned)(((p * NB + rb) * ATTN_CU + rk) * EP_LD + t), want, e);
+      float e0 = v4.x * fast_tanh(q4.x + lp0.x), e1 = v4.x * fast_tanh(q4.x + lp1.x);
+      e0 = fmaf(v4.y, fast_tanh(q4.y + lp0.y), e0);
+      e1 = fmaf(v4.y, fast_tanh(q4.y + lp1.y), e1);
+      e0 = fmaf(v4.z, fast_tanh(q4.z + lp0.z), e0);
+      e1 = fmaf(v4.z, fast_tanh(q4.z + lp1.z), e1);
+      e0 = fmaf(v4.w, fast_tanh(q4.w + lp0.w), e0);
+      e1 = fmaf(v4.w, fast_tanh(q4.w + lp1.w), e1);
+      e0 += dpp_move<0xB1, 0xf>(0.f, e0);  // quad_perm:[1,0,3,2]
+      e1 += dpp_move<0xB1, 0xf>(0.f, e1);
+      e0 += dpp_move<0x4E, 0xf>(0.f, e0);  // quad_perm:[2,3,0,1]
+      e1 += dpp_move<0x4E, 0xf>(0.f, e1);
+      if ((tid & 3) == 0) {
+        u64 *row = g.ep + (unsigned)(((p * NB + rb) * ATTN_CU + rk) * EP_LD);
+        if (t < T) publish(row + t, want, e0);
+        if (t + 64 < T) publish(row + t + 64, want, e1);
+      }
     }
-    // both LSTMs: the h_att(s) columns (decoder LSTM of this step, attention LSTM of the next)
-    mfma_segment<8>(accD, dh, s_hatt, 8 * wave, kk, n);
-    mfma_segment<8>(accA, ah, s_hatt, 8 * wave, kk, n);
+    P8_MARK(5);
+    // decoder LSTM of this step: the h_att(s) columns (in the time the partial energies travel)
+    mfma_segment<NB, 16>(accD, dh, s_hatt, 16 * wave, kk, n);
+    P8_MARK(6);
     // ---- P3 (attention role): the 8 partial-energy rows of the chunk -> softmax -> this workgroup's 64 context columns ------------
     if (attn && act_r) {
       {
-        const int t = tid >> 2, j = tid & 3;
-        float ev[2] = {0.f, 0.f};
-        gather<2>(g.ep, (unsigned)(((p * NB + rb) * ATTN_CU + j) * EP_LD + t), 4u * EP_LD, want, t < T ? 3u : 0u, pc,
-                  [&](int i, float v, unsigned) { ev[i] = v; });
-        float e = ev[0] + ev[1];
-        e += dpp_move<0xB1, 0xf>(0.f, e);
-        e += dpp_move<0x4E, 0xf>(0.f, e);
-        if (j == 0) s_e[t] = (t < T && t < nv_r) ? e : -INFINITY;  // mask, mod.rs:219-220
+        const int t = tid >> 2, j = tid & 3;  // loads i: row j + 4 (i % 2), encoder step t + 64 (i / 2)
+        float ev[4] = {0.f, 0.f, 0.f, 0.f};
+        gather<4>(g.ep + (unsigned)(((p * NB + rb) * ATTN_CU + j) * EP_LD + t), want, (t < T ? 3u : 0u) | (t + 64 < T ? 12u : 0u), pc,
+                  [](int i) { return (unsigned)((i & 1) * 4 * EP_LD + (i >> 1) * 64); }, [&](int i, float v, unsigned) { ev[i] = v; });
+        float e0 = ev[0] + ev[1], e1 = ev[2] + ev[3];
+        e0 += dpp_move<0xB1, 0xf>(0.f, e0);
+        e1 += dpp_move<0xB1, 0xf>(0.f, e1);
+        e0 += dpp_move<0x4E, 0xf>(0.f, e0);
+        e1 += dpp_move<0x4E, 0xf>(0.f, e1);
+        if (j == 0) {  // mask, mod.rs:219-220
+          s_e[t] = (t < T && t < nv_r) ? e0 : -INFINITY;
+          s_e[t + 64] = (t + 64 < T && t + 64 < nv_r) ? e1 : -INFINITY;
+        }
       }
       __syncthreads();
       {  // every wave: the softmax in registers, lane <-> steps lane, lane + 64
@@ -411,12 +525,12 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent8(DecoderBufs d, P8Buf
         const float x0 = fast_exp(e0 - m), x1 = fast_exp(e1 - m);
         const float rs = __builtin_amdgcn_rcpf(wave_sum(x0 + x1));
         const float w0 = x0 * rs, w1 = x1 * rs;
-        // context columns: this wave sums the steps t = wave + 8 j; lane = column.  The weight of step t sits in lane t % 64
+        // context columns: this wave sums the steps t = wave + 4 j; lane = column.  The weight of step t sits in lane t % 64
         float acc = 0.f;
 #pragma unroll
         for (int j = 0; j < TP / NW; ++j) {
           const int t = wave + NW * j;
-          const float wt = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t < 64 ? w0 : w1), t & 63));
+          const float wt = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(j < 64 / NW ? w0 : w1), t & 63));
           acc = fmaf(wt, rreg[j], acc);
         }
         s_part[tid] = acc;
@@ -434,16 +548,27 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent8(DecoderBufs d, P8Buf
         for (int u = 0; u < NW; ++u) v += s_part[u * 64 + tid];
         cown = v;
         ctx_valid = true;
-        publish(g.ctx + (unsigned)((p * NB + rb) * EMB + 64 * rk + tid), want, v);
+        put(g.rctx + ((size_t)(s - step0) * NB + rb) * EMB + 64 * rk + tid, value_bits(v));
       }
     }
+    mfma_segment<NB, 16>(accA, ah, s_hatt, 16 * wave, kk, n);  // attention LSTM of the next step: h_att(s) (while ctx travels)
+    P8_MARK(7);
     // ---- P4: ctx(s) of every active chunk -> decoder LSTM ------------------------------------------------------------------------
-    gather<NB>(g.ctx, (unsigned)(p * NB * EMB + tid), EMB, want, actm, pc, [&](int i, float v, unsigned) {
-      s_ctx[bidx(tid, i)] = v;
-      if (pre && i == rb) s_crow[tid] = v;
-    });
+    // quad tid + 256 i of the slab: chunk 2 i + tid / 128, columns 4 (tid % 128) .. + 3
+    unsigned needc = 0u;
+#pragma unroll
+    for (int i = 0; i < NB / 2; ++i) needc |= ((actm >> (2 * i + (wave >> 1))) & 1u) << i;
+    nap(g.delay[1]);
+    const unsigned fr1 = gather16<NB / 2>(g.rctx + (size_t)(s - step0) * NB * EMB, needc, pc, [&](int i) { return 16u * (unsigned)(tid + PT * i); },
+                                          [&](int i, u32x4 v) {
+                                            const int b = 2 * i + (wave >> 1), k = 4 * (tid & 127);
+                                            *reinterpret_cast<float4 *>(s_ctx + bidx(k, b)) = as_f4(v);
+                                            if (pre && b == rb) *reinterpret_cast<float4 *>(s_crow + k) = as_f4(v);
+                                          });
+    P8_MARK(8);
     __syncthreads();
-    mfma_segment<4>(accD, dc, s_ctx, 4 * wave, kk, n);
+    P8_MARK(9);
+    mfma_segment<NB, 8>(accD, dc, s_ctx, 8 * wave, kk, n);
     *reinterpret_cast<f32x4 *>(s_acc + (wave * 64 + lane) * 4) = accD;
     __syncthreads();
     if (wave == 0) {
@@ -453,49 +578,61 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent8(DecoderBufs d, P8Buf
                     og = fast_sigmoid(gs[3] + bias_d.w);
         c_dec = fmaf(fg, c_dec, ig * gg);
         h_dec_last = og * fast_tanh(c_dec);
-        publish(g.hdec + (unsigned)((p * NB + n16) * DEC_RNN + 4 * c + cu), want, h_dec_last);
+        put(g.rhdec + ((size_t)(s - step0) * NB + n16) * DEC_RNN + 4 * c + cu, value_bits(h_dec_last));
       }
     }
     accD = (f32x4){0.f, 0.f, 0.f, 0.f};
-    mfma_segment<4>(accA, ac, s_ctx, 4 * wave, kk, n);  // attention LSTM of the next step: ctx(s)
-    if (attn && act_r) location();                       // ... and its location features
+    P8_MARK(10);
+    mfma_segment<NB, 8>(accA, ac, s_ctx, 8 * wave, kk, n);  // attention LSTM of the next step: ctx(s)
+    if (attn && act_r) location();                           // ... and its location features
+    P8_MARK(11);
     // ---- P5: h_dec(s) -> projection rows ---------------------------------------------------------------------------------------
-    // projection + prenet role: its row of [W_p ; w_gate] is requested ahead of the gather, the Bernoulli(0.5) masks of step
-    // s + 1 (they do not depend on the data) are hashed in the time the first poll of h_dec could not succeed anyway
-    unsigned drop1 = 0u, drop2 = 0u;
+    // projection + prenet role: the Bernoulli(0.5) masks of step s + 1 (they do not depend on the data) are hashed in the time
+    // the first poll of h_dec could not succeed anyway
+    bool drop1 = false;
+    unsigned drop2 = 0u;
+    if (pre && act_r && d.dropout_mode) {
+      drop1 = prenet_dropped(d.dropout_mode, d.dropout_seed, item, d.drop_masks, d.drop_steps, rb, s + 1, 0, tid);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        drop2 |= (prenet_dropped(d.dropout_mode, d.dropout_seed, item, d.drop_masks, d.drop_steps, rb, s + 1, 1, 16 * rk + wave + NW * r) ? 1u : 0u) << r;
+    }
+    nap(g.delay[2]);
+    const unsigned fr2 = gather16<NB>(g.rhdec + (size_t)(s - step0) * NB * DEC_RNN, actm, pc, [&](int i) { return 16u * (unsigned)(tid + PT * i); },
+                                      [&](int i, u32x4 v) {
+                                        *reinterpret_cast<float4 *>(s_hdec + bidx(4 * tid, i)) = as_f4(v);
+                                        if (pre && i == rb) *reinterpret_cast<float4 *>(s_hrow + 4 * tid) = as_f4(v);
+                                      });
+    P8_MARK(12);
+    __syncthreads();
+    P8_MARK(13);
     if (pre && act_r) {
-      if (d.dropout_mode) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-          drop1 |= (prenet_dropped(d.dropout_mode, d.dropout_seed, item, d.drop_masks, d.drop_steps, rb, s + 1, 0, lane + 64 * k) ? 1u : 0u) << k;
+      for (int r = 0; r < 2; ++r) {
+        const int prow = rk + 16 * (wave + NW * r);
+        if (prow <= N_MEL) {
+          float a = 0.f;
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
-          drop2 |= (prenet_dropped(d.dropout_mode, d.dropout_seed, item, d.drop_masks, d.drop_steps, rb, s + 1, 1, 16 * rk + wave + NW * r) ? 1u : 0u) << r;
+          for (int j = 0; j < 4; ++j)
+            a = dot4(make_float4(rreg[16 + 24 * r + 4 * j], rreg[17 + 24 * r + 4 * j], rreg[18 + 24 * r + 4 * j], rreg[19 + 24 * r + 4 * j]),
+                     lds4(s_hrow + 256 * j + 4 * lane), a);
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            a = dot4(make_float4(rreg[32 + 24 * r + 4 * j], rreg[33 + 24 * r + 4 * j], rreg[34 + 24 * r + 4 * j], rreg[35 + 24 * r + 4 * j]),
+                     lds4(s_crow + 256 * j + 4 * lane), a);
+          a = wave_sum(a);
+          if (lane == 0) publish(g.mel + (unsigned)((p * NB + rb) * MEL_GL + prow), want, a + s_pb[wave + NW * r]);
+        }
       }
     }
-    gather<2 * NB>(g.hdec, (unsigned)(p * NB * DEC_RNN + tid), PT, want, need2, pc, [&](int i, float v, unsigned) {
-      const int k = tid + PT * (i & 1), b = i >> 1;
-      s_hdec[bidx(k, b)] = v;
-      if (pre && b == rb) s_hrow[k] = v;
-    });
-    __syncthreads();
-    if (prow_ok && act_r) {
-      float a = 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        a = dot4(make_float4(rreg[8 + 4 * j], rreg[9 + 4 * j], rreg[10 + 4 * j], rreg[11 + 4 * j]), lds4(s_hrow + 256 * j + 4 * lane), a);
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        a = dot4(make_float4(rreg[24 + 4 * j], rreg[25 + 4 * j], rreg[26 + 4 * j], rreg[27 + 4 * j]), lds4(s_crow + 256 * j + 4 * lane), a);
-      a = wave_sum(a);
-      if (lane == 0) publish(g.mel + (unsigned)((p * NB + rb) * MEL_GL + prow), want, a + s_pb[wave]);
-    }
-    mfma_segment<8>(accD, dd, s_hdec, 8 * wave, kk, n);  // decoder LSTM of the next step: h_dec(s)
+    P8_MARK(14);
+    mfma_segment<NB, 16>(accD, dd, s_hdec, 16 * wave, kk, n);  // decoder LSTM of the next step: h_dec(s)
+    P8_MARK(15);
     // ---- P6 (projection + prenet role): frame s, stop rule, x(s+1) ---------------------------------------------------------------
     if (pre && act_r) {  // a chunk's last x (active bit clear) is published at the step it stops
       if (tid < N_MEL + 1) {
         s_mel[tid] = 0.f;
-        gather<1>(g.mel, (unsigned)((p * NB + rb) * MEL_GL + tid), 0, want, 1u, pc, [&](int, float v, unsigned) { s_mel[tid] = v; });
+        gather<1>(g.mel + (unsigned)((p * NB + rb) * MEL_GL + tid), want, 1u, pc, [](int) { return 0u; }, [&](int, float v, unsigned) { s_mel[tid] = v; });
       }
       __syncthreads();
       const float gate = s_mel[N_MEL];
@@ -509,28 +646,26 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent8(DecoderBufs d, P8Buf
       }
       if (fired) nf_r = s + 1;
       const bool nxt = s + 1 < nf_r;
-      float xo[2] = {0.f, 0.f};
+      float xo[4] = {0.f, 0.f, 0.f, 0.f};
       if (nxt) {
-        const unsigned HM = (unsigned)((tid >> 8) * (N_MEL / 2));
-        float acc = 0.f;
+        float acc = 0.f;  // layer 1, output tid
 #pragma unroll
-        for (int k = 0; k < N_MEL / 2; k += 4) {
-          const float4 w4 = lds4(s_W0 + 4u * (((HM + k) >> 2) * PRENET + ((unsigned)tid & 255u))), m = lds4(s_mel + HM + k);
+        for (int k = 0; k < N_MEL; k += 4) {
+          const float4 w4 = lds4(s_W0 + 4u * ((unsigned)(k >> 2) * PRENET + (unsigned)tid)), m = lds4(s_mel + k);
           acc = fmaf(w4.x, m.x, acc);
           acc = fmaf(w4.y, m.y, acc);
           acc = fmaf(w4.z, m.z, acc);
           acc = fmaf(w4.w, m.w, acc);
         }
-        s_l1[tid] = acc;
+        acc = fmaxf(acc, 0.f);
+        __syncthreads();  // (s_mel read by everyone before s_hrow, free since the projection, takes the layer-1 outputs)
+        s_hrow[tid] = drop1 ? 0.f : (d.dropout_mode ? 2.f * acc : acc);
         __syncthreads();
         float pk[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float v = fmaxf(s_l1[lane + 64 * k] + s_l1[PRENET + lane + 64 * k], 0.f);
-          pk[k] = (drop1 >> k) & 1u ? 0.f : (d.dropout_mode ? 2.f * v : v);
-        }
+        for (int k = 0; k < 4; ++k) pk[k] = s_hrow[lane + 64 * k];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < 4; ++r) {
           float a = 0.f;
 #pragma unroll
           for (int k = 0; k < 4; ++k) a = fmaf(rreg[4 * r + k], pk[k], a);
@@ -539,11 +674,21 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent8(DecoderBufs d, P8Buf
         }
       }
       // the workgroup's 16 columns leave as ONE 128-byte store (decoder_persistent.hip)
-      if (lane < 2) s_mel[MEL_GL - 16 + wave + NW * lane] = lane ? xo[1] : xo[0];  // s_mel[81..95] is unused padding
+      if (lane < 4) s_mel[MEL_GL - 16 + wave + NW * lane] = lane == 0 ? xo[0] : (lane == 1 ? xo[1] : (lane == 2 ? xo[2] : xo[3]));  // s_mel[81..95] is unused padding
       __syncthreads();
       if (tid < 16)
-        publish(g.x + (unsigned)(((p ^ 1) * NB + rb) * PRENET + 16 * rk + tid), (want + 1u) | (nxt ? ACT_BIT : 0u), s_mel[MEL_GL - 16 + tid]);
+        put(g.rx + ((size_t)(s + 1 - step0) * NB + rb) * PRENET + 16 * rk + tid, value_bits(s_mel[MEL_GL - 16 + tid]) | (nxt ? 0u : 0x80000000u));
     }
+    P8_MARK(16);
+#ifdef XDTTS_P8_PROFILE
+    if (tid == 0) {
+      s_prof[17] += fr0;
+      s_prof[18] += fr1;
+      s_prof[19] += fr2;
+    }
+#else
+    (void)fr0, (void)fr1, (void)fr2;
+#endif
   }
 
   // ---- write the state back (a later launch, or the parity hook, may continue the sequence) ----------------------------------------
@@ -561,60 +706,85 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent8(DecoderBufs d, P8Buf
     }
   }
   if (c == 0 && tid == 0) d.ctl[0] = s;
+#ifdef XDTTS_P8_PROFILE
+  __syncthreads();
+  if (tid == 0 && (c == 0 || c == ATTN_CU * B || c == P_NCU - 1) && s > step0) {
+    const float k_ = 0.01f / (float)(s - step0);
+    printf("P8PROF wg %3d steps %d:  x %.2f|%.2f  attcell %.2f  hatt %.2f|%.2f  energies %.2f  mfma2 %.2f  softmax %.2f  ctx %.2f|%.2f  deccell %.2f  ac+loc %.2f  hdec %.2f|%.2f  proj %.2f  mfma-dd %.2f  prenet %.2f | failed rounds h_att %.2f ctx %.2f h_dec %.2f\n",
+           c, s - step0, k_ * s_prof[0], k_ * s_prof[1], k_ * s_prof[2], k_ * s_prof[3], k_ * s_prof[4], k_ * s_prof[5], k_ * s_prof[6], k_ * s_prof[7], k_ * s_prof[8], k_ * s_prof[9], k_ * s_prof[10],
+           k_ * s_prof[11], k_ * s_prof[12], k_ * s_prof[13], k_ * s_prof[14], k_ * s_prof[15], k_ * s_prof[16], 100.f * k_ * s_prof[17], 100.f * k_ * s_prof[18], 100.f * k_ * s_prof[19]);
+  }
+#endif
 }
 
-// x(0) = prenet(0) = 0 (the prenet has no bias, mod.rs:208) with the chunks' initial active bits
-__global__ void k_p8_seed(P8Bufs g, const int *limits) {
+// x(0) = prenet(0) = 0 (the prenet has no bias, mod.rs:208) with the chunks' initial active bits (behind the fill of the rings)
+__global__ void k_p8_seed(P8Bufs g, const int *limits, int nb) {
   const int b = blockIdx.x, i = threadIdx.x;
-  publish(g.x + (size_t)b * PRENET + i, 1u | (limits[b] > 0 ? ACT_BIT : 0u), 0.f);
+  put(g.rx + (size_t)b * PRENET + i, limits[b] > 0 ? 0u : 0x80000000u);
+  (void)nb;
 }
 // parity hook: a sequence that starts at `step` with the prenet output x [B][256] already computed (d.x)
-__global__ void k_p8_seed_at(P8Bufs g, const int *limits, const float *x, int step) {
+__global__ void k_p8_seed_at(P8Bufs g, const int *limits, const float *x, int step, int nb) {
   const int b = blockIdx.x, i = threadIdx.x;
-  publish(g.x + ((size_t)(step & 1) * NB + b) * PRENET + i, (unsigned)(step + 1) | (limits[b] > step ? ACT_BIT : 0u), x[b * PRENET + i]);
+  put(g.rx + (size_t)b * PRENET + i, value_bits(fabsf(x[b * PRENET + i])) | (limits[b] > step ? 0u : 0x80000000u));
+  (void)nb;
 }
 
 }  // namespace
 
-size_t p8_granule_words() { return (size_t)2 * NB * (PRENET + ATT_RNN + ATTN_CU * EP_LD + EMB + DEC_RNN + MEL_GL); }
+// Exchange memory of a launch of `nsteps` steps of B chunks, in 8-byte words: the two granule edges (two step parities) and the
+// four write-once rings (one slab per step; x one more, for the step after the last)
+static size_t ring_values(int B, int nsteps) { return (size_t)p8_slots(B) * ((size_t)(nsteps + 1) * PRENET + (size_t)nsteps * (ATT_RNN + EMB + DEC_RNN)); }
+size_t p8_exchange_words(int B, int nsteps) { return (size_t)2 * NBMAX * (ATTN_CU * EP_LD + MEL_GL) + (ring_values(B, nsteps) + 1) / 2; }
 
-P8Bufs p8_bufs(unsigned long long *base, int *err) {
+P8Bufs p8_bufs(unsigned long long *base, int *err, int B, int nsteps) {
   P8Bufs g{};
-  g.x = base;
-  g.hatt = g.x + (size_t)2 * NB * PRENET;
-  g.ep = g.hatt + (size_t)2 * NB * ATT_RNN;
-  g.ctx = g.ep + (size_t)2 * NB * ATTN_CU * EP_LD;
-  g.hdec = g.ctx + (size_t)2 * NB * EMB;
-  g.mel = g.hdec + (size_t)2 * NB * DEC_RNN;
+  const size_t nb = (size_t)p8_slots(B);
+  g.ep = base;
+  g.mel = g.ep + (size_t)2 * NBMAX * ATTN_CU * EP_LD;
+  g.rx = reinterpret_cast<unsigned *>(g.mel + (size_t)2 * NBMAX * MEL_GL);
+  g.rhatt = g.rx + nb * (size_t)(nsteps + 1) * PRENET;
+  g.rctx = g.rhatt + nb * (size_t)nsteps * ATT_RNN;
+  g.rhdec = g.rctx + nb * (size_t)nsteps * EMB;
+  g.ring_steps = nsteps;
   g.err = err;
+  g.delay[0] = g.delay[2] = 16;
+  if (const char *e = getenv("XDTTS_P8_DELAY")) sscanf(e, "%d,%d,%d,%d", &g.delay[0], &g.delay[1], &g.delay[2], &g.delay[3]);  // developer sweep
   return g;
+}
+
+static void fill_exchange(const DecoderBufs &d, const P8Bufs &g, hipStream_t s) {
+  HIP_CHECK(hipMemsetAsync(g.ep, 0, (size_t)2 * NBMAX * (ATTN_CU * EP_LD + MEL_GL) * sizeof(unsigned long long), s));
+  HIP_CHECK(hipMemsetAsync(g.rx, 0xff, ring_values(d.B, g.ring_steps) * sizeof(unsigned), s));
 }
 
 // The grid must be co-resident: one workgroup per CU on a 256-CU part, nothing else of ours running.
 bool decoder_p8_supported(int device, int B, int T) {
-  if (B < 1 || B > NB || T > TP) return false;
+  if (B < 1 || B > NBMAX || T > TP) return false;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) return false;
   if (prop.multiProcessorCount < P_NCU) return false;
   int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_decoder_persistent8, PT, 0) != hipSuccess) return false;
+  const void *fn = p8_slots(B) == 4 ? reinterpret_cast<const void *>(k_decoder_persistent8<4>) : reinterpret_cast<const void *>(k_decoder_persistent8<NBMAX>);
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, PT, 0) != hipSuccess) return false;
   return per_cu >= 1;
 }
 
 void launch_p8_seed(const DecoderBufs &d, const P8Bufs &g, const int *limits_dev, hipStream_t s) {
-  HIP_CHECK(hipMemsetAsync(g.x, 0, p8_granule_words() * sizeof(unsigned long long), s));
-  hipLaunchKernelGGL(k_p8_seed, dim3(d.B), dim3(PRENET), 0, s, g, limits_dev);
+  fill_exchange(d, g, s);
+  hipLaunchKernelGGL(k_p8_seed, dim3(d.B), dim3(PRENET), 0, s, g, limits_dev, p8_slots(d.B));
   HIP_CHECK(hipGetLastError());
 }
 
 void launch_p8_seed_at(const DecoderBufs &d, const P8Bufs &g, const int *limits_dev, int step, hipStream_t s) {
-  HIP_CHECK(hipMemsetAsync(g.x, 0, p8_granule_words() * sizeof(unsigned long long), s));
-  hipLaunchKernelGGL(k_p8_seed_at, dim3(d.B), dim3(PRENET), 0, s, g, limits_dev, d.x, step);
+  fill_exchange(d, g, s);
+  hipLaunchKernelGGL(k_p8_seed_at, dim3(d.B), dim3(PRENET), 0, s, g, limits_dev, d.x, step, p8_slots(d.B));
   HIP_CHECK(hipGetLastError());
 }
 
 void launch_decoder_p8(const DecoderBufs &d, const DeviceWeights &w, const P8Bufs &g, int nsteps, hipStream_t s) {
-  if (d.B < 1 || d.B > NB || d.T > TP) fail(XDTTS_ERR_BAD_ARG, "persistent MFMA decoder: %d chunks of %d encoder steps (max %d, %d)", d.B, d.T, NB, TP);
+  if (d.B < 1 || d.B > NBMAX || d.T > TP) fail(XDTTS_ERR_BAD_ARG, "persistent MFMA decoder: %d chunks of %d encoder steps (max %d, %d)", d.B, d.T, NBMAX, TP);
+  if (nsteps > g.ring_steps) fail(XDTTS_ERR_BAD_ARG, "persistent MFMA decoder: %d steps on an exchange laid out for %d", nsteps, g.ring_steps);
   P8Weights pw{};
   pw.att_w = reinterpret_cast<const float4 *>(w.att_w.p);
   pw.dec_w = reinterpret_cast<const float4 *>(w.dec_w.p);
@@ -627,7 +797,8 @@ void launch_decoder_p8(const DecoderBufs &d, const DeviceWeights &w, const P8Buf
   pw.proj_b = w.proj_b.p;
   pw.pre0T = w.pre0T.p;
   pw.pre1T = w.pre1T.p;
-  COOP_CHECK(launch_coresident(true, reinterpret_cast<const void *>(k_decoder_persistent8), dim3(P_NCU), dim3(PT), 0, s, d, g, pw, nsteps));
+  const void *fn = p8_slots(d.B) == 4 ? reinterpret_cast<const void *>(k_decoder_persistent8<4>) : reinterpret_cast<const void *>(k_decoder_persistent8<NBMAX>);
+  COOP_CHECK(launch_coresident(true, fn, dim3(P_NCU), dim3(PT), 0, s, d, g, pw, nsteps));
 }
 
 }  // namespace xdtts

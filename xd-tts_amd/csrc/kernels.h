@@ -143,12 +143,15 @@ void launch_decoder_persistent(const DecoderBufs &d, const DeviceWeights &w, con
 // stream per wave, the context as a sixth exchange ------------------------------------------------------------------------
 constexpr int P8_B_MAX = 8;
 struct P8Bufs {
-  unsigned long long *x, *hatt, *ep, *ctx, *hdec, *mel;  // granules, [2 step parities][P8_B_MAX][n] each
+  unsigned *rx, *rhatt, *rctx, *rhdec;  // write-once rings of plain values [step][chunk slots][n], 0xFFFFFFFF = not yet written
+  unsigned long long *ep, *mel;         // {tag, value} granules, [2 step parities][P8_B_MAX][n] each
   int *err;          // set by a workgroup whose bounded spin ran out
   int spins, fault;  // test hooks: poll limit (0 = default) and a workgroup (index + 1) that never runs
+  int delay[4];      // naps (64 clocks each) before the first poll of h_att / ctx / h_dec / x
+  int ring_steps;    // steps the rings are laid out for
 };
-size_t p8_granule_words();
-P8Bufs p8_bufs(unsigned long long *base, int *err);
+size_t p8_exchange_words(int B, int nsteps);
+P8Bufs p8_bufs(unsigned long long *base, int *err, int B, int nsteps);
 bool decoder_p8_supported(int device, int B, int T);
 void launch_p8_seed(const DecoderBufs &d, const P8Bufs &g, const int *limits_dev, hipStream_t s);
 void launch_p8_seed_at(const DecoderBufs &d, const P8Bufs &g, const int *limits_dev, int step, hipStream_t s);
