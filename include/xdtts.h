@@ -192,6 +192,11 @@ xdtts_status xdtts_tacotron2_decoder_steps(xdtts_tacotron2 *h, int32_t engine, i
 xdtts_status xdtts_tacotron2_engine_state(const xdtts_tacotron2 *h, int32_t *decoder_persistent,
                                           int32_t *encoder_cooperative, int32_t *batched_attention);
 xdtts_status xdtts_tacotron2_engine_reset(xdtts_tacotron2 *h);
+/* The engine of lock-step batches of 3..8 chunks (one persistent launch for the whole loop, the LSTMs of all chunks on the matrix
+ * cores: csrc/decoder_persistent8.hip): 1 = in use, 0 = off (the device cannot host its 256-workgroup grid, an exchange timed
+ * out -- such batches then run on the engines either side: pairs of the persistent decoder up to 4 chunks, the batched engine
+ * from 5 -- or XDTTS_P8=0 in the environment), -1 = not probed yet.  _engine_reset puts it back to -1 unless a launch was refused. */
+xdtts_status xdtts_tacotron2_small_batch_engine_state(const xdtts_tacotron2 *h, int32_t *state);
 
 /* Identity of this build: "src_sha256=<sha256 over the library's sources in name order> arch=gfx950 built_utc=... compiler=...".
  * The .so files are not in the git history (built by `make -C xd-tts_amd`, __graft_entry__.build()); the hash lets a test tell

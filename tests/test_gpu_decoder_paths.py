@@ -99,12 +99,14 @@ def test_context_fold_table_agrees_with_the_in_kernel_fold(pkg, orc, blob):
     ids = [synth_ids(n, seed=31 + i) for i, n in enumerate(lens)]
     out = {}
     for table in (True, False):
+        os.environ["XDTTS_P8"] = "0"  # (this test is about the pair launches of the persistent engine)
         if not table:
             os.environ["XDTTS_NO_CTXFOLD"] = "1"
         try:
             m = pkg.Tacotron2.from_blob(blob)
         finally:
             os.environ.pop("XDTTS_NO_CTXFOLD", None)
+            os.environ.pop("XDTTS_P8", None)
         out[table] = m.infer_batch(ids, opts=pkg.default_opts(dropout_seed=19), fixed_steps=steps)
         assert m.engine_state()["decoder_persistent"] == 1
         m.close()
@@ -136,12 +138,14 @@ def test_skewed_pair_loop_is_bit_identical_to_the_lock_step_loop(pkg, orc, blob)
     for wblob, ids, kw in cases:
         out = {}
         for skew in (True, False):
+            os.environ["XDTTS_P8"] = "0"  # (four chunks: two pair launches, not the 3..8-chunk engine)
             if not skew:
                 os.environ["XDTTS_NO_SKEW"] = "1"
             try:
                 m = pkg.Tacotron2.from_blob(wblob)
             finally:
                 os.environ.pop("XDTTS_NO_SKEW", None)
+                os.environ.pop("XDTTS_P8", None)
             out[skew] = m.infer_batch(ids, **kw)
             assert m.engine_state()["decoder_persistent"] == 1
             m.close()
@@ -150,15 +154,22 @@ def test_skewed_pair_loop_is_bit_identical_to_the_lock_step_loop(pkg, orc, blob)
             assert x.shape == y.shape and np.array_equal(x, y)
 
 
-def test_three_and_four_chunks_run_as_two_persistent_launches(pkg, orc, blob):
-    """B = 3..4: the persistent engine takes the chunks two at a time over views of the state arrays;
+@pytest.mark.parametrize("p8", ["0", "1"])
+def test_three_and_four_chunks_run_as_two_persistent_launches(pkg, orc, blob, p8):
+    """B = 3..4 with XDTTS_P8=0: the persistent engine takes the chunks two at a time over views of the state arrays
+    (by default they run on decoder_persistent8.hip);
     every chunk must still equal its own single-chunk oracle run (item index = dropout stream)."""
     lens = [37, 12, 58, 23]
     ids = [synth_ids(n, seed=11 + i) for i, n in enumerate(lens)]
     for B in (3, 4):
         o = pkg.default_opts(fixed_steps=40, dropout_seed=77, item_base=5)
-        m = pkg.Tacotron2.from_blob(blob)
+        os.environ["XDTTS_P8"] = p8
+        try:
+            m = pkg.Tacotron2.from_blob(blob)
+        finally:
+            del os.environ["XDTTS_P8"]
         out = m.infer_batch(ids[:B], opts=o)
+        assert m.engine_state()["decoder_persistent8"] == int(p8)
         with engine("launch"):
             ref = m.infer_batch(ids[:B], opts=o)
         m.close()
@@ -286,7 +297,7 @@ def test_engine_state_and_reset(pkg, orc, blob):
     m = pkg.Tacotron2.from_blob(blob)
     assert m.engine_state()["decoder_persistent"] == -1
     m.decoder(mem, pm, 21, pkg.default_opts(fixed_steps=6, dropout_seed=3))
-    assert m.engine_state() == {"decoder_persistent": 1, "encoder_cooperative": 1, "batched_attention": 2}
+    assert m.engine_state() == {"decoder_persistent": 1, "encoder_cooperative": 1, "batched_attention": 2, "decoder_persistent8": -1}
     os.environ["XDTTS_PERSIST_FAULT"] = "201"
     os.environ["XDTTS_PERSIST_SPINS"] = "20000"
     try:

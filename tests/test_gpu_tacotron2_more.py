@@ -436,7 +436,7 @@ def test_lost_attention_block_falls_back(pkg, orc, blob, capfd, form):
     """The blocks of a chunk wait for each other's partial energies inside one launch.  With one block never
     publishing (test hook) the bounded spins run out, the error word is set, and the handle decodes the request
     again with separate kernels: correct frames, a message on stderr, no hang; engine_reset restores the fast form."""
-    ids_list, steps = _batch_case(8)
+    ids_list, steps = _batch_case(9)  # (3..8 chunks have an engine of their own: decoder_persistent8.hip)
     os.environ["XDTTS_ATT_FUSED"] = form
     os.environ["XDTTS_ATT_FAULT"] = "3"     # block 2 = chunk 0's third attention block in either form
     os.environ["XDTTS_ATT_SPINS"] = "20000"
@@ -464,7 +464,7 @@ def test_lost_h_dec_in_the_two_launch_form_falls_back(pkg, orc, blob, capfd):
     """In the two-launch form the four tail blocks of a chunk wait, inside the decoder-LSTM launch, for the h_dec granules of all
     256 LSTM blocks.  With one block never publishing (test hook) the bounded spins run out, the error word is set and the
     handle decodes the request again with separate kernels: correct frames, a message on stderr, no hang."""
-    ids_list, steps = _batch_case(8)
+    ids_list, steps = _batch_case(9)
     os.environ["XDTTS_TAIL_FAULT"] = "7"
     os.environ["XDTTS_ATT_SPINS"] = "20000"
     try:

@@ -194,6 +194,14 @@ int main(int argc, char **argv) {
   CHECK(hipMalloc(&ring, ring_bytes));
   CHECK(hipMalloc(&out, sizeof(float) * NCU));
   CHECK(hipMalloc(&err, sizeof(int)));
+  for (int nap : {0, 8, 12, 16, 20, 24}) {
+    run<0, 1, 0>(iters, nap, gran, ring, ring_bytes, out, err, "8-B granules, 8-B sc1 loads");
+    run<1, 1, 0>(iters, nap, gran, ring, ring_bytes, out, err, "8-B granules, 16-B sc1 loads");
+    run<2, 1, 16>(iters, nap, gran, ring, ring_bytes, out, err, "ring of values, 16-B loads, first sc1");
+    run<0, 2, 0>(iters, nap, gran, ring, ring_bytes, out, err, "8-B granules, 8-B sc1 loads");
+    run<1, 2, 0>(iters, nap, gran, ring, ring_bytes, out, err, "8-B granules, 16-B sc1 loads");
+    run<2, 2, 16>(iters, nap, gran, ring, ring_bytes, out, err, "ring of values, 16-B loads, first sc1");
+  }
   for (int nap : {0, 8, 16, 24}) {
     run<0, 4, 0>(iters, nap, gran, ring, ring_bytes, out, err, "8-B granules, 8-B sc1 loads");
     run<1, 4, 0>(iters, nap, gran, ring, ring_bytes, out, err, "8-B granules, 16-B sc1 loads");

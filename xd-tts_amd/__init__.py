@@ -84,6 +84,7 @@ SYMBOLS = {
     "xdtts_tacotron2_decoder_step": (_I32, [_VP, _VP, _VP, _I32, _I32, C.POINTER(InferOpts), _U32] + [_VP] * 10),
     "xdtts_tacotron2_decoder_steps": (_I32, [_VP, _I32, _I32, _VP, _VP, _I32, _VP, C.POINTER(InferOpts), _U32, _I32] + [_VP] * 10),
     "xdtts_tacotron2_engine_state": (_I32, [_VP, C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32)]),
+    "xdtts_tacotron2_small_batch_engine_state": (_I32, [_VP, C.POINTER(_I32)]),
     "xdtts_tacotron2_engine_reset": (_I32, [_VP]),
     "xdtts_tacotron2_postnet": (_I32, [_VP, _VP, _I32, _VP]),
     "xdtts_tacotron2_last_timings": (_I32, [_VP, C.POINTER(C.c_float * 4), C.POINTER(_I32)]),
@@ -493,7 +494,9 @@ class Tacotron2:
     def engine_state(self):
         a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
         _check(lib.xdtts_tacotron2_engine_state(self._h, C.byref(a), C.byref(b), C.byref(c)))
-        return {"decoder_persistent": a.value, "encoder_cooperative": b.value, "batched_attention": c.value}
+        e = C.c_int32()
+        _check(lib.xdtts_tacotron2_small_batch_engine_state(self._h, C.byref(e)))
+        return {"decoder_persistent": a.value, "encoder_cooperative": b.value, "batched_attention": c.value, "decoder_persistent8": e.value}
 
     def engine_reset(self):
         _check(lib.xdtts_tacotron2_engine_reset(self._h))

@@ -289,6 +289,8 @@ struct xdtts_tacotron2 {
   bool ctx_fold_table = getenv("XDTTS_NO_CTXFOLD") == nullptr;
   // XDTTS_NO_SKEW (read when a handle is created): pairs of chunks run the persistent kernel's lock-step loop instead of the skewed one
   bool pair_skew = getenv("XDTTS_NO_SKEW") == nullptr;
+  // XDTTS_P8=0 (read when a handle is created): 3..8 chunks go to the engines that served them before decoder_persistent8.hip
+  bool p8_wanted = [] { const char *p = getenv("XDTTS_P8"); return !(p && p[0] == '0'); }();
   bool two_launch = getenv("XDTTS_NO_TAIL") == nullptr;  // (XDTTS_NO_TAIL: keep the prenet launch; read when a handle is created)
   int persist_state = -1;                   // -1 unknown, 0 unavailable on this device / demoted, 1 usable
   bool persist_probe_ok = false;            // the device can host the persistent grid (occupancy probe)
@@ -585,14 +587,14 @@ struct xdtts_tacotron2 {
   // 3..8 chunks: the persistent MFMA engine (decoder_persistent8.hip), one launch for the whole loop.  It shares the persistent
   // engine's fate: a timed-out exchange or a refused launch demotes both (persist_state), the request runs again on the
   // launch-per-stage engine.
-  int p8_state = -1;  // -1 unknown, 0 off (XDTTS_P8=0, or the device cannot host the grid), 1 usable
+  int p8_state = -1;  // -1 unknown, 0 off (XDTTS_P8=0, the device cannot host the grid, or an exchange timed out), 1 usable
+  bool p8_refused = false;  // the runtime refused the cooperative launch: a property of the device (engine_reset does not undo it)
   bool small_batch_engine(int B, int T) {
     if (B < 3 || B > P8_B_MAX || T > PERSIST_T_MAX) return false;
     const char *e = getenv("XDTTS_DECODER");
     if (e && std::string(e) == "launch") return false;
     if (p8_state < 0) {
-      const char *p = getenv("XDTTS_P8");
-      p8_state = (p && p[0] == '1' && decoder_p8_supported(device, P8_B_MAX, PERSIST_T_MAX)) ? 1 : 0;
+      p8_state = (p8_wanted && decoder_p8_supported(device, P8_B_MAX, PERSIST_T_MAX)) ? 1 : 0;
     }
     return p8_state == 1 && persist_state != 0;
   }
@@ -670,6 +672,7 @@ struct xdtts_tacotron2 {
       launch_decoder_init(d, limits.p, stream);
     } catch (const CoopRefused &) {
       p8_state = 0;
+      p8_refused = true;
       std::fprintf(stderr, "libxdtts_hip: persistent MFMA decoder launch refused by the runtime; this handle decodes small batches "
                            "with its other engines\n");
       HIP_CHECK(hipStreamSynchronize(stream));
@@ -1933,6 +1936,14 @@ xdtts_status xdtts_tacotron2_engine_state(const xdtts_tacotron2 *h, int32_t *dec
   });
 }
 
+xdtts_status xdtts_tacotron2_small_batch_engine_state(const xdtts_tacotron2 *h, int32_t *state) {
+  return guard([&] {
+    if (!h || !state) fail(XDTTS_ERR_BAD_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    *state = h->p8_state;
+  });
+}
+
 // Puts a demoted handle back on the fast engines (they are probed again on the next call).
 xdtts_status xdtts_tacotron2_engine_reset(xdtts_tacotron2 *h) {
   return guard([&] {
@@ -1940,6 +1951,7 @@ xdtts_status xdtts_tacotron2_engine_reset(xdtts_tacotron2 *h) {
     std::lock_guard<std::mutex> lk(h->mu);
     // (a launch the runtime REFUSED is a property of the device, not a transient: those engines stay off)
     if (!h->persist_refused) h->persist_state = -1;
+    if (!h->p8_refused) h->p8_state = -1;
     if (!h->coop_refused) h->coop_ok = true;
     h->demoted_calls = 0;
     h->enc_demoted_calls = 0;

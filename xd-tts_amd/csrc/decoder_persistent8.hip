@@ -79,16 +79,21 @@ __device__ __forceinline__ void nap(int n) {
 #pragma unroll 1
   for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
 }
-template <int N, class At, class Sink>
-__device__ __forceinline__ unsigned gather(const u64 *base, unsigned want, unsigned need, const PollCtl &pc, At at, Sink sink) {
-  unsigned pending = N < 32 ? need & ((1u << (N & 31)) - 1u) : need, spins = 0;
-  const int first = pending ? __ffs(pending) - 1 : 0;
-  while (pending) {
-    u64 v[N];
-    unsigned zero = 0u;
-    asm volatile("" : "+v"(zero));  // (opaque: the N addresses are formed next to their loads, not kept in 2 N registers across the loop)
+template <int N, class At>
+__device__ __forceinline__ void gather_issue(u64 (&v)[N], const u64 *base, unsigned need, At at) {
+  const int first = need ? __ffs(need) - 1 : 0;
+  unsigned zero = 0u;
+  asm volatile("" : "+v"(zero));  // (opaque: the N addresses are formed next to their loads, not kept in 2 N registers across the loop)
 #pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = peek(base + (zero + at(((need >> i) & 1u) ? i : first)));
+  for (int i = 0; i < N; ++i) v[i] = peek(base + (zero + at(((need >> i) & 1u) ? i : first)));
+}
+// v: the first round's loads, issued by the caller some work ago (gather_issue)
+template <int N, class At, class Sink>
+__device__ __forceinline__ unsigned gather_from(u64 (&v)[N], const u64 *base, unsigned want, unsigned need, const PollCtl &pc, At at, Sink sink) {
+  unsigned pending = N < 32 ? need & ((1u << (N & 31)) - 1u) : need, spins = 0;
+  need = pending;
+  while (pending) {
+    if (spins) gather_issue<N>(v, base, need, at);
 #pragma unroll
     for (int i = 0; i < N; ++i)
       if ((pending >> i) & 1u) {
@@ -101,6 +106,13 @@ __device__ __forceinline__ unsigned gather(const u64 *base, unsigned want, unsig
     if (pending && give_up(spins, pc)) return spins;
   }
   return spins;  // failed rounds
+}
+template <int N, class At, class Sink>
+__device__ __forceinline__ unsigned gather(const u64 *base, unsigned want, unsigned need, const PollCtl &pc, At at, Sink sink) {
+  u64 v[N];
+  need = N < 32 ? need & ((1u << (N & 31)) - 1u) : need;
+  if (need) gather_issue<N>(v, base, need, at);
+  return gather_from<N>(v, base, want, need, pc, at, sink);
 }
 // The same for a write-once slab of plain values: N 16-byte loads at byte offsets at(i) of `slab`, a quad is delivered once none
 // of its four words is the fill pattern (they are four dword stores of one producer, or one 16-byte store).  First round sc1,
@@ -149,14 +161,14 @@ struct P8Weights {
 
 // NQ b128 loads of the wave's slice of one state segment (seg: LDS base of the segment in B order [k/4][NB][4]; q0: the wave's
 // first column quad-of-quads), 4 MFMAs each, into acc.  A[q] = the lane's four weights of columns 16 (q0 + q) + 4 kk .. + 3.
-template <int NB, int NQ>
+template <int NB, int NQ, int FROM = 0, int TO = NQ>
 __device__ __forceinline__ void mfma_segment(f32x4 &acc, const float4 (&A)[NQ], const float *seg, int q0, int kk, int n) {
   // one B vector ahead of the MFMAs that consume it, and no further
   const float *bp = seg + ((4 * q0 + kk) * NB + n) * 4;
-  float4 b = lds4(bp);
+  float4 b = lds4(bp + FROM * 4 * NB * 4);
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    const float4 bn = q + 1 < NQ ? lds4(bp + (q + 1) * 4 * NB * 4) : b;
+  for (int q = FROM; q < TO; ++q) {
+    const float4 bn = q + 1 < TO ? lds4(bp + (q + 1) * 4 * NB * 4) : b;
     asm volatile("" ::: "memory");
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[q].x, b.x, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[q].y, b.y, acc, 0, 0, 0);
@@ -170,13 +182,9 @@ __device__ __forceinline__ void mfma_segment(f32x4 &acc, const float4 (&A)[NQ], 
 // Developer build (-DXDTTS_P8_PROFILE): thread 0 of three workgroups (one per role) accumulates the 100 MHz wall clock between
 // phase markers and prints the sums at exit.
 #ifdef XDTTS_P8_PROFILE
-#define P8_MARK(i)                                        \
-  do {                                                    \
-    if (tid == 0) {                                       \
-      const u64 now_ = wall_clock64();                    \
-      s_prof[i] += now_ - prof_last;                      \
-      prof_last = now_;                                   \
-    }                                                     \
+#define P8_MARK(i)                                              \
+  do {                                                          \
+    s_ts[wave * 32 + (i)] += (unsigned)wall_clock64(); /* every lane, no branch: wave 0's copy is read */ \
   } while (0)
 #else
 #define P8_MARK(i) do { } while (0)
@@ -386,9 +394,15 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent8(DecoderBufs d, P8Buf
   };
 
 #ifdef XDTTS_P8_PROFILE
-  __shared__ u64 s_prof[20];
-  if (tid < 20) s_prof[tid] = 0;
-  u64 prof_last = wall_clock64();
+  __shared__ u64 s_prof[32];
+  __shared__ unsigned s_ts[NW * 32];  // time stamp of every marker of the current step, in program order P8_ORDER
+  if (tid < 32) s_prof[tid] = 0;
+#endif
+#ifdef XDTTS_P8_PROFILE
+  __syncthreads();
+  if (tid < NW * 32) s_ts[tid] = 0;
+  __syncthreads();
+  s_ts[wave * 32 + 28] = (unsigned)wall_clock64();  // start of the loop
 #endif
   int s = step0;
   const int s_stop = step0 + nsteps;
@@ -499,15 +513,22 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent8(DecoderBufs d, P8Buf
     }
     P8_MARK(5);
     // decoder LSTM of this step: the h_att(s) columns (in the time the partial energies travel)
-    mfma_segment<NB, 16>(accD, dh, s_hatt, 16 * wave, kk, n);
+    // (attention role: the first poll of the partial energies leaves half-way through, so that it lands as the MFMAs end)
+    const int ep_t = tid >> 2, ep_j = tid & 3;  // loads i: row j + 4 (i % 2), encoder step t + 64 (i / 2)
+    const u64 *ep_base = g.ep + (unsigned)(((p * NB + rb) * ATTN_CU + ep_j) * EP_LD + ep_t);
+    const unsigned ep_need = (attn && act_r) ? ((ep_t < T ? 3u : 0u) | (ep_t + 64 < T ? 12u : 0u)) : 0u;
+    auto ep_at = [](int i) { return (unsigned)((i & 1) * 4 * EP_LD + (i >> 1) * 64); };
+    u64 ep_v[4] = {0, 0, 0, 0};
+    mfma_segment<NB, 16, 0, 8>(accD, dh, s_hatt, 16 * wave, kk, n);
+    if (ep_need) gather_issue<4>(ep_v, ep_base, ep_need, ep_at);
+    mfma_segment<NB, 16, 8, 16>(accD, dh, s_hatt, 16 * wave, kk, n);
     P8_MARK(6);
     // ---- P3 (attention role): the 8 partial-energy rows of the chunk -> softmax -> this workgroup's 64 context columns ------------
     if (attn && act_r) {
       {
-        const int t = tid >> 2, j = tid & 3;  // loads i: row j + 4 (i % 2), encoder step t + 64 (i / 2)
+        const int t = ep_t, j = ep_j;
         float ev[4] = {0.f, 0.f, 0.f, 0.f};
-        gather<4>(g.ep + (unsigned)(((p * NB + rb) * ATTN_CU + j) * EP_LD + t), want, (t < T ? 3u : 0u) | (t + 64 < T ? 12u : 0u), pc,
-                  [](int i) { return (unsigned)((i & 1) * 4 * EP_LD + (i >> 1) * 64); }, [&](int i, float v, unsigned) { ev[i] = v; });
+        gather_from<4>(ep_v, ep_base, want, ep_need, pc, ep_at, [&](int i, float v, unsigned) { ev[i] = v; });
         float e0 = ev[0] + ev[1], e1 = ev[2] + ev[3];
         e0 += dpp_move<0xB1, 0xf>(0.f, e0);
         e1 += dpp_move<0xB1, 0xf>(0.f, e1);
@@ -518,7 +539,9 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent8(DecoderBufs d, P8Buf
           s_e[t + 64] = (t + 64 < T && t + 64 < nv_r) ? e1 : -INFINITY;
         }
       }
+      P8_MARK(20);
       __syncthreads();
+      P8_MARK(21);
       {  // every wave: the softmax in registers, lane <-> steps lane, lane + 64
         const float e0 = s_e[lane], e1 = s_e[lane + 64];
         const float m = wave_max(fmaxf(e0, e1));
@@ -541,6 +564,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent8(DecoderBufs d, P8Buf
           s_awc[lane + 64] += w1;
         }
       }
+      P8_MARK(22);
       __syncthreads();
       if (tid < 64) {
         float v = 0.f;
@@ -551,6 +575,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent8(DecoderBufs d, P8Buf
         put(g.rctx + ((size_t)(s - step0) * NB + rb) * EMB + 64 * rk + tid, value_bits(v));
       }
     }
+    P8_MARK(23);
     mfma_segment<NB, 16>(accA, ah, s_hatt, 16 * wave, kk, n);  // attention LSTM of the next step: h_att(s) (while ctx travels)
     P8_MARK(7);
     // ---- P4: ctx(s) of every active chunk -> decoder LSTM ------------------------------------------------------------------------
@@ -558,7 +583,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent8(DecoderBufs d, P8Buf
     unsigned needc = 0u;
 #pragma unroll
     for (int i = 0; i < NB / 2; ++i) needc |= ((actm >> (2 * i + (wave >> 1))) & 1u) << i;
-    nap(g.delay[1]);
+    if (!(attn && act_r)) nap(g.delay[1]);  // (the attention workgroups are the producers: the others have 3 us to wait)
     const unsigned fr1 = gather16<NB / 2>(g.rctx + (size_t)(s - step0) * NB * EMB, needc, pc, [&](int i) { return 16u * (unsigned)(tid + PT * i); },
                                           [&](int i, u32x4 v) {
                                             const int b = 2 * i + (wave >> 1), k = 4 * (tid & 127);
@@ -596,6 +621,9 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent8(DecoderBufs d, P8Buf
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         drop2 |= (prenet_dropped(d.dropout_mode, d.dropout_seed, item, d.drop_masks, d.drop_steps, rb, s + 1, 1, 16 * rk + wave + NW * r) ? 1u : 0u) << r;
+      drop2 |= drop1 ? 16u : 0u;
+      asm volatile("" : "+v"(drop2));  // (computed HERE: left alone the compiler sinks the hashes behind the gather, onto the critical path)
+      drop1 = (drop2 & 16u) != 0u;
     }
     nap(g.delay[2]);
     const unsigned fr2 = gather16<NB>(g.rhdec + (size_t)(s - step0) * NB * DEC_RNN, actm, pc, [&](int i) { return 16u * (unsigned)(tid + PT * i); },
@@ -634,7 +662,9 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent8(DecoderBufs d, P8Buf
         s_mel[tid] = 0.f;
         gather<1>(g.mel + (unsigned)((p * NB + rb) * MEL_GL + tid), want, 1u, pc, [](int) { return 0u; }, [&](int, float v, unsigned) { s_mel[tid] = v; });
       }
+      P8_MARK(24);
       __syncthreads();
+      P8_MARK(25);
       const float gate = s_mel[N_MEL];
       const bool fired = d.use_gate && gate_sigmoid(gate) > d.gate_threshold;  // mod.rs:319-324
       if (rk == 0) {
@@ -658,6 +688,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent8(DecoderBufs d, P8Buf
           acc = fmaf(w4.w, m.w, acc);
         }
         acc = fmaxf(acc, 0.f);
+        P8_MARK(26);
         __syncthreads();  // (s_mel read by everyone before s_hrow, free since the projection, takes the layer-1 outputs)
         s_hrow[tid] = drop1 ? 0.f : (d.dropout_mode ? 2.f * acc : acc);
         __syncthreads();
@@ -673,6 +704,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent8(DecoderBufs d, P8Buf
           xo[r] = (drop2 >> r) & 1u ? 0.f : (d.dropout_mode ? 2.f * a : a);
         }
       }
+      P8_MARK(27);
       // the workgroup's 16 columns leave as ONE 128-byte store (decoder_persistent.hip)
       if (lane < 4) s_mel[MEL_GL - 16 + wave + NW * lane] = lane == 0 ? xo[0] : (lane == 1 ? xo[1] : (lane == 2 ? xo[2] : xo[3]));  // s_mel[81..95] is unused padding
       __syncthreads();
@@ -681,6 +713,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent8(DecoderBufs d, P8Buf
     }
     P8_MARK(16);
 #ifdef XDTTS_P8_PROFILE
+    s_ts[wave * 32 + 29] = (unsigned)wall_clock64();  // (the last marker of the last step, not summed)
     if (tid == 0) {
       s_prof[17] += fr0;
       s_prof[18] += fr1;
@@ -708,12 +741,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent8(DecoderBufs d, P8Buf
   if (c == 0 && tid == 0) d.ctl[0] = s;
 #ifdef XDTTS_P8_PROFILE
   __syncthreads();
-  if (tid == 0 && (c == 0 || c == ATTN_CU * B || c == P_NCU - 1) && s > step0) {
-    const float k_ = 0.01f / (float)(s - step0);
-    printf("P8PROF wg %3d steps %d:  x %.2f|%.2f  attcell %.2f  hatt %.2f|%.2f  energies %.2f  mfma2 %.2f  softmax %.2f  ctx %.2f|%.2f  deccell %.2f  ac+loc %.2f  hdec %.2f|%.2f  proj %.2f  mfma-dd %.2f  prenet %.2f | failed rounds h_att %.2f ctx %.2f h_dec %.2f\n",
-           c, s - step0, k_ * s_prof[0], k_ * s_prof[1], k_ * s_prof[2], k_ * s_prof[3], k_ * s_prof[4], k_ * s_prof[5], k_ * s_prof[6], k_ * s_prof[7], k_ * s_prof[8], k_ * s_prof[9], k_ * s_prof[10],
-           k_ * s_prof[11], k_ * s_prof[12], k_ * s_prof[13], k_ * s_prof[14], k_ * s_prof[15], k_ * s_prof[16], 100.f * k_ * s_prof[17], 100.f * k_ * s_prof[18], 100.f * k_ * s_prof[19]);
-  }
+  if (g.prof && tid < 32) g.prof[c * 32 + tid] = tid == 31 ? (u64)(s - step0) : (tid >= 17 && tid < 20 ? s_prof[tid] : (u64)s_ts[tid]);  // sums of time stamps (mod 2^32)
 #endif
 }
 
@@ -798,7 +826,38 @@ void launch_decoder_p8(const DecoderBufs &d, const DeviceWeights &w, const P8Buf
   pw.pre0T = w.pre0T.p;
   pw.pre1T = w.pre1T.p;
   const void *fn = p8_slots(d.B) == 4 ? reinterpret_cast<const void *>(k_decoder_persistent8<4>) : reinterpret_cast<const void *>(k_decoder_persistent8<NBMAX>);
+#ifdef XDTTS_P8_PROFILE
+  static unsigned long long *prof_dev = nullptr;
+  if (!prof_dev) HIP_CHECK(hipMalloc((void **)&prof_dev, sizeof(unsigned long long) * P_NCU * 32));
+  P8Bufs gp = g;
+  gp.prof = prof_dev;
+  COOP_CHECK(launch_coresident(true, fn, dim3(P_NCU), dim3(PT), 0, s, d, gp, pw, nsteps));
+  HIP_CHECK(hipStreamSynchronize(s));
+  static unsigned long long host[P_NCU * 32];
+  HIP_CHECK(hipMemcpy(host, prof_dev, sizeof(host), hipMemcpyDeviceToHost));
+  for (int c : {0, ATTN_CU * d.B, P_NCU - 1}) {
+    const unsigned long long *h = host + c * 32;
+    const double steps = (double)h[31];
+    if (steps <= 0) continue;
+    const bool attn = c < ATTN_CU * d.B, pre = !attn && c < (ATTN_CU + PRE_CU) * d.B;
+    static const int order[25] = {0, 1, 2, 3, 4, 5, 6, 20, 21, 22, 23, 7, 8, 9, 10, 11, 12, 13, 14, 15, 24, 25, 26, 27, 16};
+    // every marker's slot holds the SUM of its time stamps over the steps: a phase = sum - sum of the marker before it
+    unsigned prev = (unsigned)h[16] - (unsigned)h[29] + (unsigned)h[28];  // "marker before" the first one: the previous step's last, the loop start for step 0
+    for (int i = 0; i < 25; ++i) {
+      const int m = order[i];
+      if (((m >= 20 && m <= 22) && !attn) || ((m >= 24 && m <= 27) && !pre)) {
+        printf("P8PROF %d %d %d %.3f\n", c, (int)steps, m, 0.0);
+        continue;
+      }
+      printf("P8PROF %d %d %d %.3f\n", c, (int)steps, m, 0.01 * (double)((unsigned)h[m] - prev) / steps);
+      prev = (unsigned)h[m];
+    }
+    for (int i = 17; i < 20; ++i) printf("P8PROF %d %d %d %.3f\n", c, (int)steps, i, (double)h[i] / steps);
+  }
+  fflush(stdout);
+#else
   COOP_CHECK(launch_coresident(true, fn, dim3(P_NCU), dim3(PT), 0, s, d, g, pw, nsteps));
+#endif
 }
 
 }  // namespace xdtts

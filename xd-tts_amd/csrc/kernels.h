@@ -149,6 +149,7 @@ struct P8Bufs {
   int spins, fault;  // test hooks: poll limit (0 = default) and a workgroup (index + 1) that never runs
   int delay[4];      // naps (64 clocks each) before the first poll of h_att / ctx / h_dec / x
   int ring_steps;    // steps the rings are laid out for
+  unsigned long long *prof;  // developer build (-DXDTTS_P8_PROFILE): [workgroup][32] phase clocks
 };
 size_t p8_exchange_words(int B, int nsteps);
 P8Bufs p8_bufs(unsigned long long *base, int *err, int B, int nsteps);
