@@ -46,6 +46,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int PT = 256, NW = PT / 64, NBMAX = P8_B_MAX, P_NCU = ATT_RNN / 4, TP = PERSIST_T_MAX;
 constexpr int ATTN_CU = 8, PRE_CU = 16, EP_LD = TP, MEL_GL = 96, WPAD = TP + 32;
 constexpr unsigned P_SPIN_LIMIT = 1u << 21, ACT_BIT = 0x80000000u;
+#ifndef XDTTS_P8_ATTN_SCHED
+#define XDTTS_P8_ATTN_SCHED 0
+#endif
+constexpr int DH_A = 8;  // column groups of the decoder LSTM's h_att segment ahead of the first energies poll (schedule 0)
+// 1: the attention workgroups put nothing but a nap between their energies and the poll of the other seven's, and run their
+// h_att MFMAs behind the context / the decoder cell instead.  Measured equal (14.6-14.9 us at 4 chunks either way: what the
+// energies edge gains, the later h_dec of those 32 workgroups loses for everybody), so the simpler order is the default.
+constexpr bool ATTN_SCHED = XDTTS_P8_ATTN_SCHED != 0;
 static_assert(NBMAX == 8 && ATT_RNN == DEC_RNN && P_NCU == 256 && (ATTN_CU + PRE_CU) * NBMAX <= P_NCU, "role workgroups of 8 chunks fit the grid");
 static_assert(TP == 128 && PRENET == PT && EMB == 2 * PT && ATT_RNN == 4 * PT, "thread <-> granule maps below");
 
@@ -164,6 +172,7 @@ struct P8Weights {
 template <int NB, int NQ, int FROM = 0, int TO = NQ>
 __device__ __forceinline__ void mfma_segment(f32x4 &acc, const float4 (&A)[NQ], const float *seg, int q0, int kk, int n) {
   // one B vector ahead of the MFMAs that consume it, and no further
+  if constexpr (FROM >= TO) return;
   const float *bp = seg + ((4 * q0 + kk) * NB + n) * 4;
   float4 b = lds4(bp + FROM * 4 * NB * 4);
 #pragma unroll
@@ -519,9 +528,18 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent8(DecoderBufs d, P8Buf
     const unsigned ep_need = (attn && act_r) ? ((ep_t < T ? 3u : 0u) | (ep_t + 64 < T ? 12u : 0u)) : 0u;
     auto ep_at = [](int i) { return (unsigned)((i & 1) * 4 * EP_LD + (i >> 1) * 64); };
     u64 ep_v[4] = {0, 0, 0, 0};
-    mfma_segment<NB, 16, 0, 8>(accD, dh, s_hatt, 16 * wave, kk, n);
-    if (ep_need) gather_issue<4>(ep_v, ep_base, ep_need, ep_at);
-    mfma_segment<NB, 16, 8, 16>(accD, dh, s_hatt, 16 * wave, kk, n);
+    const bool attn_on = attn && act_r;
+    if (ATTN_SCHED && attn_on) {
+      // the attention workgroups are the step's critical chain here: nothing but a nap between their energies and the poll of
+      // the chunk's other seven; their h_att MFMAs follow the context (and the next step's follow the decoder cell)
+      nap(g.delay[4]);
+      gather_issue<4>(ep_v, ep_base, ep_need, ep_at);
+    } else {
+      mfma_segment<NB, 16, 0, DH_A>(accD, dh, s_hatt, 16 * wave, kk, n);
+      if (ep_need) gather_issue<4>(ep_v, ep_base, ep_need, ep_at);
+      mfma_segment<NB, 16, DH_A, 16>(accD, dh, s_hatt, 16 * wave, kk, n);
+      if (ATTN_SCHED) mfma_segment<NB, 16>(accA, ah, s_hatt, 16 * wave, kk, n);  // attention LSTM of the next step: h_att(s)
+    }
     P8_MARK(6);
     // ---- P3 (attention role): the 8 partial-energy rows of the chunk -> softmax -> this workgroup's 64 context columns ------------
     if (attn && act_r) {
@@ -576,7 +594,8 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent8(DecoderBufs d, P8Buf
       }
     }
     P8_MARK(23);
-    mfma_segment<NB, 16>(accA, ah, s_hatt, 16 * wave, kk, n);  // attention LSTM of the next step: h_att(s) (while ctx travels)
+    if (!ATTN_SCHED) mfma_segment<NB, 16>(accA, ah, s_hatt, 16 * wave, kk, n);  // attention LSTM of the next step: h_att(s) (while ctx travels)
+    else if (attn_on) mfma_segment<NB, 16>(accD, dh, s_hatt, 16 * wave, kk, n);
     P8_MARK(7);
     // ---- P4: ctx(s) of every active chunk -> decoder LSTM ------------------------------------------------------------------------
     // quad tid + 256 i of the slab: chunk 2 i + tid / 128, columns 4 (tid % 128) .. + 3
@@ -608,6 +627,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent8(DecoderBufs d, P8Buf
     }
     accD = (f32x4){0.f, 0.f, 0.f, 0.f};
     P8_MARK(10);
+    if (ATTN_SCHED && attn_on) mfma_segment<NB, 16>(accA, ah, s_hatt, 16 * wave, kk, n);
     mfma_segment<NB, 8>(accA, ac, s_ctx, 8 * wave, kk, n);  // attention LSTM of the next step: ctx(s)
     if (attn && act_r) location();                           // ... and its location features
     P8_MARK(11);
@@ -777,7 +797,9 @@ P8Bufs p8_bufs(unsigned long long *base, int *err, int B, int nsteps) {
   g.ring_steps = nsteps;
   g.err = err;
   g.delay[0] = g.delay[2] = 16;
-  if (const char *e = getenv("XDTTS_P8_DELAY")) sscanf(e, "%d,%d,%d,%d", &g.delay[0], &g.delay[1], &g.delay[2], &g.delay[3]);  // developer sweep
+  g.delay[1] = 64;
+  g.delay[4] = 24;
+  if (const char *e = getenv("XDTTS_P8_DELAY")) sscanf(e, "%d,%d,%d,%d,%d", &g.delay[0], &g.delay[1], &g.delay[2], &g.delay[3], &g.delay[4]);  // developer sweep
   return g;
 }
 

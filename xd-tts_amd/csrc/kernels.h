@@ -147,7 +147,7 @@ struct P8Bufs {
   unsigned long long *ep, *mel;         // {tag, value} granules, [2 step parities][P8_B_MAX][n] each
   int *err;          // set by a workgroup whose bounded spin ran out
   int spins, fault;  // test hooks: poll limit (0 = default) and a workgroup (index + 1) that never runs
-  int delay[4];      // naps (64 clocks each) before the first poll of h_att / ctx / h_dec / x
+  int delay[5];      // naps (64 clocks each) before the first poll of h_att / ctx / h_dec / x / the partial energies
   int ring_steps;    // steps the rings are laid out for
   unsigned long long *prof;  // developer build (-DXDTTS_P8_PROFILE): [workgroup][32] phase clocks
 };
