@@ -723,6 +723,8 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent8(DecoderBufs d, P8Buf
           a = fmaxf(wave_sum(a), 0.f);
           xo[r] = (drop2 >> r) & 1u ? 0.f : (d.dropout_mode ? 2.f * a : a);
         }
+      } else {
+        P8_MARK(26);  // (profile build: every marker of the role once per step)
       }
       P8_MARK(27);
       // the workgroup's 16 columns leave as ONE 128-byte store (decoder_persistent.hip)
