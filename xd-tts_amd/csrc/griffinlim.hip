@@ -641,34 +641,59 @@ __global__ __launch_bounds__(64 * W, PC) void k_gl_persistent(GlBufs g, GlPersis
   if (own) {
     const float *S = g.S + (size_t)(fbase + f) * g.nb;
     const float2 *A = ang_in + (size_t)(fbase + f) * g.nb, *P = tprev_in + (size_t)(fbase + f) * g.nb;
-    for (int k = lane; k < 513; k += 64) {
-      const float sk = S[k];
-      float2 ak, pk = make_float2(0.f, 0.f);
-      if (p.gen_phase) {  // the seeded stream of k_phase_init: u keyed (seed, frame * 513 + bin), frame inside the utterance
-        const float u = rng_uniform(p.seed, 0x47u, (uint32_t)(f * g.nb + k));
-        float sn, cs;
-        sincospif(2.0f * u, &sn, &cs);
-        ak = make_float2(cs, sn);
-      } else {
-        ak = A[k];
-        pk = P[k];
-      }
-      sS[wave * 516 + k] = sk;
-      sA[wave * 513 + k] = make_float2(ak.x * sk, ak.y * sk);
-      sP[wave * 513 + k] = pk;
-    }
-  }
-  for (int j = tid; j < range; j += nthr) {
-    const int q = Q0 + j, jb = q >> 8, r = q & (HOP - 1);
-    float wss = 0.f;
+    // (all of a lane's loads in flight together: as a loop this was nine dependent round trips to memory per call)
+    float sk9[9];
+    float2 ak9[9], pk9[9];
 #pragma unroll
-    for (int k = 3; k >= 0; --k) {
-      const int fr = jb - k;
-      const float w = g.win[r + k * HOP];
-      wss = (fr >= 0 && fr < F) ? wss + w * w : wss;
+    for (int i = 0; i < 9; ++i) {
+      const int k = lane + 64 * i;
+      sk9[i] = k < 513 ? S[k] : 0.f;
+      ak9[i] = pk9[i] = make_float2(0.f, 0.f);
+      if (!p.gen_phase && k < 513) {
+        ak9[i] = A[k];
+        pk9[i] = P[k];
+      }
     }
-    ws[j] = wss > 1.17549435e-38f ? 1.0f / wss : 1.0f;  // reciprocal of the divisor: one multiply per sample and iteration
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const int k = lane + 64 * i;
+      if (k < 513) {
+        const float sk = sk9[i];
+        float2 ak = ak9[i];
+        if (p.gen_phase) {  // the seeded stream of k_phase_init: u keyed (seed, frame * 513 + bin), frame inside the utterance
+          const float u = rng_uniform(p.seed, 0x47u, (uint32_t)(f * g.nb + k));
+          float sn, cs;
+          sincospif(2.0f * u, &sn, &cs);
+          ak = make_float2(cs, sn);
+        }
+        sS[wave * 516 + k] = sk;
+        sA[wave * 513 + k] = make_float2(ak.x * sk, ak.y * sk);
+        sP[wave * 513 + k] = pk9[i];
+      }
+    }
   }
+  {
+    // a thread's samples j = tid + m nthr all sit at the same offset r of their hop (Q0 and nthr are multiples of 256): its
+    // four window values once, not per sample
+    const int r = tid & (HOP - 1);
+    float w2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float w = g.win[r + k * HOP];
+      w2[k] = w * w;
+    }
+    for (int j = tid; j < range; j += nthr) {
+      const int jb = (Q0 + j) >> 8;
+      float wss = 0.f;
+#pragma unroll
+      for (int k = 3; k >= 0; --k) {
+        const int fr = jb - k;
+        wss = (fr >= 0 && fr < F) ? wss + w2[k] : wss;
+      }
+      ws[j] = wss > 1.17549435e-38f ? 1.0f / wss : 1.0f;  // reciprocal of the divisor: one multiply per sample and iteration
+    }
+  }
+  if (tid == 0) s_err[1] = 0;
   __syncthreads();
 
   u64 *inL = p.xch + (size_t)b * 4 * GLP_HALO, *outL = !seg_first ? p.xch + ((size_t)(b - 1) * 4 + 1) * GLP_HALO : nullptr;
@@ -771,6 +796,10 @@ __global__ __launch_bounds__(64 * W, PC) void k_gl_persistent(GlBufs g, GlPersis
         ev_r[u] = (k < GLP_HALO && outR != nullptr) ? __hip_atomic_load(gr0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
       }
     };
+    // (the error word the workgroup acts on at the end of B2 is requested here, ahead of the overlap-add: read where it is
+    // needed, its round trip -- 0.3 us -- sat between the last LDS store of B2 and the barrier of every iteration)
+    int err_seen = 0;
+    if (tid == 0) err_seen = __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (p.poll_delay >= 0) {
       for (int i = 0; i < p.poll_delay; ++i) __builtin_amdgcn_s_sleep(2);
       early_poll();
@@ -886,11 +915,12 @@ __global__ __launch_bounds__(64 * W, PC) void k_gl_persistent(GlBufs g, GlPersis
           yb[j] = (has_r ? pr[u] + hr[u] : pr[u]) * ws[j];
         }
       }
-      if (tid == 0) *s_err = __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) s_err[0] = err_seen;  // what thread 0 saw before the overlap-add ...
+      if (spins > 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) s_err[1] = 1;  // ... or a poll of this workgroup that gave up (only threads that had to poll again look)
     }
     __syncthreads();
     GLP_MARK(6);  // finalise + barrier after B
-    if (*s_err) return;  // an exchange timed out somewhere: the whole launch drains, the host falls back
+    if (s_err[0] | s_err[1]) return;  // an exchange timed out somewhere: the whole launch drains, the host falls back
     if (it == n_iter) {
       // ---- final ISTFT: the block's share of the centre-trimmed signal ----
       if (audio) {
