@@ -111,4 +111,9 @@ def test_long_sequences_and_the_sizes_either_side(pkg, orc, blob):
     m.infer_batch(ids[:2], opts=o, fixed_steps=[5, 5])
     m.infer_batch([ids[i % 6] for i in range(9)], opts=o, fixed_steps=[5] * 9)
     assert m.engine_state()["decoder_persistent8"] == -1  # never probed
+    # ... nor does a request capped beyond 16384 steps (the rings hold one slab per step): the synthetic gate never fires, so
+    # this one runs to its cap on the batched engine
+    long = m.infer_batch(ids[:5], opts=pkg.default_opts(dropout_seed=1, max_steps=16500))
+    assert all(x.shape == (80, 16500) for x in long) and m.engine_state()["decoder_persistent8"] == -1
+    assert all(np.isfinite(x).all() for x in long)
     m.close()

@@ -589,8 +589,8 @@ struct xdtts_tacotron2 {
   // launch-per-stage engine.
   int p8_state = -1;  // -1 unknown, 0 off (XDTTS_P8=0, the device cannot host the grid, or an exchange timed out), 1 usable
   bool p8_refused = false;  // the runtime refused the cooperative launch: a property of the device (engine_reset does not undo it)
-  bool small_batch_engine(int B, int T) {
-    if (B < 3 || B > P8_B_MAX || T > PERSIST_T_MAX) return false;
+  bool small_batch_engine(int B, int T, int max_steps) {
+    if (B < 3 || B > P8_B_MAX || T > PERSIST_T_MAX || max_steps > P8_STEPS_MAX) return false;
     const char *e = getenv("XDTTS_DECODER");
     if (e && std::string(e) == "launch") return false;
     if (p8_state < 0) {
@@ -654,7 +654,9 @@ struct xdtts_tacotron2 {
       if (after_ran) *after_ran = spec_ran && as_planned;
       return steps;
     };
-    if (!d.xf && small_batch_engine(d.B, d.T)) try {
+    // (its exchange holds one slab per step, 11.3 kB per chunk slot: a request capped at more than 16384 steps -- 190 s of speech --
+    // takes the other engines rather than gigabytes of ring)
+    if (!d.xf && small_batch_engine(d.B, d.T, max_lim)) try {
       std::lock_guard<ChipLock> lk(chip_mutex(device));
       dec_exchange.alloc(p8_exchange_words(d.B, max_lim));
       P8Bufs g8 = p8_bufs(dec_exchange.p, dec_err.p, d.B, max_lim);
@@ -970,7 +972,7 @@ struct xdtts_tacotron2 {
     upload_dropout_masks(o, B, lim0.data());  // (caller's chunk order: a sorted batch finds its masks through item_perm)
     const bool gate_off = fixed_per_item || o.fixed_steps > 0 || o.fixed_frames_per_id > 0.f;
     // (3..8 chunks on the persistent MFMA engine keep the row-major state of the small-batch engines and the caller's order)
-    const bool batched_mode = B >= BATCH_MFMA_MIN && !small_batch_engine(B, T);
+    const bool batched_mode = B >= BATCH_MFMA_MIN && !small_batch_engine(B, T, *std::max_element(lim0.begin(), lim0.end()));
     if (batched_mode)
       std::stable_sort(order.begin(), order.end(), [&](int a, int c) {
         return gate_off ? lim0[a] > lim0[c] : lens[a] > lens[c];  // with the gate on, length is the proxy for duration

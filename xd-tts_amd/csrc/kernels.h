@@ -142,6 +142,7 @@ void launch_decoder_persistent(const DecoderBufs &d, const DeviceWeights &w, con
 // ---- persistent weight-stationary decoder for 3..8 chunks (decoder_persistent8.hip): the LSTMs of all chunks as one MFMA
 // stream per wave, the context as a sixth exchange ------------------------------------------------------------------------
 constexpr int P8_B_MAX = 8;
+constexpr int P8_STEPS_MAX = 16384;  // longest request it takes: 190 s of speech, 1.5 GB of ring at 8 chunk slots
 struct P8Bufs {
   unsigned *rx, *rhatt, *rctx, *rhdec;  // write-once rings of plain values [step][chunk slots][n], 0xFFFFFFFF = not yet written
   unsigned long long *ep, *mel;         // {tag, value} granules, [2 step parities][P8_B_MAX][n] each
