@@ -2257,7 +2257,9 @@ static void gl_batch_from_device(xdtts_griffinlim *g, const float *mel_dev_all, 
             }
             launches.push_back({seg0, (int)segs.size() - seg0, riders[k]});
           }
-        return (tf <= 4 ? (wg > 1 ? 7.1 : 5.35) : 6.8) * (double)riders.size() + 6.8 * n_alone;
+        // us per iteration of one launch of each shape (tools/vocoder_shapes.py, round 4 with the 16-byte exchange granules of the
+        // 4-frame workgroups: 4.6-5.3 / 5.9-6.5 / 6.8-7.3; round 3: 5.35 / 7.1 / 6.8)
+        return (tf <= 4 ? (wg > 1 ? 6.2 : 4.9) : 7.0) * (double)riders.size() + 7.0 * n_alone;
       };
       int TF = 4, WG = 1;
       if (pers) {
