@@ -1122,7 +1122,6 @@ struct xdtts_griffinlim {
   DevBuf<int> gl_err;
   int *host_err = nullptr;         // pinned
   unsigned epoch = 0;              // tag base; tags are never reused while xch lives
-  int xch_wide = -1;               // granule layout xch was last used with (0: 16-byte {3 values, tag} of the 4-frame workgroups, 1: 8-byte {value, tag}); a change clears it
   int persist_state = -1;          // -1 unknown, 0 unavailable / demoted, 1 usable
   int n_cu = 0;
   int per_cu4 = 1;                 // co-resident workgroups of the 4-frame shape per CU (vocoder batch)
@@ -1268,11 +1267,10 @@ struct xdtts_griffinlim {
     if (tprev_fin) *tprev_fin = g.tprev;
     if (persistent_usable() && gl_persistent_plan(g.F, n_cu, &TF, &nblk)) {
       const size_t words = gl_persistent_xch_words(nblk);
-      if (words > xch.n || epoch > 0x7fff0000u - (unsigned)n_iter || xch_wide != (TF > 4 ? 1 : 0)) {  // fresh (or wrapped) tags, or the other granule layout: clear every granule
+      if (words > xch.n || epoch > 0x7fff0000u - (unsigned)n_iter) {  // fresh (or wrapped) tags: clear every granule
         xch.alloc(words);
         HIP_CHECK(hipMemsetAsync(xch.p, 0, xch.n * sizeof(unsigned long long), stream));
         epoch = 0;
-        xch_wide = TF > 4 ? 1 : 0;
       }
       if (!gl_err.p) {
         gl_err.alloc(1);
@@ -2257,9 +2255,9 @@ static void gl_batch_from_device(xdtts_griffinlim *g, const float *mel_dev_all, 
             }
             launches.push_back({seg0, (int)segs.size() - seg0, riders[k]});
           }
-        // us per iteration of one launch of each shape (tools/vocoder_shapes.py, round 4 with the 16-byte exchange granules of the
-        // 4-frame workgroups: 4.6-5.3 / 5.9-6.5 / 6.8-7.3; round 3: 5.35 / 7.1 / 6.8)
-        return (tf <= 4 ? (wg > 1 ? 6.2 : 4.9) : 7.0) * (double)riders.size() + 7.0 * n_alone;
+        // us per iteration of one launch of each shape (tools/vocoder_shapes.py, round 4 with the 16-byte exchange granules:
+        // 4.5-5.2 / 5.8-6.3 / 5.9-6.3; round 3: 5.35 / 7.1 / 6.8) -- at equal cost the 4-frame shape, whose audio is the single call's
+        return (tf <= 4 ? (wg > 1 ? 6.0 : 4.85) : 6.1) * (double)riders.size() + 6.1 * n_alone;
       };
       int TF = 4, WG = 1;
       if (pers) {
@@ -2325,11 +2323,10 @@ static void gl_batch_from_device(xdtts_griffinlim *g, const float *mel_dev_all, 
         const size_t words = gl_persistent_xch_words(g->n_cu * std::max(1, std::min(g->per_cu4, 2)));
         unsigned need = 0;
         for (size_t i = 0; i < launches.size(); ++i) need += (unsigned)g->iters + 2u;
-        if (words > g->xch.n || g->epoch > 0x7fff0000u - need || g->xch_wide != (TF > 4 ? 1 : 0)) {
+        if (words > g->xch.n || g->epoch > 0x7fff0000u - need) {
           g->xch.alloc(words);
           HIP_CHECK(hipMemsetAsync(g->xch.p, 0, g->xch.n * sizeof(unsigned long long), st));
           g->epoch = 0;
-          g->xch_wide = TF > 4 ? 1 : 0;
         }
         if (!g->gl_err.p) {
           g->gl_err.alloc(1);

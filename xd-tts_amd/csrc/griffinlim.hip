@@ -511,7 +511,7 @@ __global__ __launch_bounds__(64 * (TF + 6)) void k_gl_fused(GlBufs g, const floa
 // neighbours' sample ranges: 768 pre-summed samples each way (at hop = n_fft/4 a sample is covered
 // by four frames, so a block's range [256 f0, 256 (f0 + n) + 768) takes three frames' tails from
 // the left neighbour and three frames' heads from the right one).  They travel as data-tagged
-// 8-byte granules {tag = epoch + iteration + 1, value} -- one relaxed agent-scope store each, the
+// 16-byte granules {three samples, tag = epoch + iteration + 1} -- one sc1 store each, the
 // reader re-reads until the tag matches (MI355X_MICROARCH.md hand-off recipe R2, the decoder's
 // scheme): no flags, no fences, no grid barrier, placement-independent; two slots by iteration
 // parity (a slot is rewritten two iterations later, after its reader has published the iteration
@@ -615,11 +615,8 @@ __global__ __launch_bounds__(64 * W, PC) void k_gl_persistent(GlBufs g, GlPersis
   // nine bins a lane updates (pairs k / 512-k for k = lane + 64 r, and k = 256 on lane 0) stay in REGISTERS
   // for the whole call -- 27 LDS accesses less per iteration in the phase-update chain.
   constexpr bool REGSTATE = W == 4 && PC == 1;
-  // 256-thread workgroups: a thread's three samples of an edge (k = tid, tid + 256, tid + 512) and the tag travel as ONE 16-byte
-  // granule (one sc1 store, one sc1 load per side instead of three 8-byte ones; 16-byte sc1 accesses are not torn on gfx950:
-  // MI355X_MICROARCH.md, hand-off recipe R2).  The 512-thread instantiation keeps the 8-byte {value, tag} form (its threads
-  // hold one or two samples of an edge); the host clears the exchange when a vocoder changes between the two.
-  constexpr bool WIDE_GRANULES = W == 4;
+  // The edges of the range cross as 16-byte granules {three samples, tag}: one sc1 store and one sc1 load per side for each of the
+  // workgroup's first 256 threads (16-byte sc1 accesses are not torn on gfx950: MI355X_MICROARCH.md, hand-off recipe R2).
   f2 rP[9];
   float rS[9];
   if (REGSTATE && own) {
@@ -676,19 +673,16 @@ __global__ __launch_bounds__(64 * W, PC) void k_gl_persistent(GlBufs g, GlPersis
     // a thread's samples j = tid + m nthr all sit at the same offset r of their hop (Q0 and nthr are multiples of 256): its
     // four window values once, not per sample
     const int r = tid & (HOP - 1);
-    float w2[4];
+    float w4[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float w = g.win[r + k * HOP];
-      w2[k] = w * w;
-    }
+    for (int k = 0; k < 4; ++k) w4[k] = g.win[r + k * HOP];
     for (int j = tid; j < range; j += nthr) {
       const int jb = (Q0 + j) >> 8;
       float wss = 0.f;
 #pragma unroll
       for (int k = 3; k >= 0; --k) {
         const int fr = jb - k;
-        wss = (fr >= 0 && fr < F) ? wss + w2[k] : wss;
+        wss = (fr >= 0 && fr < F) ? fmaf(w4[k], w4[k], wss) : wss;  // (one rounding per term, as the launch-per-iteration kernels' window sum)
       }
       ws[j] = wss > 1.17549435e-38f ? 1.0f / wss : 1.0f;  // reciprocal of the divisor: one multiply per sample and iteration
     }
@@ -741,33 +735,30 @@ __global__ __launch_bounds__(64 * W, PC) void k_gl_persistent(GlBufs g, GlPersis
     // ---- B0: the own frames' sums over the first and the last 768 samples of the range (own frames 0..2 / n-3..n-1,
     // ascending), straight from the frames and before anything else: they are what the neighbours lack -- so the granules
     // travel while the middle of the range is summed -- and what B2 adds the neighbours' sums to, kept in registers ----
-    constexpr int U = 3;  // ceil(768 / threads) for 256..512 threads
+    // Edge threads: the first 256 of the workgroup, thread t <-> samples t, t + 256, t + 512 of each edge (u = the 256-sample
+    // third, hence which own frames reach it); they travel as ONE 16-byte granule {three samples, tag} per side and thread.
+    constexpr int U = 3, ETHR = 256;
+    const bool edge = tid < ETHR;
     float pl[U], pr[U];
     {
       const bool has_l = !seg_first, has_r = outR != nullptr;
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int k = tid + u * nthr;
+        const int k = tid + u * ETHR;
         pl[u] = pr[u] = 0.f;
-        if (k < GLP_HALO) {
+        if (edge) {
           float v = fb[k];
-          if (W == 4 ? u >= 1 : k >= HOP) v += fb[FBS + k - HOP];           // W == 4: 256 threads, u = the 256-sample third
-          if (W == 4 ? u >= 2 : k >= 2 * HOP) v += fb[2 * FBS + k - 2 * HOP];
+          if (u >= 1) v += fb[FBS + k - HOP];
+          if (u >= 2) v += fb[2 * FBS + k - 2 * HOP];
           pl[u] = v;
-          if (!WIDE_GRANULES && has_l)
-            __hip_atomic_store(outL + (size_t)par * 2 * GLP_HALO + k, ((u64)want << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
           const float l1 = fb[(nb_own - 1) * FBS + HOP + k];
           v = l1;
-          if (W == 4 ? u == 0 : k < HOP) v = (fb[(nb_own - 3) * FBS + 3 * HOP + k] + fb[(nb_own - 2) * FBS + 2 * HOP + k]) + l1;
-          else if (W == 4 ? u == 1 : k < 2 * HOP) v = fb[(nb_own - 2) * FBS + 2 * HOP + k] + l1;
+          if (u == 0) v = (fb[(nb_own - 3) * FBS + 3 * HOP + k] + fb[(nb_own - 2) * FBS + 2 * HOP + k]) + l1;
+          else if (u == 1) v = fb[(nb_own - 2) * FBS + 2 * HOP + k] + l1;
           pr[u] = v;
-          if (!WIDE_GRANULES && has_r)
-            __hip_atomic_store(outR + (size_t)par * 2 * GLP_HALO + k, ((u64)want << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
         }
       }
-      if (WIDE_GRANULES) {  // the thread's three samples of a side and the tag as ONE 16-byte store
+      if (edge) {
         if (has_l) put16(outL, (unsigned)(par * 2 * GLP_HALO) * 8u + 16u * (unsigned)tid, (u32x4){__float_as_uint(pl[0]), __float_as_uint(pl[1]), __float_as_uint(pl[2]), want});
         if (has_r) put16(outR, (unsigned)(par * 2 * GLP_HALO) * 8u + 16u * (unsigned)tid, (u32x4){__float_as_uint(pr[0]), __float_as_uint(pr[1]), __float_as_uint(pr[2]), want});
       }
@@ -778,23 +769,11 @@ __global__ __launch_bounds__(64 * W, PC) void k_gl_persistent(GlBufs g, GlPersis
     // First poll of the neighbours' granules, issued NOW: the loads' round trip (~1 us) overlaps the own overlap-add
     // below; the neighbours run in lock-step with this workgroup, so their stores are usually on their way already.
     // What is not there yet is polled again in B2.
-    constexpr int U0 = WIDE_GRANULES ? 1 : 3;
-    u64 ev_l[U0], ev_r[U0];
     u32x4 qv_l = (u32x4){0u, 0u, 0u, 0u}, qv_r = qv_l;
     auto early_poll = [&]() {
       const u64 *gl0 = inL + (size_t)par * 2 * GLP_HALO, *gr0 = gl0 + GLP_HALO;
-      if (WIDE_GRANULES) {
-        if (!seg_first) qv_l = get16(gl0, 16u * (unsigned)tid);
-        if (outR != nullptr) qv_r = get16(gr0, 16u * (unsigned)tid);
-        ev_l[0] = ev_r[0] = 0ull;
-        return;
-      }
-#pragma unroll
-      for (int u = 0; u < U0; ++u) {
-        const int k = tid + u * nthr;
-        ev_l[u] = (k < GLP_HALO && !seg_first) ? __hip_atomic_load(gl0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-        ev_r[u] = (k < GLP_HALO && outR != nullptr) ? __hip_atomic_load(gr0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-      }
+      if (edge && !seg_first) qv_l = get16(gl0, 16u * (unsigned)tid);
+      if (edge && outR != nullptr) qv_r = get16(gr0, 16u * (unsigned)tid);
     };
     // (the error word the workgroup acts on at the end of B2 is requested here, ahead of the overlap-add: read where it is
     // needed, its round trip -- 0.3 us -- sat between the last LDS store of B2 and the barrier of every iteration)
@@ -832,32 +811,12 @@ __global__ __launch_bounds__(64 * W, PC) void k_gl_persistent(GlBufs g, GlPersis
     // ---- B2: take the neighbours' contributions to the first / last 768 samples, normalise ----
     {
       float hl[U], hr[U];
-      bool dl[U], dr[U];
       const bool has_l = !seg_first, has_r = outR != nullptr;
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int k = tid + u * nthr;
-        const bool in = k < GLP_HALO;
-        hl[u] = hr[u] = 0.f;
-        dl[u] = !(in && has_l);
-        dr[u] = !(in && has_r);
-        if (!WIDE_GRANULES) {
-          if (!dl[u] && (unsigned)(ev_l[u < U0 ? u : 0] >> 32) == want) {  // the early poll already brought it
-            hl[u] = __uint_as_float((unsigned)ev_l[u < U0 ? u : 0]);
-            dl[u] = true;
-          }
-          if (!dr[u] && (unsigned)(ev_r[u < U0 ? u : 0] >> 32) == want) {
-            hr[u] = __uint_as_float((unsigned)ev_r[u < U0 ? u : 0]);
-            dr[u] = true;
-          }
-        }
-      }
       const u64 *gl_ = inL + (size_t)par * 2 * GLP_HALO, *gr_ = gl_ + GLP_HALO;
       unsigned spins = 0;
       GLP_MARK(4);  // middle samples
-      bool pending = false;
-      if (WIDE_GRANULES) {  // one granule per side and thread: {samples tid, tid + 256, tid + 512, tag}
-        bool wl = has_l, wr = has_r;
+      {
+        bool wl = edge && has_l, wr = edge && has_r;
         for (;;) {
           if (wl && qv_l.w == want) wl = false;
           if (wr && qv_r.w == want) wr = false;
@@ -870,44 +829,12 @@ __global__ __launch_bounds__(64 * W, PC) void k_gl_persistent(GlBufs g, GlPersis
         hr[0] = __uint_as_float(qv_r.x), hr[1] = __uint_as_float(qv_r.y), hr[2] = __uint_as_float(qv_r.z);
         if (wl) hl[0] = hl[1] = hl[2] = 0.f;  // (timed out: the launch drains)
         if (wr) hr[0] = hr[1] = hr[2] = 0.f;
-      } else {
-#pragma unroll
-        for (int u = 0; u < U; ++u) pending = pending || !dl[u] || !dr[u];
-      }
-      while (pending) {
-        u64 vl[U], vr[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          if (!dl[u]) vl[u] = __hip_atomic_load(gl_ + tid + u * nthr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (!dr[u]) vr[u] = __hip_atomic_load(gr_ + tid + u * nthr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        bool all = true;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          if (!dl[u]) {
-            if ((unsigned)(vl[u] >> 32) == want) {
-              hl[u] = __uint_as_float((unsigned)vl[u]);
-              dl[u] = true;
-            } else {
-              all = false;
-            }
-          }
-          if (!dr[u]) {
-            if ((unsigned)(vr[u] >> 32) == want) {
-              hr[u] = __uint_as_float((unsigned)vr[u]);
-              dr[u] = true;
-            } else {
-              all = false;
-            }
-          }
-        }
-        if (all || glp_give_up(spins, p.err, limit)) break;
       }
       GLP_MARK(5);  // wait for the neighbours' overlaps
+      if (edge) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int k = tid + u * nthr;
-        if (k < GLP_HALO) {
+        for (int u = 0; u < U; ++u) {
+          const int k = tid + u * ETHR;
           // left neighbour's frames come first in ascending order, the right neighbour's last.  When the
           // block has 3 frames the two edges meet at j = 768 and never overlap (256 n >= 768).
           yb[k] = (has_l ? hl[u] + pl[u] : pl[u]) * ws[k];
