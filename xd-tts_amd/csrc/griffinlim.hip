@@ -829,6 +829,7 @@ __global__ __launch_bounds__(64 * W, PC) void k_gl_persistent(GlBufs g, GlPersis
         hr[0] = __uint_as_float(qv_r.x), hr[1] = __uint_as_float(qv_r.y), hr[2] = __uint_as_float(qv_r.z);
         if (wl) hl[0] = hl[1] = hl[2] = 0.f;  // (timed out: the launch drains)
         if (wr) hr[0] = hr[1] = hr[2] = 0.f;
+        if (wl || wr) s_err[1] = 1;  // a poll of this workgroup gave up (or saw the error word set)
       }
       GLP_MARK(5);  // wait for the neighbours' overlaps
       if (edge) {
@@ -842,8 +843,7 @@ __global__ __launch_bounds__(64 * W, PC) void k_gl_persistent(GlBufs g, GlPersis
           yb[j] = (has_r ? pr[u] + hr[u] : pr[u]) * ws[j];
         }
       }
-      if (tid == 0) s_err[0] = err_seen;  // what thread 0 saw before the overlap-add ...
-      if (spins > 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) s_err[1] = 1;  // ... or a poll of this workgroup that gave up (only threads that had to poll again look)
+      if (tid == 0) s_err[0] = err_seen;  // what thread 0 saw before the overlap-add (or s_err[1]: a poll that gave up)
     }
     __syncthreads();
     GLP_MARK(6);  // finalise + barrier after B
