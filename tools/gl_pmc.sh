@@ -35,6 +35,6 @@ for k in f:
     print("k_gl_persistent<4>: dispatches %d  FETCH_SIZE %.1f KB  WRITE_SIZE %.1f KB  -> corrected traffic %.1f MB per dispatch" % (n, fe, wr, tr / 1e6))
     print("algorithmic bytes (SURVEY 8d: 12 308 B per frame per iteration) = %.1f MB  ->  traffic / algorithmic = %.2f" % (alg / 1e6, tr / alg))
 print("(the state -- S, angles, previous spectrum -- is read once into LDS / registers and never written back; per iteration only the 768-sample overlaps")
-print(" cross between neighbouring workgroups as 8-byte tagged granules, plus their polls)")
+print(" cross between neighbouring workgroups as 16-byte tagged granules {three samples, tag}, plus their polls)")
 PY
 cat $OUT/gl_pmc.txt
