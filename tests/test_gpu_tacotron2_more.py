@@ -44,6 +44,33 @@ def test_gate_stop_rule_matches_oracle(pkg, orc, blob):
         m.close()
 
 
+def test_stop_rule_next_to_the_threshold(pkg, model, orc, blob):
+    """The kernels decide sigmoid(gate) > threshold without the sigmoid when the logit is clear of logit(threshold) (a band of
+    1e-3 (1 + |logit|), device_utils.h: gate_fires) and with the reference's two-branch sigmoid inside it.  Thresholds placed
+    2e-4 below / above the largest logit of a 30-step sequence put that step INSIDE the band on either side of the verdict;
+    a threshold well away takes the short cut.  Frame counts must equal the oracle's every time."""
+    ids = np.zeros(100, dtype=np.int64)
+    ids[:27] = synth_ids(27, seed=6)
+    mem, pm = orc.encoder(blob, ids)
+    _, gates = orc.run_decoder(blob, mem, pm, 27, orc.default_opts(fixed_steps=30, dropout_seed=4))
+    k = int(np.argmax(gates))
+    top, second = float(gates[k]), float(np.sort(gates)[-2])
+    assert top - second > 5e-4  # (no other step comes nearer to the two thresholds around `top` than the step itself)
+    sig = lambda x: float(1.0 / (1.0 + np.exp(-np.float64(x))))
+    first_above = lambda x: next((i + 1 for i, g in enumerate(gates) if g > x), 30)
+    for logit in (top - 2e-4, top + 2e-4, top - 0.05):
+        frames_expected = first_above(logit)
+        thr = np.float32(sig(logit))
+        rf, _ = orc.run_decoder(blob, mem, pm, 27, orc.default_opts(gate_threshold=float(thr), max_steps=30, dropout_seed=4))
+        gf, gg = model.decoder(mem, pm, 27, pkg.default_opts(gate_threshold=float(thr), max_steps=30, dropout_seed=4))
+        assert len(rf) == frames_expected and gf.shape == rf.shape, (logit, len(rf), gf.shape)
+        assert rms(gf, rf) <= 1e-5
+    # degenerate thresholds (no band: always the sigmoid itself): > 1 never fires, < 0 fires at once
+    assert len(model.decoder(mem, pm, 27, pkg.default_opts(gate_threshold=1.5, max_steps=7, dropout_seed=4))[0]) == 7
+    assert len(model.decoder(mem, pm, 27, pkg.default_opts(gate_threshold=-0.5, max_steps=7, dropout_seed=4))[0]) == 1
+    assert len(model.decoder(mem, pm, 27, pkg.default_opts(gate_threshold=0.9999, max_steps=7, dropout_seed=4))[0]) == 7
+
+
 def test_max_steps_cap_and_threshold_option(pkg, model, orc, blob):
     ids = np.zeros(100, dtype=np.int64)
     ids[:20] = synth_ids(20)

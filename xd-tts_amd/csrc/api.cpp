@@ -490,6 +490,16 @@ struct xdtts_tacotron2 {
     d.max_steps = ms;
     d.use_gate = o.fixed_steps > 0 ? 0 : 1;
     d.gate_threshold = o.gate_threshold;
+    {  // gate_fires (device_utils.h): where the verdict needs no sigmoid
+      const double t = (double)o.gate_threshold;
+      d.gate_lo = -INFINITY;  // (an empty band on either side = always the reference's arithmetic)
+      d.gate_hi = INFINITY;
+      if (t > 1e-3 && t < 1.0 - 1e-3) {
+        const double L = std::log(t / (1.0 - t)), w = 1e-3 * (1.0 + std::fabs(L));
+        d.gate_lo = (float)(L - w);
+        d.gate_hi = (float)(L + w);
+      }
+    }
     d.dropout_mode = o.dropout_mode;
     d.dropout_seed = o.dropout_seed;
     d.item_base = o.item_base;
@@ -771,18 +781,15 @@ struct xdtts_tacotron2 {
         } else {
           launch_decoder_persistent(v, w, g, sub_lim, stream);
           if (g.shrink) {
-            // which chunk, if any, is still running?  (ctl[0] = steps executed, nframes[b] = its end)
-            HIP_CHECK(hipMemcpyAsync(host_ctl, d.ctl, sizeof(int) * 2, hipMemcpyDeviceToHost, stream));
-            HIP_CHECK(hipMemcpyAsync(host_ctl + 2, v.nframes, sizeof(int) * n, hipMemcpyDeviceToHost, stream));
-            HIP_CHECK(hipStreamSynchronize(stream));
-            const int done = host_ctl[0];
-            for (int r = 0; r < n; ++r)
-              if (host_ctl[2 + r] > done) {
-                PersistBufs g1 = persist_view(g, r);
-                g1.shrink = 0;
-                launch_decoder_persistent(view(b0 + r, 1), w, g1, lim[b0 + r] - done, stream);
-                break;  // at most one chunk of a pair survives the other
-              }
+            // Which chunk, if any, is still running is on the device (ctl[0] = steps executed, nframes[b] = its end): rather than
+            // ask (a stream sync and two copies, ~0.1 ms of an 6.7 ms utterance) the continuation of BOTH chunks is enqueued --
+            // the 1-chunk kernel returns at once for a chunk that has stopped (at most one survives the other; a survivor that
+            // runs first leaves ctl[0] at its own end, which is past the other's), and stops by itself at the chunk's cap.
+            for (int r = 0; r < n; ++r) {
+              PersistBufs g1 = persist_view(g, r);
+              g1.shrink = 0;
+              launch_decoder_persistent(view(b0 + r, 1), w, g1, lim[b0 + r], stream);
+            }
           }
         }
 #ifdef XDTTS_PERSIST_PROFILE

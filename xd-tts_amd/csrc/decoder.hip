@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void k_prenet(DecoderBufs d, int i, int flush,
   }
   __syncthreads();
   const float gate = s_mel[N_MEL];
-  const bool fired = have_prev && d.use_gate && gate_sigmoid(gate) > d.gate_threshold;
+  const bool fired = have_prev && d.use_gate && gate_fires(gate, d.gate_lo, d.gate_hi, d.gate_threshold);
   if (jblk == 0 && have_prev) {
     if (tid < N_MEL) d.frames[((size_t)b * d.max_steps + (step - 1)) * N_MEL + tid] = s_mel[tid];
     if (tid == 0) {
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(PRENET_BT) void k_prenet_b(DecoderBufs d, int i, in
   }
   __syncthreads();
   const float gate = s_mel[N_MEL];
-  const bool fired = have_prev && d.use_gate && gate_sigmoid(gate) > d.gate_threshold;
+  const bool fired = have_prev && d.use_gate && gate_fires(gate, d.gate_lo, d.gate_hi, d.gate_threshold);
   if (half == 0 && have_prev) {
     if (tid < N_MEL) d.frames[((size_t)b * d.max_steps + (step - 1)) * N_MEL + tid] = s_mel[tid];
     if (tid == 0) {
@@ -1151,7 +1151,7 @@ __device__ __forceinline__ void dec_tail_chunk(const DecoderBufs &d, int step, i
   __syncthreads();
   TPROBE(3);
   const float gate = s_mel[N_MEL];
-  const bool fired = d.use_gate && gate_sigmoid(gate) > d.gate_threshold;
+  const bool fired = d.use_gate && gate_fires(gate, d.gate_lo, d.gate_hi, d.gate_threshold);
   const int nf = d.nframes[b];
   if (part == 0) {
     if (tid < N_MEL) d.frames[((size_t)b * d.max_steps + step) * N_MEL + tid] = s_mel[tid];

@@ -274,6 +274,9 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
 
   // ---- state of the sequence so far (zeros at step 0; a previous launch's write-back otherwise) ----
   const int step0 = d.ctl[0];
+  // A 1-chunk launch on a chunk that has already stopped (the host enqueues the continuation of BOTH chunks of a pair behind the
+  // pair's launch instead of asking which one survived): nothing to do, nothing to write back -- grid-uniform, ahead of the set-up.
+  if (PB == 1 && !(step0 < d.nframes[0])) return;
   if (tid < PB) {
     s_act[tid] = 0;
     s_act[2 + tid] = step0 < d.nframes[tid];  // a stopped chunk is never polled again
@@ -828,7 +831,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       __syncthreads();
       PROF_MARK(11 + 3 * b);  // (role only: mel gathered)
       const float gate = s_mel[N_MEL];
-      const bool fired = d.use_gate && gate_sigmoid(gate) > d.gate_threshold;  // mod.rs:319-324
+      const bool fired = d.use_gate && gate_fires(gate, d.gate_lo, d.gate_hi, d.gate_threshold);  // mod.rs:319-324
       if (rk == 0) {
         if (tid < N_MEL) d.frames[((size_t)b * d.max_steps + s) * N_MEL + tid] = s_mel[tid];
         if (tid == 0) {
@@ -1180,7 +1183,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
         __syncthreads();
         PROF_MARK(11);  // prenet role: mel gathered
         const float gate = s_mel[N_MEL];
-        const bool fired = d.use_gate && gate_sigmoid(gate) > d.gate_threshold;  // mod.rs:319-324
+        const bool fired = d.use_gate && gate_fires(gate, d.gate_lo, d.gate_hi, d.gate_threshold);  // mod.rs:319-324
         if (rk == 0) {
           if (tid < N_MEL) d.frames[((size_t)rb * d.max_steps + s) * N_MEL + tid] = s_mel[tid];
           if (tid == 0) {

@@ -686,7 +686,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent8(DecoderBufs d, P8Buf
       __syncthreads();
       P8_MARK(25);
       const float gate = s_mel[N_MEL];
-      const bool fired = d.use_gate && gate_sigmoid(gate) > d.gate_threshold;  // mod.rs:319-324
+      const bool fired = d.use_gate && gate_fires(gate, d.gate_lo, d.gate_hi, d.gate_threshold);  // mod.rs:319-324
       if (rk == 0) {
         if (tid < N_MEL) d.frames[((size_t)rb * d.max_steps + s) * N_MEL + tid] = s_mel[tid];
         if (tid == 0) {

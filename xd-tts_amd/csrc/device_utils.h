@@ -67,6 +67,16 @@ __device__ __forceinline__ float gate_sigmoid(float x) {
   return e / (1.0f + e);
 }
 
+// The stop rule (mod.rs:319-324): sigmoid(gate) > threshold.  The two-branch sigmoid above is ~100 dependent instructions (libm
+// expf, a division) on the prenet role's critical path of EVERY step -- 0.4 us of a 9 us step -- although its verdict is plain
+// for all but the logits next to logit(threshold): the host passes a band [lo, hi] around that point, 1e-3 (1 + |logit|) wide --
+// a thousand times the f32 sigmoid's own uncertainty there -- and only a logit inside it takes the reference's arithmetic.
+__device__ __forceinline__ bool gate_fires(float x, float lo, float hi, float threshold) {
+  if (x < lo) return false;
+  if (x > hi) return true;
+  return gate_sigmoid(x) > threshold;  // (also NaN: both comparisons above are false)
+}
+
 // Hardware exp2/rcp forms for the few transcendental chains that sit on the per-step critical path
 // (cell updates, energies, softmax).  v_exp_f32 / v_rcp_f32 are 1-ulp instructions; against libm's
 // expf/tanhf the results move by a few 1e-7 absolute, far inside the 1e-4 parity bar, and each cell

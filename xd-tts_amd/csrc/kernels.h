@@ -30,6 +30,7 @@ struct DecoderBufs {
   int max_steps;
   int use_gate;
   float gate_threshold;
+  float gate_lo, gate_hi;  // logits below / above which sigmoid(gate) > gate_threshold is decided without the sigmoid (device_utils.h: gate_fires)
   int dropout_mode;
   uint32_t dropout_seed, item_base;
   // dropout_mode 2: the caller's keep bytes [chunk][drop_steps][2][256] on the device (chunk = index within the call:
