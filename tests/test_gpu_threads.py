@@ -69,8 +69,20 @@ def test_two_handles_and_one_vocoder_interleaved(pkg, blob):
                                 lambda: [m2.infer(reqs[j][0], opts=reqs[j][1]).copy() for j in range(5)]])
     assert all(np.array_equal(x, y) for x, y in zip(got_b, want_b))
     assert all(np.array_equal(x, serial[j][0]) for j, x in enumerate(got_s))
+    # small batches (the 3..8-chunk persistent engine: its grid owns the chip too) on both handles at once, beside each other and
+    # beside single decodes: the chip lock makes the launches take turns, every result keeps its bits, nothing times out
+    ids4 = [synth_ids(22 + 13 * i, seed=30 + i) for i in range(4)]
+    o4 = pkg.default_opts(fixed_steps=21, dropout_seed=8)
+    want4 = [x.copy() for x in m1.infer_batch(ids4, opts=o4)]
+    want5 = [x.copy() for x in m2.infer_batch(ids6[:5], opts=ob)]
+    got4, got5, got1 = run_threads([lambda: [[x.copy() for x in m1.infer_batch(ids4, opts=o4)] for _ in range(3)],
+                                    lambda: [[x.copy() for x in m2.infer_batch(ids6[:5], opts=ob)] for _ in range(3)],
+                                    lambda: [voc.infer(serial[j][0]).copy() for j in range(5)]])
+    assert all(np.array_equal(x, y) for rep in got4 for x, y in zip(rep, want4))
+    assert all(np.array_equal(x, y) for rep in got5 for x, y in zip(rep, want5))
+    assert all(np.array_equal(x, serial[j][1]) for j, x in enumerate(got1))
     for m in (m1, m2):
         st = m.engine_state()
-        assert st["decoder_persistent"] == 1 and st["encoder_cooperative"] == 1 and st["batched_attention"] == 2
+        assert st["decoder_persistent"] == 1 and st["encoder_cooperative"] == 1 and st["batched_attention"] == 2 and st["decoder_persistent8"] == 1
         m.close()
     voc.close()
