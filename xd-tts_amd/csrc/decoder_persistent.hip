@@ -209,7 +209,11 @@ struct PersistWeights {
 // SKEW (PB = 2 only): the two chunks do not run their steps in lock-step but two phases apart, a workgroup alternating
 // between them -- while one chunk's vector crosses the chip the workgroup runs the other chunk's phase instead of sleeping
 // (see the loop at "skewed pair").
-template <int PB, bool SKEW = false>
+// GATE: the stop rule decides (mod.rs:319-324; the reference's mode) -- its verdict through gate_fires, and a 1-chunk launch returns at
+// once for a chunk that has stopped.  The gate-less instantiations (fixed frame counts: parity hooks, benchmarks; d.use_gate = 0)
+// keep the runtime form they were tuned with: with gate_fires compiled in, the hot loop of a gate-less decode was 0.1 us per step
+// slower, and with no stop-rule code at all the skewed pair loop compiled into something that ran 49 us per step.
+template <int PB, bool SKEW = false, bool GATE = false>
 __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, PersistBufs g, PersistWeights w, int nsteps) {
   // static LDS: with compile-time addresses the per-access offsets fold into the ds instructions
   // (a dynamic base made the compiler keep ~100 hoisted addresses live across the step loop)
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
   const int step0 = d.ctl[0];
   // A 1-chunk launch on a chunk that has already stopped (the host enqueues the continuation of BOTH chunks of a pair behind the
   // pair's launch instead of asking which one survived): nothing to do, nothing to write back -- grid-uniform, ahead of the set-up.
-  if (PB == 1 && !(step0 < d.nframes[0])) return;
+  if (GATE && PB == 1 && !(step0 < d.nframes[0])) return;
   if (tid < PB) {
     s_act[tid] = 0;
     s_act[2 + tid] = step0 < d.nframes[tid];  // a stopped chunk is never polled again
@@ -831,7 +835,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
       __syncthreads();
       PROF_MARK(11 + 3 * b);  // (role only: mel gathered)
       const float gate = s_mel[N_MEL];
-      const bool fired = d.use_gate && gate_fires(gate, d.gate_lo, d.gate_hi, d.gate_threshold);  // mod.rs:319-324
+      const bool fired = GATE ? gate_fires(gate, d.gate_lo, d.gate_hi, d.gate_threshold) : (d.use_gate && gate_sigmoid(gate) > d.gate_threshold);  // mod.rs:319-324
       if (rk == 0) {
         if (tid < N_MEL) d.frames[((size_t)b * d.max_steps + s) * N_MEL + tid] = s_mel[tid];
         if (tid == 0) {
@@ -1183,7 +1187,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
         __syncthreads();
         PROF_MARK(11);  // prenet role: mel gathered
         const float gate = s_mel[N_MEL];
-        const bool fired = d.use_gate && gate_fires(gate, d.gate_lo, d.gate_hi, d.gate_threshold);  // mod.rs:319-324
+        const bool fired = GATE ? gate_fires(gate, d.gate_lo, d.gate_hi, d.gate_threshold) : (d.use_gate && gate_sigmoid(gate) > d.gate_threshold);  // mod.rs:319-324
         if (rk == 0) {
           if (tid < N_MEL) d.frames[((size_t)rb * d.max_steps + s) * N_MEL + tid] = s_mel[tid];
           if (tid == 0) {
@@ -1315,7 +1319,8 @@ __global__ void k_pack_ctx_rows(const float4 *__restrict__ att_w, const float4 *
 
 template <int PB, bool SKEW = false>
 void launch_pb(const DecoderBufs &d, const PersistBufs &g, const PersistWeights &pw, int nsteps, hipStream_t s) {
-  COOP_CHECK(launch_coresident(true, reinterpret_cast<const void *>(k_decoder_persistent<PB, SKEW>), dim3(P_NCU), dim3(PT), 0, s, d, g, pw, nsteps));
+  const void *fn = d.use_gate ? reinterpret_cast<const void *>(k_decoder_persistent<PB, SKEW, true>) : reinterpret_cast<const void *>(k_decoder_persistent<PB, SKEW, false>);
+  COOP_CHECK(launch_coresident(true, fn, dim3(P_NCU), dim3(PT), 0, s, d, g, pw, nsteps));
 }
 
 }  // namespace
@@ -1374,7 +1379,7 @@ bool decoder_persistent_supported(int device, int B, int T) {
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) return false;
   if (prop.multiProcessorCount < P_NCU) return false;
   int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_decoder_persistent<PERSIST_B_MAX>, PT, 0) != hipSuccess)
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_decoder_persistent<PERSIST_B_MAX, false, true>, PT, 0) != hipSuccess)
     return false;
   return per_cu >= 1;
 }
