@@ -14,7 +14,7 @@ import re
 import sqlite3
 import sys
 
-DECODER_KERNELS = ("k_decoder_persistent<2, true>", "k_decoder_persistent<1, false>")   # per utterance: one launch each on the bench workload
+DECODER_KERNELS = ("k_decoder_persistent<2, true, false>", "k_decoder_persistent<1, false, false>")   # per utterance: one launch each on the bench workload (PB, SKEW, GATE)
 # (the skewed pair kernel while both chunks run, then the 1-chunk kernel for the survivor; profile `bench.py --no-extras` so that
 #  no other caller of these kernels -- the gate-on variant's trajectory recording -- is averaged in)
 STEPS_PER_LAUNCH = 633                        # bench: chunks [95, 25] -> 633 lock-step iterations
