@@ -145,13 +145,13 @@ def test_persistent_step_hook_refuses_an_inconsistent_context(pkg, model, orc, b
                             np.zeros((3, 80), dtype=np.float32), 0, 1)  # three chunks: not the persistent engine's shape
 
 
-@pytest.mark.parametrize("engine,B", [("persistent", 1), ("persistent", 2), ("launch", 2), ("batched", 6)])
+@pytest.mark.parametrize("engine,B", [("persistent", 1), ("persistent", 2), ("launch", 2), ("persistent8", 3), ("persistent8", 6), ("batched", 9)])
 def test_explicit_dropout_masks_on_every_engine(pkg, orc, blob, engine, B):
     """dropout_mode 2: the caller's keep bytes [chunk][step][layer][unit] replace the seeded stream; every chunk must
     equal the oracle run with ITS masks (the batched engine sorts the chunks by length internally)."""
-    lens = [37, 91, 12, 58, 23, 100][:B]
+    lens = [37, 91, 12, 58, 23, 100, 45, 71, 8][:B]
     ids = [synth_ids(n, seed=61 + i) for i, n in enumerate(lens)]
-    steps = [24, 40, 16, 33, 40, 9][:B]
+    steps = [24, 40, 16, 33, 40, 9, 28, 36, 12][:B]
     rng = np.random.Generator(np.random.PCG64(99))
     masks = (rng.random((B, 40, 2, 256)) < 0.5).astype(np.uint8)
     masks[0, :, 1, :] *= 3  # any non-zero byte keeps
@@ -159,6 +159,8 @@ def test_explicit_dropout_masks_on_every_engine(pkg, orc, blob, engine, B):
     with env(**({"XDTTS_DECODER": "launch"} if engine == "launch" else {})):
         m = pkg.Tacotron2.from_blob(blob)
         mels = m.infer_batch(ids, opts=o, fixed_steps=np.array(steps, dtype=np.int32))
+        st = m.engine_state()
+        assert st["decoder_persistent8"] == (1 if engine == "persistent8" else -1), st  # (the batch ran on the engine the label names)
         m.close()
     for b in range(B):
         ref = orc.infer_chunk(blob, ids[b], orc.default_opts(fixed_steps=steps[b], masks=masks[b]))

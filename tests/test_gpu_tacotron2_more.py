@@ -287,15 +287,28 @@ def test_batch_beyond_one_mfma_pass(pkg, model, orc, blob):
         assert rms(mels[b], ref) <= 1e-5, b
 
 
-@pytest.mark.parametrize("n", [5, 64])
-def test_one_launch_attention_at_the_batch_size_limits(pkg, model, orc, blob, n):
+def _handle(pkg, blob, p8):
+    """a handle with the 3..8-chunk persistent engine on ("1") or off ("0": such batches then take the engines either side)"""
+    os.environ["XDTTS_P8"] = p8  # read when the handle is created
+    try:
+        return pkg.Tacotron2.from_blob(blob)
+    finally:
+        del os.environ["XDTTS_P8"]
+
+
+@pytest.mark.parametrize("n", [5, 9, 64])
+def test_one_launch_attention_at_the_batch_size_limits(pkg, orc, blob, n):
     """5 chunks is the smallest lock-step batch of the MFMA path (20 of the 256 blocks of k_att_lstm_attention turn
-    into attention blocks), 64 the largest that keeps the attention LSTM and the attention in one launch (all 256 do)."""
+    into attention blocks; with the 3..8-chunk engine off -- by default 9 is the smallest), 64 the largest that keeps the
+    attention LSTM and the attention in one launch (all 256 do)."""
     rng = np.random.Generator(np.random.PCG64(40 + n))
     ids_list = [synth_ids(int(x), seed=700 + i) for i, x in enumerate(rng.integers(4, 90, size=n))]
     steps = [int(x) for x in rng.integers(3, 10, size=n)]
+    model = _handle(pkg, blob, "0" if n == 5 else "1")
     mels = model.infer_batch(ids_list, opts=pkg.default_opts(dropout_seed=37), fixed_steps=steps)
-    assert model.engine_state()["batched_attention"] == 2
+    st = model.engine_state()
+    model.close()
+    assert st["batched_attention"] == 2 and st["decoder_persistent8"] == (0 if n == 5 else -1)
     assert [m.shape for m in mels] == [(80, s) for s in steps]
     for b in sorted({0, 1, n // 2, n - 2, n - 1}):
         ref = orc.infer_chunk(blob, ids_list[b], orc.default_opts(fixed_steps=steps[b], dropout_seed=37, item=b))
@@ -329,14 +342,18 @@ def test_onnx_export_converts_and_loads(pkg, model, blob, tmp_path):
     assert np.array_equal(got, want)
 
 
-def test_batched_path_with_a_smaller_window(pkg, model, orc, blob):
-    """The batched MFMA path (>= 5 chunks) with max_chunk = 50: encoder window, mask, location tiles and the
-    operand-order activation copies all follow T; every chunk still equals its own oracle run."""
+@pytest.mark.parametrize("p8", ["0", "1"])
+def test_batched_path_with_a_smaller_window(pkg, orc, blob, p8):
+    """Seven chunks with max_chunk = 50 on the batched MFMA path (XDTTS_P8=0) and on the 3..8-chunk persistent engine: encoder
+    window, mask, location tiles and the operand-order activation copies all follow T; every chunk still equals its own oracle run."""
     lens = [50, 7, 33, 48, 21, 50, 12]
     ids_list = [synth_ids(n, seed=90 + i) for i, n in enumerate(lens)]
     steps = [18, 5, 11, 20, 9, 14, 16]
     o = pkg.default_opts(dropout_seed=23, item_base=2, max_chunk=50)
+    model = _handle(pkg, blob, p8)
     mels = model.infer_batch(ids_list, opts=o, fixed_steps=steps)
+    assert model.engine_state()["decoder_persistent8"] == int(p8)
+    model.close()
     for b, (ids, st) in enumerate(zip(ids_list, steps)):
         ref = orc.infer_chunk(blob, ids, orc.default_opts(fixed_steps=st, dropout_seed=23, item=2 + b), window=50)
         assert mels[b].shape == (80, st) and rms(mels[b], ref) <= 1e-5, b
