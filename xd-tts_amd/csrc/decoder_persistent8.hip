@@ -81,8 +81,10 @@ __device__ __forceinline__ bool give_up(unsigned &spins, const PollCtl &pc) {
 // is never delivered.  EVERY round issues all N loads (a granule that is not wanted, or has been delivered, is asked for again --
 // or the first wanted one in its place): with the loads themselves under per-lane conditions, lanes were handed the value of
 // ANOTHER granule of the same round now and then (four neighbouring lanes = one 32-byte sector at a time, caught by comparing
-// the LDS copy with the granule it came from: the chunk-1 value in chunk 0's place) -- the wait counts of a round assume its
-// loads were all issued.
+// the LDS copy with the granule it came from: the chunk-1 value in chunk 0's place).  That was a 512-thread build that spilled
+// 1.3 kB per lane; the form alone does not misdeliver (tools/ubench_condload.hip: 0 wrong values in 2 x 3000 x 256 gathers of
+// 4..32 granules per thread, conditional or not), so the culprit was probably the spill code around the divergent loads -- the
+// kernel as it is has no scratch, and keeps the unconditional form.
 __device__ __forceinline__ void nap(int n) {
 #pragma unroll 1
   for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
