@@ -190,10 +190,28 @@ int main(int argc, char **argv) {
   float *out;
   int *err;
   const size_t ring_bytes = (size_t)iters * 8 * K * sizeof(unsigned);
-  CHECK(hipMalloc(&gran, sizeof(u64) * 2 * 8 * K));
-  CHECK(hipMalloc(&ring, ring_bytes));
+  // argv[2]: allocation flavour of the exchange memory: 0 hipMalloc, 1 hipDeviceMallocUncached, 2 hipDeviceMallocFinegrained
+  const int flavour = argc > 2 ? atoi(argv[2]) : 0;
+  if (flavour == 0) {
+    CHECK(hipMalloc(&gran, sizeof(u64) * 2 * 8 * K));
+    CHECK(hipMalloc(&ring, ring_bytes));
+  } else {
+    const unsigned fl = flavour == 1 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained;
+    CHECK(hipExtMallocWithFlags((void **)&gran, sizeof(u64) * 2 * 8 * K, fl));
+    CHECK(hipExtMallocWithFlags((void **)&ring, ring_bytes, fl));
+  }
+  printf("exchange memory: %s\n", flavour == 0 ? "hipMalloc" : flavour == 1 ? "hipDeviceMallocUncached" : "hipDeviceMallocFinegrained");
   CHECK(hipMalloc(&out, sizeof(float) * NCU));
   CHECK(hipMalloc(&err, sizeof(int)));
+  if (argc > 3) {  // short form: the engines' cases only
+    for (int nap : {8, 12, 16, 20}) {
+      run<0, 1, 0>(iters, nap, gran, ring, ring_bytes, out, err, "8-B granules, 8-B sc1 loads");
+      run<0, 2, 0>(iters, nap, gran, ring, ring_bytes, out, err, "8-B granules, 8-B sc1 loads");
+      run<2, 4, 16>(iters, nap, gran, ring, ring_bytes, out, err, "ring of values, 16-B loads, first sc1");
+      run<2, 8, 16>(iters, nap, gran, ring, ring_bytes, out, err, "ring of values, 16-B loads, first sc1");
+    }
+    return 0;
+  }
   for (int nap : {0, 8, 12, 16, 20, 24}) {
     run<0, 1, 0>(iters, nap, gran, ring, ring_bytes, out, err, "8-B granules, 8-B sc1 loads");
     run<1, 1, 0>(iters, nap, gran, ring, ring_bytes, out, err, "8-B granules, 16-B sc1 loads");
