@@ -48,7 +48,7 @@ __global__ __launch_bounds__(PT) void k_ag(u64 *gran, unsigned *ring, int iters,
     // publish: wave 0, lane = (chunk b = lane / 4, unit u = lane % 4)
     if (tid < 4 * NB) {
       const int b = tid >> 2, u = tid & 3;
-      if (VAR <= 1) {
+      if (VAR <= 1 || VAR == 3) {
         __hip_atomic_store(gran + (size_t)(p * NB + b) * K + 4 * c + u, ((u64)want << 32) | (u64)__float_as_uint(val + u), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
       } else {
@@ -64,6 +64,52 @@ __global__ __launch_bounds__(PT) void k_ag(u64 *gran, unsigned *ring, int iters,
       while (pending) {
         u64 v[N];
         unsigned zero = 0;
+        asm volatile("" : "+v"(zero));
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = __hip_atomic_load(base + (zero + i * PT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          if (((pending >> i) & 1u) && (unsigned)(v[i] >> 32) == want) {
+            s_h[i * PT + tid] = __uint_as_float((unsigned)v[i]);
+            pending &= ~(1u << i);
+          }
+        if (pending && ++spins > (1u << 20)) {
+          atomicExch(err, 1);
+          break;
+        }
+        if (pending) __builtin_amdgcn_s_sleep(1);
+      }
+    } else if (VAR == 3) {
+      // 8-byte granules, TWO rounds of polls in flight `FIRST_AUX` x 64 clocks apart: a first round that comes too early then
+      // costs that gap, not a round trip
+      constexpr int N = 4 * NB;
+      unsigned pending = N == 32 ? 0xffffffffu : (1u << (N & 31)) - 1u;
+      const u64 *base = gran + (size_t)p * NB * K + tid;
+      u64 va[N], vb[N];
+      unsigned zero = 0;
+      asm volatile("" : "+v"(zero));
+#pragma unroll
+      for (int i = 0; i < N; ++i) va[i] = __hip_atomic_load(base + (zero + i * PT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int i = 0; i < FIRST_AUX; ++i) __builtin_amdgcn_s_sleep(1);
+      asm volatile("" : "+v"(zero));
+#pragma unroll
+      for (int i = 0; i < N; ++i) vb[i] = __hip_atomic_load(base + (zero + i * PT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int i = 0; i < N; ++i)
+        if ((unsigned)(va[i] >> 32) == want) {
+          s_h[i * PT + tid] = __uint_as_float((unsigned)va[i]);
+          pending &= ~(1u << i);
+        }
+      if (pending) {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          if (((pending >> i) & 1u) && (unsigned)(vb[i] >> 32) == want) {
+            s_h[i * PT + tid] = __uint_as_float((unsigned)vb[i]);
+            pending &= ~(1u << i);
+          }
+      }
+      while (pending) {
+        u64 v[N];
         asm volatile("" : "+v"(zero));
 #pragma unroll
         for (int i = 0; i < N; ++i) v[i] = __hip_atomic_load(base + (zero + i * PT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -139,7 +185,7 @@ __global__ __launch_bounds__(PT) void k_ag(u64 *gran, unsigned *ring, int iters,
     for (int j = 0; j < 4; ++j) {
       const int k = tid * 4 + j;  // value index within the vector: workgroup k / 4, unit k % 4
       float got;
-      if (VAR == 0) got = s_h[(k / PT) * PT + (k % PT)];  // i = k / 256 (chunk 0: i < 4), tid' = k % 256
+      if (VAR == 0 || VAR == 3) got = s_h[(k / PT) * PT + (k % PT)];  // i = k / 256 (chunk 0: i < 4), tid' = k % 256
       else if (VAR == 1) got = s_h[k];                      // pairs in order
       else got = s_h[k];
       const float expect = (float)((s * 7 + (k >> 2)) & 1023) + (float)(k & 3);
@@ -203,6 +249,17 @@ int main(int argc, char **argv) {
   printf("exchange memory: %s\n", flavour == 0 ? "hipMalloc" : flavour == 1 ? "hipDeviceMallocUncached" : "hipDeviceMallocFinegrained");
   CHECK(hipMalloc(&out, sizeof(float) * NCU));
   CHECK(hipMalloc(&err, sizeof(int)));
+  if (argc > 3 && argv[3][0] == 'd') {  // staggered double polls against single ones, 1 and 2 chunks
+    for (int nap : {4, 6, 8, 10, 12, 14, 16, 20}) {
+      run<0, 1, 0>(iters, nap, gran, ring, ring_bytes, out, err, "8-B granules, one poll round");
+      run<3, 1, 4>(iters, nap, gran, ring, ring_bytes, out, err, "8-B granules, two rounds 4 x 64 clocks apart");
+      run<3, 1, 8>(iters, nap, gran, ring, ring_bytes, out, err, "8-B granules, two rounds 8 x 64 clocks apart");
+      run<0, 2, 0>(iters, nap, gran, ring, ring_bytes, out, err, "8-B granules, one poll round");
+      run<3, 2, 4>(iters, nap, gran, ring, ring_bytes, out, err, "8-B granules, two rounds 4 x 64 clocks apart");
+      run<3, 2, 8>(iters, nap, gran, ring, ring_bytes, out, err, "8-B granules, two rounds 8 x 64 clocks apart");
+    }
+    return 0;
+  }
   if (argc > 3) {  // short form: the engines' cases only
     for (int nap : {8, 12, 16, 20}) {
       run<0, 1, 0>(iters, nap, gran, ring, ring_bytes, out, err, "8-B granules, 8-B sc1 loads");
