@@ -9,13 +9,14 @@
 // 16 gate rows of attention-LSTM units 4c..4c+3 and of decoder-LSTM units 4c..4c+3 with their weights in REGISTERS for the
 // whole loop; the state crosses CUs through memory that every workgroup polls; roles per chunk on top of the LSTM slices -- and
 // changes the three things that do not scale with the chunk count there:
-//   * the LSTM pre-activations of ALL chunks are one v_mfma_f32_16x16x4_f32 stream per wave: the wave's 16 x (K/8) weight
-//     slab is the A operand (136 VGPRs per lane, the same budget as the dot-product form), the chunks' state vectors in LDS
-//     in [k/4][8 chunks][4] order are the B operand (one ds_read_b128 feeds four MFMAs; columns 8..15 of the tile carry
-//     don't-care values that nothing reads), the 16 x 16 D tile holds unit u = lane / 16, chunk n = lane % 16, gates i,f,g,o
-//     in a lane's four registers -- so the eight K-slices meet in LDS and wave 0 does every cell update in registers.
-//     272 MFMAs per wave and step (3.6 us of a SIMD's matrix pipe, one wave per SIMD with 512 registers: the 272 weights sit in
-//     AGPRs) whatever the number of chunks;
+//   * the LSTM pre-activations of ALL chunks are one v_mfma_f32_16x16x4_f32 stream per wave: the wave's 16 x (K/4) weight
+//     slab of both LSTMs is the A operand (272 registers per lane: four waves per workgroup, one per SIMD, each with the whole
+//     512-register file -- the weights mostly in AGPRs; as eight waves of 256 registers the kernel spilled 1.3 kB per lane
+//     and ran 57 us per step), the chunks' state vectors in LDS in [k/4][NB chunk slots][4] order are the B operand (one
+//     ds_read_b128 feeds four MFMAs; columns beyond NB of the tile carry don't-care values that nothing reads), the 16 x 16 D
+//     tile holds unit u = lane / 16, chunk n = lane % 16, gates i,f,g,o in a lane's four registers -- so the four K-slices
+//     meet in LDS and wave 0 does every cell update in registers.  272 MFMAs per wave and step (3.6 us of a SIMD's matrix
+//     pipe) whatever the number of chunks; two instances, NB = 4 and NB = 8 chunk slots;
 //   * the attention context crosses as a SIXTH edge (512 values per chunk, from the chunk's 8 attention workgroups) instead
 //     of being folded into the encoder memory: the fold tables cost 20 registers or 16 kB of LDS per chunk.  In exchange the
 //     partial energies only travel among a chunk's own 8 attention workgroups, which are the only ones that need the softmax.
@@ -28,8 +29,8 @@
 //     8 attention workgroups, mel rows among its 16 projection workgroups) stay data-tagged 8-byte granules.
 // Per step:  x -> [attention LSTM] -> h_att -> [query, energies] -> e -> [softmax, context] -> ctx -> [decoder LSTM] -> h_dec
 //            -> [projection rows] -> mel -> [stop rule, prenet] -> x(s+1)
-// Only the columns of the newest vector are multiplied on the critical path (8 / 16 MFMAs per wave); the others are
-// accumulated while the next vector's producers are busy.  Every spin is bounded and watches a global error word.
+// Only the columns of the newest vector are multiplied on the critical path (x: 16 MFMAs per wave, ctx -> decoder LSTM: 32); the
+// others are accumulated while the next vector's producers are busy.  Every spin is bounded and watches a global error word.
 #include <cstdio>
 #include <cstdlib>
 
