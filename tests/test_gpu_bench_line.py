@@ -1,0 +1,40 @@
+"""The driver's contract for `python bench.py` (one GPU, default flags but fewer steps): ONE JSON line on stdout with the
+headline metric of BASELINE.json configs[1], the `roofline` object of the dominant kernel and the `cpu_baseline` object
+(the oracle timed on a bounded sample) -- checked field by field, so that a change to bench.py that breaks the line is caught
+here and not at round end."""
+import json
+import math
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_prints_one_contract_line():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-extras"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    with open(os.path.join(ROOT, "BASELINE.json")) as fh:
+        base = json.load(fh)
+    assert "mel-frames/s" in out["metric"] and "mel-frames/s" in base["metric"]
+    assert out["unit"] == "mel-frames/s" and out["higher_is_better"] is True and out["scaling"] == "weak"
+    assert (out["n_gpus"], out["steps"], out["warmup"]) == (1, 3, 1)
+    assert out["value"] > 50_000 and abs(out["value"] * out["ms_per_step"] * 1e-3 - 800) < 1.0   # 800 frames per step (utterance)
+    assert out["vs_baseline"] is None and base["published"] == {}                                 # no published number for this metric
+    assert out["dtype"] == "f32" and out["data"].startswith("synthetic")
+    assert "configs[1]" in out["config"]["workload"] and "model" not in out["config"]
+    rl = out["roofline"]
+    assert rl["bound"] in ("hbm", "mfma", "latency") and rl["unit"] in ("GB/s", "TFLOP/s")
+    assert 0.0 < rl["frac"] <= 1.0 and rl["achieved"] > 0 and rl["peak"] > 0
+    assert rl["traffic"] is None or rl["traffic"] > 0
+    assert math.isclose(rl["frac"], rl["frac_of_floor"], rel_tol=1e-9) and rl["latency_floor_us"] > 0   # this kernel's ruler
+    cb = out["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["unit"] == "mel-frames/s" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    assert out["value"] > 20 * cb["value"]   # (north_star: >= 20x real time is a far lower bar; the CPU port runs ~1.5x real time per core)
