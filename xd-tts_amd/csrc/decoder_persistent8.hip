@@ -734,7 +734,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent8(DecoderBufs d, P8Buf
       if (lane < 4) s_mel[MEL_GL - 16 + wave + NW * lane] = lane == 0 ? xo[0] : (lane == 1 ? xo[1] : (lane == 2 ? xo[2] : xo[3]));  // s_mel[81..95] is unused padding
       __syncthreads();
       if (tid < 16)
-        put(g.rx + ((size_t)(s + 1 - step0) * NB + rb) * PRENET + 16 * rk + tid, value_bits(s_mel[MEL_GL - 16 + tid]) | (nxt ? 0u : 0x80000000u));
+        put(g.rx + ((size_t)(s + 1 - step0) * NB + rb) * PRENET + 16 * rk + tid, (value_bits(s_mel[MEL_GL - 16 + tid]) & 0x7fffffffu) | (nxt ? 0u : 0x80000000u));  // (x >= 0; a -0.0 must not read as "stopped")
     }
     P8_MARK(16);
 #ifdef XDTTS_P8_PROFILE
