@@ -508,6 +508,27 @@ def main():
                 ms = model.last_timings()["decoder_ms"]
                 sb["runs"].append({"chunks": B, "us_per_iteration": ms * 1e3 / 200, "mel_frames_per_s": B * 200 / (ms * 1e-3)})
             sb["engine"] = "k_decoder_persistent8 (one persistent launch, LSTMs of all chunks on the matrix cores)" if model.engine_state()["decoder_persistent8"] == 1 else "fallback engines"
+            # four sentences that arrive together: one xdtts_synthesize_batch call against four xdtts_synthesize_ids calls
+            import time as _t
+            four = [wl.synth_ids(95, seed=30 + u) for u in range(4)]
+            o4 = pkg.default_opts(fixed_frames_per_id=wl.FRAMES_PER_ID, dropout_seed=0)
+            st4 = [[int(round(wl.FRAMES_PER_ID * 95))]] * 4
+            for _ in range(2):
+                pkg.synthesize_batch(model, vocoder, [[u] for u in four], opts=o4, fixed_steps=st4, want_mels=False)
+            t0 = _t.perf_counter()
+            for _ in range(3):
+                _, au = pkg.synthesize_batch(model, vocoder, [[u] for u in four], opts=o4, fixed_steps=st4, want_mels=False)
+            tb = (_t.perf_counter() - t0) / 3
+            for u in four:
+                pkg.synthesize(model, vocoder, u, opts=o4)
+            t0 = _t.perf_counter()
+            for _ in range(3):
+                for u in four:
+                    pkg.synthesize(model, vocoder, u, opts=o4)
+            ts = (_t.perf_counter() - t0) / 3
+            fr = 4 * st4[0][0]
+            sb["four_sentences"] = {"what": "4 utterances of 95 ids (633 frames each), 60-iteration Griffin-Lim: one batched call against four single calls, host wall clock",
+                                    "batched_call_ms": tb * 1e3, "four_single_calls_ms": ts * 1e3, "mel_frames_per_s_batched": fr / tb, "mel_frames_per_s_single_calls": fr / ts}
             extra["small_batches"] = sb
             log("small batches done")
           except Exception as e:  # noqa: BLE001
