@@ -253,7 +253,8 @@ xdtts_status xdtts_griffinlim_new(const float *mel_basis, size_t n_mels, size_t 
  *                   for the batch at hand (the overlap-add then sums in a different order than the single call:
  *                   same audio within the fp32 drift of DESIGN.md section 2, not bit for bit)
  *                   4: always the shape of the single-utterance call: every audio of a batch is bit-identical to
- *                   xdtts_griffinlim_infer on that utterance alone (about 1.5x the time on a large batch) */
+ *                   xdtts_griffinlim_infer on that utterance alone (the same time when its workgroups run two per CU, up to 1.6x
+ *                   on a device that admits only one per CU) */
 typedef struct {
   int32_t nnls_iters;
   int32_t power_mode;
