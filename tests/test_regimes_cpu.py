@@ -74,4 +74,4 @@ def test_speech_like_mel_has_a_floor_and_a_voice(orc):
     assert np.mean(mel < -11.0) > 0.2
     basis = orc.mel_filter_bank()
     raw = orc.pinv(basis).astype(np.float64) @ np.exp(mel.astype(np.float64))
-    assert np.mean(raw < 0) > 0.05      # the pseudo-inverse goes negative: the clip of mel->linear is exercised
+    assert np.mean(raw < 0) > 0.01      # the pseudo-inverse goes negative: the clip of mel->linear is exercised
