@@ -31,10 +31,10 @@ def test_bench_prints_one_contract_line():
     assert out["dtype"] == "f32" and out["data"].startswith("synthetic")
     assert "configs[1]" in out["config"]["workload"] and "model" not in out["config"]
     rl = out["roofline"]
-    assert rl["bound"] in ("hbm", "mfma", "latency") and rl["unit"] in ("GB/s", "TFLOP/s")
-    assert 0.0 < rl["frac"] <= 1.0 and rl["achieved"] > 0 and rl["peak"] > 0
+    assert rl["bound"] in ("hbm", "mfma") and rl["unit"] in ("GB/s", "TFLOP/s")
+    assert rl["achieved"] > 0 and rl["peak"] > 0 and math.isclose(rl["frac"], rl["achieved"] / rl["peak"], rel_tol=1e-9)   # the contract's definition, unclamped
     assert rl["traffic"] is None or rl["traffic"] > 0
-    assert math.isclose(rl["frac"], rl["frac_of_floor"], rel_tol=1e-9) and rl["latency_floor_us"] > 0   # this kernel's ruler
+    assert 0.0 < rl["frac_of_floor"] < 1.2 and rl["latency_floor_us"] > 0   # this kernel's ruler, under its own key
     cb = out["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["unit"] == "mel-frames/s" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
     assert out["value"] > 20 * cb["value"]   # (north_star: >= 20x real time is a far lower bar; the CPU port runs ~1.5x real time per core)

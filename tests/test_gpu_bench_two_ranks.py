@@ -41,7 +41,7 @@ def test_bench_two_ranks_on_one_gpu(pkg, tmp_path):
     assert len(lines) == 1, r.stdout[-2000:]          # ONE JSON line, from rank 0
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["cpu_baseline"] is None
-    assert out["value"] > 0 and out["roofline"]["frac"] is not None and out["roofline"]["frac"] <= 1.0
+    assert out["value"] > 0 and out["roofline"]["frac"] > 0 and out["roofline"]["frac_of_floor"] > 0   # (the floor is measured while the other rank shares the GPU: no upper bound here)
     assert os.path.exists(tmp_path / "model" / "tacotron2.xdtw")
     # the engines stayed on their fast paths (no exchange timed out into a fallback while the two ranks shared the GPU)
     assert "timed out" not in r.stderr and "refused" not in r.stderr, r.stderr[-3000:]

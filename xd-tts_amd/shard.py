@@ -22,7 +22,7 @@ def gather_counters(local, dist=None, device="cpu"):
     `dist` is torch.distributed (already initialised) or None for a single process."""
     keys = ("frames", "samples", "seconds")
     vec = [float(local[k]) for k in keys]
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():      # (a world of one rank still goes through the collective: bench.py XDTTS_BENCH_FORCE_DIST)
         rows = [vec]
     else:
         import torch
