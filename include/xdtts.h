@@ -243,8 +243,11 @@ xdtts_status xdtts_griffinlim_new(const float *mel_basis, size_t n_mels, size_t 
  *   power_mode      0: S = x^(1/power) (librosa mel_to_stft)   1: S = x^power   2: S = x
  *   mel_decompress  0: m = exp(mel) (Tacotron2's ln compression)   1: m = mel   2: m = 10^mel
  *   output_normalise  (G6: the last step of GriffinLim::infer before src/lib.rs:155 scales by i16::MAX)
- *                   0: audio as is   1: audio / max|audio|   2: audio * rms_target / rms(audio)   [default 2]
- *   rms_target      0.1 = -20 dBFS.  Why 2 / 0.1: the only outputs of this path the reference holds --
+ *                   0: audio as is   1: audio / max|audio|   2: audio * rms_target / rms(audio)
+ *                   3: like 2, the scale limited to 1 / max|audio| so that no sample leaves [-1, 1]   [default 3]
+ *                   (2 and 3 differ only for a crest factor above 1 / rms_target = 20 dB -- an utterance that is mostly
+ *                   pause -- where 2 would hand src/lib.rs:155's saturating cast samples beyond +-1 to clip)
+ *   rms_target      0.1 = -20 dBFS.  Why rms / 0.1: the only outputs of this path the reference holds --
  *                   slides/audio/goodbye.wav and capital_nonsense.wav, both exactly WAV_SPEC (src/lib.rs:25-30) -- sit
  *                   at RMS 0.099994 and 0.099995 of full scale with peaks 0.82 and 0.61: an RMS-0.1 signal after the
  *                   truncating `as i16` cast (tests/golden/reference_audio_facts.json, tools/reference_audio_facts.py)

@@ -915,7 +915,8 @@ void orc_griffinlim(const real *S, const real *phase0, uint32_t seed, int F, int
 /* G6 -- the last step of GriffinLim::infer (src/lib.rs:141) before src/lib.rs:155 scales by i16::MAX.
  * The crate is absent (Cargo.lock:666-668); the reference's own WAV_SPEC files (slides/audio/goodbye.wav,
  * capital_nonsense.wav: RMS 0.099994 / 0.099995 of full scale, peaks 0.82 / 0.61) say "RMS = 0.1".
- * mode 0: as is; 1: y / max|y|; 2: y * target / sqrt(mean(y^2)).  Sums in double in both builds. */
+ * mode 0: as is; 1: y / max|y|; 2: y * target / sqrt(mean(y^2)); 3: mode 2 with the scale limited to 1 / max|y|, so that
+ * no sample leaves [-1, 1] (where src/lib.rs:155's saturating `as i16` cast would clip).  Sums in double in both builds. */
 void orc_output_normalise(real *y, size_t n, int mode, double target) {
   if (mode == 1) {
     real peak = 0;
@@ -925,12 +926,18 @@ void orc_output_normalise(real *y, size_t n, int mode, double target) {
     }
     if (peak > 0)
       for (size_t i = 0; i < n; ++i) y[i] = y[i] / peak;
-  } else if (mode == 2 && n > 0) {
-    double ss = 0;
-    for (size_t i = 0; i < n; ++i) ss += (double)y[i] * (double)y[i];
+  } else if ((mode == 2 || mode == 3) && n > 0) {
+    double ss = 0, peak = 0;
+    for (size_t i = 0; i < n; ++i) {
+      ss += (double)y[i] * (double)y[i];
+      double a = y[i] < 0 ? -(double)y[i] : (double)y[i];
+      if (a > peak) peak = a;
+    }
     double r = sqrt(ss / (double)n);
     if (r > 0) {
-      real sc = (real)(target / r);
+      double scd = target / r;
+      if (mode == 3 && scd * peak > 1.0) scd = 1.0 / peak;
+      real sc = (real)scd;
       for (size_t i = 0; i < n; ++i) y[i] = y[i] * sc;
     }
   }

@@ -45,9 +45,9 @@ def test_full_infer_from_mel(pkg, voc, orc):
     audio = voc.infer(mel)
     S = orc.mel_to_linear(orc.pinv(orc.mel_filter_bank()), mel, power=1.7)
     raw = orc.griffinlim(S, seed=5, iters=30)
-    ref = orc.output_normalise(raw, mode=2, target=0.1)  # G6: the handle's default (rms 0.1)
+    ref = orc.output_normalise(raw, mode=3, target=0.1)  # G6: the handle's default (rms 0.1, never past +-1)
     d = voc.get_opts()
-    assert d.output_normalise == 2 and d.rms_target == np.float32(0.1)
+    assert d.output_normalise == 3 and d.rms_target == np.float32(0.1)
     assert audio.shape == ref.shape == (256 * (F - 1),)
     assert rms(audio, ref) <= 1e-4 * 0.1 / float(np.sqrt(np.mean(raw.astype(np.float64) ** 2))) and rms(audio, ref) <= 1e-4
     assert abs(float(np.sqrt(np.mean(audio.astype(np.float64) ** 2))) - 0.1) <= 1e-6
@@ -133,7 +133,7 @@ def test_mel_to_linear_options_match_the_oracle(pkg, orc):
     F = 70
     mel = (rng.uniform(-7.0, -1.0, size=(80, F)) + 1.5 * np.sin(np.arange(F) / 4.0)[None, :]).astype(np.float32)
     d = v.get_opts()
-    assert (d.nnls_iters, d.power_mode, d.mel_decompress, d.output_normalise) == (0, 0, 0, 2)
+    assert (d.nnls_iters, d.power_mode, d.mel_decompress, d.output_normalise) == (0, 0, 0, 3)
     base = v.mel_to_linear(mel)
     scale = float(np.sqrt(np.mean(base.astype(np.float64) ** 2)))
     for kw in (dict(), dict(power_mode=1), dict(power_mode=2), dict(mel_decompress=1), dict(mel_decompress=2),

@@ -23,13 +23,15 @@ def test_every_mode_of_the_single_call_matches_the_oracle(pkg, orc):
         v.set_opts(output_normalise=0)
         raw = v.infer(mel)
         assert raw.shape == (256 * (F - 1),) and _rms(raw) > 0
-        for mode, target in ((1, 0.1), (2, 0.1), (2, 0.25)):
+        for mode, target in ((1, 0.1), (2, 0.1), (2, 0.25), (3, 0.1), (3, 0.6)):
             v.set_opts(output_normalise=mode, rms_target=target)
             got = v.infer(mel)
             ref = orc.output_normalise(raw, mode=mode, target=target)
             assert np.abs(got - ref).max() <= 4e-7 * float(np.abs(ref).max()), (F, mode)
-            if mode == 2:
+            if mode == 2 or (mode == 3 and target == 0.1):
                 assert abs(_rms(got) - target) <= 2e-7 * target / 0.1 + 1e-7
+            elif mode == 3:   # rms 0.6 would push the peaks past 1: the scale stops at 1 / max|y| (no sample for the i16 cast to clip)
+                assert abs(float(np.abs(got).max()) - 1.0) <= 2e-7 and _rms(got) < target and float(np.abs(orc.output_normalise(raw, mode=2, target=target)).max()) > 1.0
             else:
                 assert float(np.abs(got).max()) == 1.0
         v.set_opts(output_normalise=2, rms_target=0.1)
@@ -37,7 +39,7 @@ def test_every_mode_of_the_single_call_matches_the_oracle(pkg, orc):
         # xdtts_griffinlim_infer_linear is the loop alone (G2..G5): never normalised
         S = v.mel_to_linear(mel)
         assert np.array_equal(v.infer_linear(S), raw)
-    for bad in (dict(output_normalise=3), dict(output_normalise=-1), dict(rms_target=0.0), dict(rms_target=float("nan"))):
+    for bad in (dict(output_normalise=4), dict(output_normalise=-1), dict(rms_target=0.0), dict(rms_target=float("nan"))):
         with pytest.raises(pkg.XdttsError) as e:
             v.set_opts(**bad)
         assert e.value.status == pkg.XDTTS_ERR_BAD_ARG
@@ -55,7 +57,7 @@ def test_a_vocoder_batch_normalises_each_utterance_on_its_own(pkg, orc):
     raw = v.infer_batch(mels)
     levels = [_rms(a) for a in raw]
     assert max(levels) > 1.5 * min(levels)
-    for mode in (2, 1):
+    for mode in (2, 1, 3):
         v.set_opts(batch_shape=4, output_normalise=mode)
         got = v.infer_batch(mels)
         single = [v.infer(m) for m in mels]
@@ -65,7 +67,11 @@ def test_a_vocoder_batch_normalises_each_utterance_on_its_own(pkg, orc):
             assert np.abs(a - ref).max() <= 4e-7 * float(np.abs(ref).max())
         v.set_opts(batch_shape=0)
         for a, r in zip(v.infer_batch(mels), raw):  # (8-frame workgroups: another summation order inside Griffin-Lim)
-            assert abs((_rms(a) if mode == 2 else float(np.abs(a).max())) - (0.1 if mode == 2 else 1.0)) <= 1e-6
+            pk = float(np.abs(a).max())
+            if mode == 3:  # rms 0.1, or -- a crest factor above 20 dB (the 4-frame utterance) -- a peak of exactly 1 below that level
+                assert abs(_rms(a) - 0.1) <= 1e-6 or (abs(pk - 1.0) <= 1e-6 and _rms(a) < 0.1)
+            else:
+                assert abs((_rms(a) if mode == 2 else pk) - (0.1 if mode == 2 else 1.0)) <= 1e-6
     v.close()
 
 
@@ -78,8 +84,8 @@ def test_the_pipelines_return_normalised_audio(pkg, model, orc):
     assert np.array_equal(audio, v.infer(mel))
     v.set_opts(output_normalise=0)
     _, raw = pkg.synthesize(model, v, ids, opts=o)
-    assert np.abs(audio - orc.output_normalise(raw, mode=2)).max() <= 4e-7 * float(np.abs(audio).max())
-    v.set_opts(output_normalise=2)
+    assert np.abs(audio - orc.output_normalise(raw, mode=3)).max() <= 4e-7 * float(np.abs(audio).max())
+    v.set_opts(output_normalise=3)
     groups = [[ids], [ids[:6], ids[3:]], [ids[::-1].copy()]]
     steps = [[20], [18, 30], [41]]
     mels, audios = pkg.synthesize_batch(model, v, groups, opts=pkg.default_opts(dropout_seed=5), fixed_steps=steps)

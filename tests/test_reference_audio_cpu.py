@@ -83,10 +83,17 @@ def test_oracle_output_normalise_modes(orc):
     z = np.zeros(100, dtype=np.float32)
     assert np.array_equal(orc.output_normalise(z, mode=1), z) and np.array_equal(orc.output_normalise(z, mode=2), z)
     assert orc.output_normalise(np.zeros(0, dtype=np.float32), mode=2).size == 0
+    # mode 3 = mode 2 unless that would push a sample past +-1 (crest factor above 1 / target): then the peak lands on 1
+    assert np.array_equal(orc.output_normalise(y, mode=3, target=0.1), orc.output_normalise(y, mode=2, target=0.1))
+    spiky = np.zeros(4000, dtype=np.float32)
+    spiky[::400] = 0.5
+    assert float(np.abs(orc.output_normalise(spiky, mode=2, target=0.1)).max()) > 1.0
+    lim = orc.output_normalise(spiky, mode=3, target=0.1)
+    assert abs(float(np.abs(lim).max()) - 1.0) <= 1e-7 and np.sqrt(np.mean(lim.astype(np.float64) ** 2)) < 0.1
 
 
 def test_default_options_of_the_abi(pkg):
     o = pkg.GriffinLimOpts()
     pkg.lib.xdtts_griffinlim_opts_default(C.byref(o))
-    assert (o.nnls_iters, o.power_mode, o.mel_decompress, o.output_normalise, o.batch_shape) == (0, 0, 0, 2, 0)
+    assert (o.nnls_iters, o.power_mode, o.mel_decompress, o.output_normalise, o.batch_shape) == (0, 0, 0, 3, 0)
     assert o.rms_target == np.float32(0.1)

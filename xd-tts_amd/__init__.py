@@ -538,7 +538,7 @@ class GriffinLim:
 
     def set_opts(self, **kw):
         """nnls_iters, power_mode (0 inverse / 1 direct / 2 none), mel_decompress (0 exp / 1 none / 2 10^x),
-        output_normalise (0 none / 1 peak / 2 rms), rms_target, batch_shape (0 auto / 4 the single-utterance shape: bit-identical batches); unspecified
+        output_normalise (0 none / 1 peak / 2 rms / 3 rms limited to a peak of 1), rms_target, batch_shape (0 auto / 4 the single-utterance shape: bit-identical batches); unspecified
         fields keep their current value."""
         o = self.get_opts()
         for k, v in kw.items():

@@ -13,6 +13,7 @@
 #include <sys/file.h>
 #include <unistd.h>
 #include <cerrno>
+#include <cstring>
 
 #include "kernels.h"
 
@@ -208,9 +209,14 @@ using namespace xdtts;
 // timing out into the fallback engines (bench.py's two-ranks-on-one-GPU test mode uses it; so can a multi-worker server).
 class ChipLock {
   std::recursive_mutex m;
-  int depth = 0, fd = -2, device = 0;  // fd -2: not looked at yet, -1: no file lock
+  int depth = 0, fd = -2;  // fd -2: not looked at yet (in this process), -1: no file lock
+  const int device;
+  pid_t owner = 0;         // the process that opened fd: a forked child inherits the open file DESCRIPTION, on which parent and
+                           // child would both "hold" the flock -- it opens its own
   void open_file() {
+    if (fd >= 0 && owner != getpid()) ::close(fd);   // (the inherited descriptor; the parent's stays open in the parent)
     fd = -1;
+    owner = getpid();
     const char *dir = getenv("XDTTS_CHIP_LOCK_DIR");
     if (!dir || !*dir) return;
     char bus[64] = "unknown";
@@ -219,19 +225,30 @@ class ChipLock {
       if (*c == ':' || *c == '/') *c = '_';
     const std::string path = std::string(dir) + "/xdtts_chip_" + bus + ".lock";
     fd = ::open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0666);
-    if (fd < 0) std::fprintf(stderr, "libxdtts_hip: cannot open %s; co-resident launches are serialised within this process only\n", path.c_str());
+    if (fd < 0) {
+      // the caller asked for cross-process serialisation and cannot have it: an error, not a warning (without the lock two
+      // processes time each other's co-resident launches out into the fallback engines)
+      fd = -2;
+      fail(XDTTS_ERR_IO, "XDTTS_CHIP_LOCK_DIR: cannot open %s (%s)", path.c_str(), std::strerror(errno));
+    }
   }
 
  public:
-  void set_device(int d) { device = d; }
+  explicit ChipLock(int d) : device(d) {}
   void lock() {
     m.lock();
-    if (depth++ == 0) {
-      if (fd == -2) open_file();
+    if (depth == 0) {
+      try {
+        if (fd == -2 || owner != getpid()) open_file();
+      } catch (...) {
+        m.unlock();
+        throw;
+      }
       if (fd >= 0)
         while (::flock(fd, LOCK_EX) != 0 && errno == EINTR) {
         }
     }
+    ++depth;
   }
   void unlock() {
     if (--depth == 0 && fd >= 0) (void)::flock(fd, LOCK_UN);
@@ -239,10 +256,12 @@ class ChipLock {
   }
 };
 static ChipLock &chip_mutex(int device) {
-  static ChipLock m[64];  // one per GPU of this process
-  ChipLock &c = m[(unsigned)device % 64u];
-  c.set_device(device);
-  return c;
+  static std::mutex g;
+  static std::map<int, std::unique_ptr<ChipLock>> locks;  // one per GPU of this process, keyed by the device id itself
+  std::lock_guard<std::mutex> l(g);
+  std::unique_ptr<ChipLock> &p = locks[device];
+  if (!p) p.reset(new ChipLock(device));
+  return *p;
 }
 
 // ================================================================================================
@@ -598,13 +617,22 @@ struct xdtts_tacotron2 {
   // engine's fate: a timed-out exchange or a refused launch demotes both (persist_state), the request runs again on the
   // launch-per-stage engine.
   int p8_state = -1;  // -1 unknown, 0 off (XDTTS_P8=0, the device cannot host the grid, or an exchange timed out), 1 usable
+  bool p8_probe_ok = false;  // wanted, and the device can host the grid (occupancy probe): a demotion may be transient
+  int p8_demoted_calls = 0;  // small-batch requests since a timed-out exchange demoted the engine (own re-probe counter)
   bool p8_refused = false;  // the runtime refused the cooperative launch: a property of the device (engine_reset does not undo it)
   bool small_batch_engine(int B, int T, int max_steps) {
     if (B < 3 || B > P8_B_MAX || T > PERSIST_T_MAX || max_steps > P8_STEPS_MAX) return false;
     const char *e = getenv("XDTTS_DECODER");
     if (e && std::string(e) == "launch") return false;
     if (p8_state < 0) {
-      p8_state = (p8_wanted && decoder_p8_supported(device, P8_B_MAX, PERSIST_T_MAX)) ? 1 : 0;
+      p8_probe_ok = p8_wanted && decoder_p8_supported(device, P8_B_MAX, PERSIST_T_MAX);
+      p8_state = p8_probe_ok ? 1 : 0;
+    }
+    // like the persistent engine: the cause of a timed-out exchange (another process holding CUs) may be transient
+    if (p8_state == 0 && p8_probe_ok && !p8_refused && ++p8_demoted_calls >= PROBE_AFTER) {
+      p8_demoted_calls = 0;
+      p8_state = 1;
+      if (persist_state == 0 && persist_probe_ok) persist_state = 1, demoted_calls = 0;  // (they were demoted together)
     }
     return p8_state == 1 && persist_state != 0;
   }
@@ -666,9 +694,16 @@ struct xdtts_tacotron2 {
     };
     // (its exchange holds one slab per step, 11.3 kB per chunk slot: a request capped at more than 16384 steps -- 190 s of speech --
     // takes the other engines rather than gigabytes of ring)
-    if (!d.xf && small_batch_engine(d.B, d.T, max_lim)) try {
+    bool p8_go = !d.xf && small_batch_engine(d.B, d.T, max_lim);
+    if (p8_go) try {
+      dec_exchange.alloc(p8_exchange_words(d.B, max_lim));   // 11.3 kB per chunk slot and step: 90 MB at 8 slots x 1000 steps
+    } catch (const Error &e) {
+      if (e.code != XDTTS_ERR_OOM) throw;
+      p8_go = false;      // no room for the ring: this request takes the other engines (whose exchange is 63 kB per chunk)
+      (void)hipGetLastError();
+    }
+    if (p8_go) try {
       std::lock_guard<ChipLock> lk(chip_mutex(device));
-      dec_exchange.alloc(p8_exchange_words(d.B, max_lim));
       P8Bufs g8 = p8_bufs(dec_exchange.p, dec_err.p, d.B, max_lim);
       if (const char *sp = getenv("XDTTS_PERSIST_SPINS")) g8.spins = atoi(sp);  // test hooks for the lost-workgroup path
       if (const char *ft = getenv("XDTTS_PERSIST_FAULT")) g8.fault = atoi(ft);
@@ -678,9 +713,18 @@ struct xdtts_tacotron2 {
       if (!host_ctl[HOST_DEC_ERR]) return finish();
       spec_ran = false;
       HIP_CHECK(hipMemsetAsync(dec_err.p, 0, sizeof(int), stream));
+      // the 256-workgroup grid was not co-resident: the pair-persistent engine, which needs the same, would spend a second
+      // 2^21-spin time-out finding that out -- both are demoted, both are probed again after PROBE_AFTER requests.  The
+      // request runs again on the launch-per-stage engine (row-major state, any B <= 8).
       p8_state = 0;
+      p8_demoted_calls = 0;
+      if (persist_state != 0) {
+        if (persist_state < 0) persist_probe_ok = decoder_persistent_supported(device, PERSIST_B_MAX, PERSIST_T_MAX);
+        persist_state = 0;
+        demoted_calls = 0;
+      }
       std::fprintf(stderr, "libxdtts_hip: persistent MFMA decoder exchange timed out (grid not co-resident); this handle now "
-                           "decodes small batches with its other engines\n");
+                           "uses the launch-per-stage decoder (probed again after %d calls)\n", PROBE_AFTER);
       launch_decoder_init(d, limits.p, stream);
     } catch (const CoopRefused &) {
       p8_state = 0;
@@ -764,6 +808,12 @@ struct xdtts_tacotron2 {
         if (const char *ft = getenv("XDTTS_PERSIST_FAULT")) g.fault = atoi(ft);  // lost-workgroup path
         if (const char *sl = getenv("XDTTS_PERSIST_SLOW")) g.slow = atoi(sl);    // straggler workgroup
         g.shrink = (n == 2 && !no_shrink) ? 1 : 0;
+        if (g.shrink && !d.use_gate && lim[b0] == lim[b0 + 1]) {
+          // gate-less pair with equal caps: the host knows that neither chunk outlives the other, so no continuation launches
+          // (each would do the full weight / LDS set-up and write-back for zero steps)
+          g.shrink = 0;
+          g.both_run = 1;
+        }
 #ifdef XDTTS_PERSIST_PROFILE
         static DevBuf<unsigned long long> prof;
         prof.alloc(256 * 24);
@@ -1111,9 +1161,9 @@ struct xdtts_griffinlim {
   float last_ms[3] = {0, 0, 0};
   DevBuf<float> pinv, win, S, melT, mel_in, frames, wss_inv, audio, phase0;
   // mel->linear options (xdtts_griffinlim_opts) and the NNLS refinement's operands
-  xdtts_griffinlim_opts gopts{0, 0, 0, 2, 0, 0.1f};
+  xdtts_griffinlim_opts gopts = [] { xdtts_griffinlim_opts o; xdtts_griffinlim_opts_default(&o); return o; }();  // one source for the defaults
   static constexpr int NBP = 528;  // bins padded to the GEMM's K granule
-  DevBuf<float> basis_p, basisT_p, nnls_x, nnls_r, norm_parts;  // norm_parts: GLN_PARTS per utterance
+  DevBuf<float> basis_p, basisT_p, nnls_x, nnls_r, norm_parts;  // norm_parts: GLN_SCRATCH per utterance
   DevBuf<int2> norm_tab;  // (first sample, samples) per utterance of a vocoder batch
   float nnls_step = 0.f;   // 1 / lambda_max(A A^T)
   hipGraphExec_t graph = nullptr;  // n_iter x (istft, stft) + final ISTFT for the cached (buffers, F, iterations)
@@ -1963,6 +2013,7 @@ xdtts_status xdtts_tacotron2_engine_reset(xdtts_tacotron2 *h) {
     if (!h->p8_refused) h->p8_state = -1;
     if (!h->coop_refused) h->coop_ok = true;
     h->demoted_calls = 0;
+    h->p8_demoted_calls = 0;
     h->enc_demoted_calls = 0;
     h->att_fused = xdtts_tacotron2::att_fused_default();
     h->att_demoted = false;
@@ -2066,7 +2117,7 @@ xdtts_status xdtts_griffinlim_new(const float *mel_basis, size_t n_mels, size_t 
       g->basis_p.upload(bp.data(), bp.size(), g->stream);
       g->basisT_p.upload(bt.data(), bt.size(), g->stream);
       g->nnls_step = (float)(1.0 / host_lipschitz(mel_basis, nm, nbi));
-      g->norm_parts.alloc(GLN_PARTS);
+      g->norm_parts.alloc(GLN_SCRATCH);
     }
     std::vector<float2> tw(n_fft);
     std::vector<float> win(n_fft);
@@ -2087,7 +2138,7 @@ void xdtts_griffinlim_opts_default(xdtts_griffinlim_opts *o) {
   o->nnls_iters = 0;
   o->power_mode = 0;
   o->mel_decompress = 0;
-  o->output_normalise = 2;  // rms: the level of the reference's own WAV_SPEC files
+  o->output_normalise = 3;  // rms, never past +-1: the level of the reference's own WAV_SPEC files
   o->batch_shape = 0;
   o->rms_target = 0.1f;
 }
@@ -2096,7 +2147,7 @@ xdtts_status xdtts_griffinlim_set_opts(xdtts_griffinlim *g, const xdtts_griffinl
   return guard([&] {
     if (!g || !o) fail(XDTTS_ERR_BAD_ARG, "null argument");
     if (o->nnls_iters < 0 || o->nnls_iters > 100000 || o->power_mode < 0 || o->power_mode > 2 || o->mel_decompress < 0 ||
-        o->mel_decompress > 2 || o->output_normalise < 0 || o->output_normalise > 2 || !(o->rms_target > 0.f) || !(o->rms_target <= 1e6f) || (o->batch_shape != 0 && o->batch_shape != 4))
+        o->mel_decompress > 2 || o->output_normalise < 0 || o->output_normalise > 3 || !(o->rms_target > 0.f) || !(o->rms_target <= 1e6f) || (o->batch_shape != 0 && o->batch_shape != 4))
       fail(XDTTS_ERR_BAD_ARG, "griffin-lim option out of range");
     std::lock_guard<std::mutex> lk(g->mu);
     g->gopts = *o;
@@ -2305,7 +2356,7 @@ static void gl_batch_from_device(xdtts_griffinlim *g, const float *mel_dev_all, 
         for (int u = 0; u < n_utt; ++u)
           if (!batched[u]) add(u);
         g->norm_tab.upload(tab.data(), tab.size(), st);
-        g->norm_parts.alloc((size_t)GLN_PARTS * (size_t)n_utt);
+        g->norm_parts.alloc((size_t)GLN_SCRATCH * (size_t)n_utt);
         HIP_CHECK(hipStreamSynchronize(st));
       }
       size_t n_ev = 0;
@@ -2315,7 +2366,7 @@ static void gl_batch_from_device(xdtts_griffinlim *g, const float *mel_dev_all, 
           for (int u : utts) n_max = std::max(n_max, g->hop * (Fu[u] - 1));
           const int r0 = tab_pos[(size_t)utts[0]];
           launch_gl_output_normalise(g->audio.p, g->norm_tab.p + r0, (int)utts.size(), 0, n_max, norm_mode, g->gopts.rms_target,
-                                     g->norm_parts.p + (size_t)r0 * GLN_PARTS, st);
+                                     g->norm_parts.p + (size_t)r0 * GLN_SCRATCH, st);
         }
         hipEvent_t e = g->launch_done(n_ev++);
         HIP_CHECK(hipEventRecord(e, st));

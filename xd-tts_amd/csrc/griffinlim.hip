@@ -1035,36 +1035,45 @@ __global__ void k_pow_rows(const float *in, int ld, float *out, int nb, int F, f
   out[i] = p == 1.0f ? v : powf(fmaxf(v, 0.f), p);
 }
 
-// Output normalisation (G6; xdtts_griffinlim_opts.output_normalise): 1 = y / max|y|, 2 = y * target / rms(y).
+// Output normalisation (G6; xdtts_griffinlim_opts.output_normalise): 1 = y / max|y|, 2 = y * target / rms(y),
+// 3 = y * min(target / rms(y), 1 / max|y|) (mode 2 that never scales a sample past +-1, where src/lib.rs:155's cast would clip).
 // Two launches per group of utterances, no atomics: GLN_PARTS blocks per utterance each reduce a fixed strided share
 // (lane-strided accumulation, xor-shuffle tree, the four waves summed in order), then every scaling block re-reduces the
-// utterance's GLN_PARTS partials in one fixed order -- the result does not depend on scheduling.
+// utterance's GLN_PARTS partials in one fixed order -- the result does not depend on scheduling.  An utterance's scratch is
+// two planes of GLN_PARTS floats: sums of squares (peaks in mode 1), and the peaks of mode 3.
 __global__ void __launch_bounds__(256) k_norm_partials(const float *y, const int2 *tab, int2 single, int mode, float *parts) {
   const int2 t = tab ? tab[blockIdx.y] : single;  // (first sample, samples)
   const float *p = y + t.x;
-  float acc = 0.f;
+  float acc = 0.f, pk = 0.f;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < t.y; i += GLN_PARTS * 256) {
     const float v = p[i];
     acc = mode == 1 ? fmaxf(acc, fabsf(v)) : fmaf(v, v, acc);
+    pk = fmaxf(pk, fabsf(v));
   }
   for (int o = 32; o > 0; o >>= 1) {
     const float b = __shfl_xor(acc, o, 64);
     acc = mode == 1 ? fmaxf(acc, b) : acc + b;
+    pk = fmaxf(pk, __shfl_xor(pk, o, 64));
   }
-  __shared__ float w[4];
-  if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = acc;
+  __shared__ float w[4], wp[4];
+  if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = acc, wp[threadIdx.x >> 6] = pk;
   __syncthreads();
-  if (threadIdx.x == 0)
-    parts[blockIdx.y * GLN_PARTS + blockIdx.x] = mode == 1 ? fmaxf(fmaxf(w[0], w[1]), fmaxf(w[2], w[3])) : ((w[0] + w[1]) + (w[2] + w[3]));
+  if (threadIdx.x == 0) {
+    float *q = parts + (size_t)blockIdx.y * GLN_SCRATCH;
+    q[blockIdx.x] = mode == 1 ? fmaxf(fmaxf(w[0], w[1]), fmaxf(w[2], w[3])) : ((w[0] + w[1]) + (w[2] + w[3]));
+    q[GLN_PARTS + blockIdx.x] = fmaxf(fmaxf(wp[0], wp[1]), fmaxf(wp[2], wp[3]));
+  }
 }
 __global__ void __launch_bounds__(256) k_norm_scale(float *y, const int2 *tab, int2 single, int mode, float target, const float *parts) {
   const int2 t = tab ? tab[blockIdx.y] : single;
   if (blockIdx.x * 1024 >= t.y) return;
   static_assert(GLN_PARTS == 64, "one lane per partial");
-  float acc = parts[blockIdx.y * GLN_PARTS + (threadIdx.x & 63)];
+  const float *q = parts + (size_t)blockIdx.y * GLN_SCRATCH;
+  float acc = q[threadIdx.x & 63], pk = q[GLN_PARTS + (threadIdx.x & 63)];
   for (int o = 32; o > 0; o >>= 1) {
     const float b = __shfl_xor(acc, o, 64);
     acc = mode == 1 ? fmaxf(acc, b) : acc + b;
+    pk = fmaxf(pk, __shfl_xor(pk, o, 64));
   }
   float *p = y + t.x;
   if (mode == 1) {
@@ -1073,7 +1082,8 @@ __global__ void __launch_bounds__(256) k_norm_scale(float *y, const int2 *tab, i
   } else {
     const float r = sqrtf(acc / (float)t.y);
     if (!(r > 0.f)) return;
-    const float sc = target / r;
+    float sc = target / r;
+    if (mode == 3 && sc * pk > 1.f) sc = 1.f / pk;
     for (int i = blockIdx.x * 1024 + threadIdx.x; i < min(t.y, (int)(blockIdx.x + 1) * 1024); i += 256) p[i] = p[i] * sc;
   }
 }

@@ -258,8 +258,9 @@ void launch_gl_exp_transpose(const float *mel_80xF, float *out_Fx80, int n_mels,
 void launch_gl_pow_rows(const float *in, int ld, float *out, int nb, int F, float p, hipStream_t s);
 // Output normalisation (mode 1: y / max|y|, 2: y * target / rms(y)) of n_utt utterances in two launches: utterance u is
 // the samples [tab_dev[u].x, + tab_dev[u].y) of y (tab_dev == nullptr: one utterance, [first, first + n_max)); n_max = the
-// longest of them; parts = GLN_PARTS floats of device scratch per utterance.  Deterministic (fixed reduction order).
+// longest of them; parts = GLN_SCRATCH floats of device scratch per utterance.  Deterministic (fixed reduction order).
 constexpr int GLN_PARTS = 64;
+constexpr int GLN_SCRATCH = 2 * GLN_PARTS;  // floats of scratch per utterance: sums of squares / peaks
 void launch_gl_output_normalise(float *y, const int2 *tab_dev, int n_utt, int first, int n_max, int mode, float target,
                                 float *parts, hipStream_t s);
 void launch_gl_phase_init(const GlBufs &g, uint32_t seed, const float *phase0_dev, hipStream_t s);
