@@ -278,14 +278,35 @@ struct xdtts_tacotron2 {
   int last_steps = 0;
 
   // workspaces (grown on demand)
-  DevBuf<int64_t> ids;
-  DevBuf<int> n_valid, limits, nframes, ctl;
+  // an input array on the device: either its own allocation (upload) or a view into the request's one staged block (infer_batch_device)
+  template <class T>
+  struct DevSlot {
+    T *p = nullptr;
+    DevBuf<T> own;
+    void upload(const T *src, size_t count, hipStream_t s) {
+      own.upload(src, count, s);
+      p = own.p;
+    }
+  };
+  DevSlot<int64_t> ids;
+  DevSlot<int> n_valid, limits;
+  DevBuf<unsigned char> in_blk;       // ids | lens | step caps | dropout-stream order of one request: ONE host-to-device copy
+  unsigned char *in_host = nullptr;   // pinned staging of the same
+  size_t in_host_bytes = 0;
+  std::vector<int> lim_on_dev;        // the step caps limits.p holds (run_decoder uploads them only when they differ)
+  // One control block on the device, mirrored by host_ctl: [0..1] ctl (step counter, spare), [2] encoder error word, [3] decoder
+  // error word, [4 ..] frames per chunk -- so that what a decode hands back to the host is ONE copy (it was three of 4-5 us each)
+  struct IntRef {
+    int *p = nullptr;
+  };
+  DevBuf<int> ctlblk;
+  IntRef ctl, enc_err, dec_err, nframes;
   DevBuf<float> xpadA, xpadB, xproj, memory, pmem;
+  const float *xpad_zero[2] = {nullptr, nullptr};  // the allocations and layout whose padding rows are known to be zero
+  int xpad_B = 0, xpad_T = 0;
   DevBuf<unsigned long long> enc_exchange;
-  DevBuf<int> enc_err;
   DevBuf<unsigned long long> dec_exchange;  // granule buffers of the persistent decoder
   DevBuf<float> ctx_fold;                   // [B][CTXF_ROWS][CTXF_LD] context-fold table of the persistent decoder (kernels.h)
-  DevBuf<int> dec_err;
   DevBuf<unsigned long long> att_exchange;
   DevBuf<float> att_part;  // early partial pre-activations of the attention LSTM (DecoderBufs::att_part)
   DevBuf<float> dec_part;  // two-launch form: early partial of the decoder LSTM's h_dec columns (DecoderBufs::dec_part)
@@ -322,15 +343,16 @@ struct xdtts_tacotron2 {
   DevBuf<float> att_h, att_c, dec_h, dec_c, aw, awc, ctx, x, loc, e_part, pmel, frames, gates;
   DevBuf<float> frag;       // batched mode: MFMA-operand copies of x, ctx, att_h[2], dec_h[2]
   DevBuf<float> pmem_t;     // batched mode: processed_memory as [B][32][T][4]
-  DevBuf<int> item_perm;    // batched mode: dropout-stream index of the (length-sorted) chunks
+  DevSlot<int> item_perm;    // batched mode: dropout-stream index of the (length-sorted) chunks
   DevBuf<float> dec_in_dev; // parity hook: decoder_input of xdtts_tacotron2_decoder_step
   DevBuf<unsigned char> drop_dev;  // dropout_mode 2: the caller's keep masks
   DevBuf<float> state_stage;       // parity hook: the seven state tensors in the caller's layout
   int demoted_calls = 0;    // decoder calls since a demotion (the fast engines are probed again after PROBE_AFTER)
   static constexpr int PROBE_AFTER = 64;
-  DevBuf<float> ppA, ppB, mel_dev;
-  int *host_ctl = nullptr;  // pinned: [0..1] ctl, [2..] nframes, [HOST_ENC_ERR] / [HOST_DEC_ERR] the engines' error words
-  static constexpr int HOST_ENC_ERR = 2 + 4096, HOST_DEC_ERR = HOST_ENC_ERR + 1;
+  DevBuf<float> pp0, ppA, ppB, mel_dev;
+  std::vector<long> pp_sig;  // layout (items, frames, allocations) whose padding is known to be zero in pp0 / ppA / ppB
+  int *host_ctl = nullptr;  // pinned mirror of ctlblk: [0..1] ctl, [HOST_ENC_ERR] / [HOST_DEC_ERR] the engines' error words, [HOST_NF ..] nframes
+  static constexpr int HOST_ENC_ERR = 2, HOST_DEC_ERR = 3, HOST_NF = 4, CTL_INTS = HOST_NF + 4096;
 
   // cached hipGraph of GRAPH_STEPS decoder steps for the current (B, T, buffers)
   static constexpr int GRAPH_STEPS = 20;
@@ -342,6 +364,7 @@ struct xdtts_tacotron2 {
     if (fetched) (void)hipEventDestroy(fetched);
     if (graph) (void)hipGraphExecDestroy(graph);
     if (host_ctl) (void)hipHostFree(host_ctl);
+    if (in_host) (void)hipHostFree(in_host);
     if (stream) (void)hipStreamDestroy(stream);
   }
 
@@ -351,15 +374,17 @@ struct xdtts_tacotron2 {
     HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     ev.create();
     HIP_CHECK(hipEventCreateWithFlags(&fetched, hipEventDisableTiming));
-    HIP_CHECK(hipHostMalloc((void **)&host_ctl, sizeof(int) * (2 + 4096 + 2), hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc((void **)&host_ctl, sizeof(int) * CTL_INTS, hipHostMallocDefault));
     int cus = 0;
     HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     coop_group = cus / 8 < 1 ? 1 : cus / 8;
     n_cu = cus;
-    enc_err.alloc(1);
-    HIP_CHECK(hipMemsetAsync(enc_err.p, 0, sizeof(int), stream));
-    dec_err.alloc(1);
-    HIP_CHECK(hipMemsetAsync(dec_err.p, 0, sizeof(int), stream));
+    ctlblk.alloc(CTL_INTS);
+    HIP_CHECK(hipMemsetAsync(ctlblk.p, 0, sizeof(int) * CTL_INTS, stream));
+    ctl.p = ctlblk.p;
+    enc_err.p = ctlblk.p + HOST_ENC_ERR;
+    dec_err.p = ctlblk.p + HOST_DEC_ERR;
+    nframes.p = ctlblk.p + HOST_NF;
     w.upload(blob, stream);
   }
 
@@ -372,8 +397,16 @@ struct xdtts_tacotron2 {
     xproj.alloc((size_t)2 * B * T * 4 * ENC_H);
     memory.alloc((size_t)B * T * EMB);
     pmem.alloc((size_t)B * T * ATT_DIM);
-    HIP_CHECK(hipMemsetAsync(xpadA.p, 0, padded * sizeof(float), stream));
-    HIP_CHECK(hipMemsetAsync(xpadB.p, 0, padded * sizeof(float), stream));
+    // only the padding rows must read as zero, and nothing ever writes them (the embedding and the convolutions store rows
+    // pad .. pad + T - 1 of every chunk): the fills are needed when the layout (or the allocation) changes, not per request
+    if (xpad_zero[0] != xpadA.p || xpad_zero[1] != xpadB.p || xpad_B != B || xpad_T != T) {
+      HIP_CHECK(hipMemsetAsync(xpadA.p, 0, padded * sizeof(float), stream));
+      HIP_CHECK(hipMemsetAsync(xpadB.p, 0, padded * sizeof(float), stream));
+      xpad_zero[0] = xpadA.p;
+      xpad_zero[1] = xpadB.p;
+      xpad_B = B;
+      xpad_T = T;
+    }
     launch_embed(ids.p, w.emb.p, xpadA.p, B, T, pad, stream);
     float *src = xpadA.p, *dst = xpadB.p;
     for (int i = 0; i < ENC_CONVS; ++i) {
@@ -481,8 +514,6 @@ struct xdtts_tacotron2 {
     pmel.alloc(decoder_pmel_floats(B));
     frames.alloc((size_t)B * ms * N_MEL);
     gates.alloc((size_t)B * ms);
-    nframes.alloc(B);
-    ctl.alloc(2);
     DecoderBufs d{};
     d.B = B;
     d.T = T;
@@ -660,7 +691,10 @@ struct xdtts_tacotron2 {
   int run_decoder(const DecoderBufs &d, const std::vector<int> &lim, const std::function<void()> &after = {},
                   bool *after_ran = nullptr) {
     if (after_ran) *after_ran = false;
-    limits.upload(lim.data(), lim.size(), stream);
+    if (lim_on_dev != lim || !limits.p) {
+      limits.upload(lim.data(), lim.size(), stream);
+      lim_on_dev = lim;
+    }
     launch_decoder_init(d, limits.p, stream);
     launch_decoder_prologue(d, w, stream);
     const int max_lim = *std::max_element(lim.begin(), lim.end());
@@ -670,9 +704,8 @@ struct xdtts_tacotron2 {
     // step counter and frame counts to the host; the last fetch of a decode brings the engines' error word along and,
     // for a gate-less decode, lets `after` enqueue its work before the host waits (for the copies only)
     auto fetch = [&](bool last = false) {
-      HIP_CHECK(hipMemcpyAsync(host_ctl, d.ctl, sizeof(int) * 2, hipMemcpyDeviceToHost, stream));
-      HIP_CHECK(hipMemcpyAsync(host_ctl + 2, d.nframes, sizeof(int) * d.B, hipMemcpyDeviceToHost, stream));
-      if (last) HIP_CHECK(hipMemcpyAsync(host_ctl + HOST_DEC_ERR, dec_err.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+      (void)last;  // (the error words ride along every time: they sit between the step counter and the frame counts)
+      HIP_CHECK(hipMemcpyAsync(host_ctl, ctlblk.p, sizeof(int) * (size_t)(HOST_NF + d.B), hipMemcpyDeviceToHost, stream));
       if (last && spec) {
         HIP_CHECK(hipEventRecord(fetched, stream));
         after();
@@ -686,8 +719,8 @@ struct xdtts_tacotron2 {
       int steps = 0;
       bool as_planned = true;
       for (int b = 0; b < d.B; ++b) {
-        steps = std::max(steps, host_ctl[2 + b]);
-        as_planned = as_planned && host_ctl[2 + b] == lim[b];
+        steps = std::max(steps, host_ctl[HOST_NF + b]);
+        as_planned = as_planned && host_ctl[HOST_NF + b] == lim[b];
       }
       if (after_ran) *after_ran = spec_ran && as_planned;
       return steps;
@@ -909,7 +942,7 @@ struct xdtts_tacotron2 {
         }
         fetch();
         int need = 0;
-        for (int b = 0; b < d.B; ++b) need = std::max(need, host_ctl[2 + b]);
+        for (int b = 0; b < d.B; ++b) need = std::max(need, host_ctl[HOST_NF + b]);
         if (host_ctl[0] >= need || launched >= max_lim) break;
       }
       // the projection of step s is completed by the first kernel of step s+1: finish the last one
@@ -947,21 +980,34 @@ struct xdtts_tacotron2 {
     const int pad = (POST_K - 1) / 2;
     int Fmax = 0;
     for (int i = 0; i < n; ++i) Fmax = std::max(Fmax, F[i]);
-    const size_t FP = (size_t)Fmax + 2 * pad, slot = FP * POST_CH;
+    const size_t FP = (size_t)Fmax + 2 * pad, slot = FP * POST_CH, slot0 = FP * N_MEL;
+    pp0.alloc(slot0 * n);
     ppA.alloc(slot * n);
     ppB.alloc(slot * n);
-    HIP_CHECK(hipMemsetAsync(ppA.p, 0, slot * n * sizeof(float), stream));
-    HIP_CHECK(hipMemsetAsync(ppB.p, 0, slot * n * sizeof(float), stream));
-    // layer 0 input: the frames themselves, viewed as zero-padded [FP][80] buffers
-    launch_copy_rows(frames_dev, frame_stride, ppB.p + (size_t)pad * N_MEL, slot, F, n, N_MEL, stream);
-    float *src = ppB.p, *dst = ppA.p;
+    // What must read as zero -- the padding rows and, in a ragged group, the rows between a chunk's end and the longest chunk's
+    // -- is never written (the copy and the convolutions store rows pad .. pad + F[z] - 1 of item z), so the three fills are
+    // due when the group's layout or an allocation changes, not per request (the 80-channel input has its own buffer for that:
+    // as a second view of ppB it left 80-channel rows where the 512-channel layout has its padding)
+    {
+      std::vector<long> sig{(long)n, (long)Fmax, (long)(size_t)pp0.p, (long)(size_t)ppA.p, (long)(size_t)ppB.p};
+      for (int z = 0; z < n; ++z) sig.push_back(F[z]);
+      if (sig != pp_sig) {
+        HIP_CHECK(hipMemsetAsync(pp0.p, 0, slot0 * n * sizeof(float), stream));
+        HIP_CHECK(hipMemsetAsync(ppA.p, 0, slot * n * sizeof(float), stream));
+        HIP_CHECK(hipMemsetAsync(ppB.p, 0, slot * n * sizeof(float), stream));
+        pp_sig = sig;
+      }
+    }
+    // layer 0 input: the frames themselves in zero-padded [FP][80] buffers
+    launch_copy_rows(frames_dev, frame_stride, pp0.p + (size_t)pad * N_MEL, slot0, F, n, N_MEL, stream);
+    float *src = pp0.p, *dst = ppA.p;
     for (int i = 0; i < POST_CONVS; ++i) {
       const ConvGemm &c = w.post_conv[i];
       const bool last = i == POST_CONVS - 1;
       GemmArgs g{};
       g.A = src;
       g.lda = c.ci;
-      g.strideA = (long)slot;
+      g.strideA = (long)(i == 0 ? slot0 : slot);
       g.W = c.w.p;
       g.bias = c.b.p;
       g.M = Fmax;
@@ -988,10 +1034,7 @@ struct xdtts_tacotron2 {
         g.strideR = (long)frame_stride;
       }
       launch_gemm_nt(g, stream);
-      if (i == 0) {
-        // ppB held the 80-channel inputs; clear it before it becomes a 512-channel buffer
-        HIP_CHECK(hipMemsetAsync(ppB.p, 0, slot * n * sizeof(float), stream));
-      }
+      if (i == 0) src = ppB.p;  // (layers 1.. ping-pong between the two 512-channel buffers)
       std::swap(src, dst);
     }
   }
@@ -1043,16 +1086,32 @@ struct xdtts_tacotron2 {
     }
     ids_host = ids_sorted.data();
     lens = lens_sorted.data();
-    ids.upload(ids_host, (size_t)B * T, stream);
-    n_valid.upload(lens, B, stream);
-    if (batched_mode) item_perm.upload(order.data(), B, stream);
-    // (no sync here: the three sources are locals of this function -- the sorted copies -- and outlive the stream work,
-    // which run_decoder waits out before it returns; a pageable source is staged before hipMemcpyAsync returns anyway)
+    {  // ids, lengths, step caps and (batched mode) the dropout-stream order: one pinned block, one copy (it was four of 4-5 us
+       // each, with the host's enqueue time in front of every one of them at the start of a request)
+      const size_t b_ids = sizeof(int64_t) * (size_t)B * T, b_int = sizeof(int) * (size_t)B, need = b_ids + 3 * b_int;
+      if (need > in_host_bytes) {
+        if (in_host) (void)hipHostFree(in_host);
+        in_host = nullptr;
+        in_host_bytes = 0;
+        HIP_CHECK(hipHostMalloc((void **)&in_host, need, hipHostMallocDefault));
+        in_host_bytes = need;
+      }
+      std::memcpy(in_host, ids_host, b_ids);
+      std::memcpy(in_host + b_ids, lens, b_int);
+      std::memcpy(in_host + b_ids + b_int, lim.data(), b_int);
+      std::memcpy(in_host + b_ids + 2 * b_int, order.data(), b_int);
+      in_blk.alloc(need);
+      HIP_CHECK(hipMemcpyAsync(in_blk.p, in_host, need, hipMemcpyHostToDevice, stream));  // (run_decoder's final wait is behind it)
+      ids.p = reinterpret_cast<int64_t *>(in_blk.p);
+      n_valid.p = reinterpret_cast<int *>(in_blk.p + b_ids);
+      limits.p = reinterpret_cast<int *>(in_blk.p + b_ids + b_int);
+      item_perm.p = reinterpret_cast<int *>(in_blk.p + b_ids + 2 * b_int);
+      lim_on_dev = lim;
+    }
     std::lock_guard<ChipLock> chip(chip_mutex(device));  // released after run_decoder's final wait
     run_encoder(B, T);
     HIP_CHECK(hipEventRecord(ev.e[1], stream));
-    // the cooperative BiLSTM's error word comes back with the decoder's own final fetch (one stream sync less per call)
-    HIP_CHECK(hipMemcpyAsync(host_ctl + HOST_ENC_ERR, enc_err.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+    // (the cooperative BiLSTM's error word comes back with the decoder's own final fetch: same block, same copy)
     if (batched_mode) w.ensure_batched_layout(blob, stream);
     DecoderBufs d = decoder_bufs(B, T, memory.p, pmem.p, o, batched_mode ? 1 : 0);
     if (batched_mode) d.item_perm = item_perm.p;
@@ -1100,7 +1159,7 @@ struct xdtts_tacotron2 {
       if (d.pmem_t) launch_dimgroup_transpose(pmem.p, pmem_t.p, B, T, stream);
       last_steps = run_decoder(d, lim);
     }
-    if (!postnet_done) postnet_all(host_ctl + 2);
+    if (!postnet_done) postnet_all(host_ctl + HOST_NF);
     *F_total = total;
     return F;
   }
@@ -1789,7 +1848,7 @@ xdtts_status xdtts_tacotron2_decoder(xdtts_tacotron2 *h, const float *memory, co
     h->last_steps = h->run_decoder(d, lim);
     HIP_CHECK(hipEventRecord(h->ev.e[2], h->stream));
     HIP_CHECK(hipEventRecord(h->ev.e[3], h->stream));
-    const int F = h->host_ctl[2];
+    const int F = h->host_ctl[xdtts_tacotron2::HOST_NF];
     HIP_CHECK(hipMemcpyAsync(frames, d.frames, (size_t)F * N_MEL * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     if (gates) HIP_CHECK(hipMemcpyAsync(gates, d.gates, (size_t)F * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     h->finish_timings();
@@ -1847,6 +1906,7 @@ xdtts_status xdtts_tacotron2_decoder_steps(xdtts_tacotron2 *h, int32_t engine, i
     DecoderBufs d = h->decoder_bufs(B, T, h->memory.p, h->pmem.p, o, engine == 2 ? 1 : 0);
     d.use_gate = 0;  // the caller applies the stop rule to gate_prediction (mod.rs:319)
     h->limits.upload(lim.data(), lim.size(), st);
+    h->lim_on_dev = lim;
     launch_decoder_init(d, h->limits.p, st);
     h->dec_in_dev.upload(decoder_input, (size_t)B * N_MEL, st);
     // staging of the seven state tensors in the caller's row-major layout

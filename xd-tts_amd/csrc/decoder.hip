@@ -75,6 +75,9 @@ __global__ void k_decoder_init(DecoderBufs d, const int *limits) {
   for (int i = threadIdx.x; i < EMB; i += blockDim.x) d.ctx[b * EMB + i] = 0.f;
   // step 0: location features of all-zero attention weights
   for (int i = threadIdx.x; i < d.T * ATT_DIM; i += blockDim.x) d.loc[(size_t)b * d.T * ATT_DIM + i] = 0.f;
+  // partial-mel rows are summed unconditionally: padding columns 81..83 and a first step's rows must read as zero (this chunk's
+  // PM_ROWS x MEL_LD share; it was a fill of its own in front of this kernel)
+  for (int i = threadIdx.x; i < PM_ROWS * MEL_LD; i += blockDim.x) d.pmel[(size_t)b * PM_ROWS * MEL_LD + i] = 0.f;
   if (threadIdx.x == 0) {
     d.nframes[b] = limits[b];
     if (b == 0) d.ctl[0] = 0;
@@ -1833,9 +1836,6 @@ void launch_decoder_init(const DecoderBufs &d, const int *limits_dev, hipStream_
     HIP_CHECK(hipMemsetAsync(d.att_c, 0, sizeof(float) * (size_t)d.Bpad * ATT_RNN, s));
     HIP_CHECK(hipMemsetAsync(d.dec_c, 0, sizeof(float) * (size_t)d.Bpad * DEC_RNN, s));
   }
-  // partial-mel rows are summed unconditionally; padding columns 81..83 and a first step's rows
-  // must read as zero
-  HIP_CHECK(hipMemsetAsync(d.pmel, 0, decoder_pmel_floats(d.B) * sizeof(float), s));
   if (d.ep_g) HIP_CHECK(hipMemsetAsync(d.ep_g, 0, sizeof(unsigned long long) * (size_t)d.B * CTX_BLOCKS * d.T, s));  // step tags restart at 1
   if (d.hg) HIP_CHECK(hipMemsetAsync(d.hg, 0, sizeof(unsigned long long) * (size_t)d.B * ATT_RNN, s));
   if (d.att_part) HIP_CHECK(hipMemsetAsync(d.att_part, 0, sizeof(float) * (size_t)NBLK * 4 * 64 * 4, s));  // step 0: context and hidden state are zero

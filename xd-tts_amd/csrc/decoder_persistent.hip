@@ -1294,8 +1294,11 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent(DecoderBufs d, Persis
 }
 
 // x(0) = prenet(0) = 0 (the prenet has no bias, mod.rs:208) with the chunks' initial active bits
-__global__ void k_persist_seed(PersistBufs g, const int *limits, int B) {
+// ... and clears the whole exchange first (it was a fill of its own): thread (b, i) zeroes words b 256 + i + k (B 256), the
+// first of which is the slot it then seeds -- same thread, program order
+__global__ void k_persist_seed(PersistBufs g, const int *limits, int B, unsigned words) {
   const int b = blockIdx.x, i = threadIdx.x;
+  for (unsigned w = (unsigned)(b * PRENET + i); w < words; w += (unsigned)(B * PRENET)) g.x[w] = 0ull;
   publish(g.x + (size_t)b * PRENET + i, 1u | (limits[b] > 0 ? ACT_BIT : 0u), 0.f);
 }
 
@@ -1385,8 +1388,7 @@ bool decoder_persistent_supported(int device, int B, int T) {
 }
 
 void launch_persist_seed(const DecoderBufs &d, const PersistBufs &g, const int *limits_dev, hipStream_t s) {
-  HIP_CHECK(hipMemsetAsync(g.x, 0, persist_granule_words(d.B) * sizeof(unsigned long long), s));
-  hipLaunchKernelGGL(k_persist_seed, dim3(d.B), dim3(PRENET), 0, s, g, limits_dev, d.B);
+  hipLaunchKernelGGL(k_persist_seed, dim3(d.B), dim3(PRENET), 0, s, g, limits_dev, d.B, (unsigned)persist_granule_words(d.B));
   HIP_CHECK(hipGetLastError());
 }
 
