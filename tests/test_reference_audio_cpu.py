@@ -97,3 +97,24 @@ def test_default_options_of_the_abi(pkg):
     pkg.lib.xdtts_griffinlim_opts_default(C.byref(o))
     assert (o.nnls_iters, o.power_mode, o.mel_decompress, o.output_normalise, o.batch_shape) == (0, 0, 0, 3, 0)
     assert o.rms_target == np.float32(0.1)
+
+
+def test_mel_images_of_the_reference_talk():
+    """slides/images/melgen_py_vs_rust.svg (slides/melgen.typ:176-184) is the only view of Tacotron2::infer's OUTPUT the reference
+    holds: two nearest-neighbour renderings of one utterance's mel ("Python Output" / "Rust ONNX Output").  What
+    tools/reference_mel_image_facts.py reads off them (statistics only) pins the layout this build returns: 80 rows = mel bands
+    (Array2 (80, F), mod.rs:349-355,430), band 0 first (imshow's default origin puts row 0 at the top, and the speech energy sits
+    at the top), a frame count per utterance that differs between the two runs of the SAME sentence -- the exported graph's
+    always-on prenet dropout moves the stop step -- by a few frames in 135."""
+    with open(os.path.join(G, "reference_audio_facts.json")) as fh:
+        facts = json.load(fh)["mel_images"]["images"]
+    assert set(facts) == {"Python Output", "Rust ONNX Output"}
+    for name, im in facts.items():
+        assert im["bands"] == 80 and im["pixels"] == [496, 168], name
+        assert im["low_bands_at"] == "top" and im["mean_level_top_quarter"] > 1.5 * im["mean_level_bottom_quarter"], name
+        assert im["pixels_per_frame"][0] >= 3 and im["pixels_per_frame"][1] <= 4   # 496 px / ~137 frames: every frame is visible
+        assert 0.0 <= im["floor_share"] < 0.1
+    py, rs = facts["Python Output"]["frames_at_least"], facts["Rust ONNX Output"]["frames_at_least"]
+    assert (py, rs) == (135, 138) and py != rs     # same sentence, different stop step: the dropout is live in the ONNX graph
+    # the product's (80, F) layout is the same orientation: row m of xdtts_tacotron2_infer_ids' output is mel band m
+    # (tests/test_gpu_parity_basic.py compares it with the oracle's [mel][frame] array element by element)
