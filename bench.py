@@ -369,6 +369,24 @@ def main():
         except Exception as e:  # noqa: BLE001  (the headline line must still be printed)
             extra["headline_30_iterations"] = {"error": repr(e)}
     if not args.no_extras:
+        # ---- the same K utterances as ONE sequence call (xdtts_synthesize_sequence): each still decoded alone, batch 1, but the vocoder
+        # of utterance u runs beside the encoder of utterance u + 1 (the frame loop in between owns every CU) -- what a server that
+        # streams sentences gets instead of the reference's strictly sequential loop (src/lib.rs:122-141); same bits per utterance
+        try:
+            seq_utts = [utterances[g] for g in mine]
+            pkg.synthesize_sequence(model, vocoder, seq_utts[:2], [sp] * 2, opts=opts, want_mels=False)
+            barrier()
+            ts0 = time.perf_counter()
+            _m, seq_audio = pkg.synthesize_sequence(model, vocoder, seq_utts, [sp] * len(seq_utts), opts=opts)
+            barrier()
+            es = max_over_ranks(time.perf_counter() - ts0)
+            extra["headline_pipelined"] = {
+                "workload": "configs[1]'s K utterances through one xdtts_synthesize_sequence call: batch 1 per utterance, vocoder(u) overlapped with encoder(u + 1)",
+                "mel_frames_per_s": frames * K * world / es, "ms_per_utterance": es / K * 1e3, "x_realtime": (samples / SAMPLE_RATE) / (es / K),
+                "same_bits_as_the_single_calls": bool(np.array_equal(seq_audio[-1], audio) and np.array_equal(_m[-1], mel))}
+        except Exception as e:  # noqa: BLE001
+            extra["headline_pipelined"] = {"error": repr(e)}
+    if not args.no_extras:
         # ---- the same utterance with the gate ON (the reference's real mode, mod.rs:319-324): gate_layer rigged so that
         # sigmoid(gate) > 0.6 fires exactly at 633 / 167 frames (xd-tts_amd/gate_rig.py; every frame is unchanged), so the
         # device-side stop rule, the survivor hand-over of the pair and the frame-count round trip are TIMED, not only tested

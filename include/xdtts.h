@@ -334,6 +334,17 @@ xdtts_status xdtts_synthesize_batch(xdtts_tacotron2 *h, xdtts_griffinlim *g, con
                                     const int32_t *fixed_steps_per_item, float **mels,
                                     size_t *n_frames, float **audios, size_t *n_samples);
 
+/* XdTts::infer (src/lib.rs:110-159) for a SEQUENCE of n_utt utterances, each decoded alone (batch 1) exactly as
+ * xdtts_synthesize_ids does it -- what a loop over src/lib.rs:122-141 does -- with the vocoder of utterance u overlapped with the
+ * encoder of utterance u + 1 (the frame loop in between owns the whole GPU; it is ordered behind the previous vocoder).
+ * ids[u] / n_ids[u] / splits[u] / n_splits[u] as in xdtts_synthesize_ids (splits may be NULL: one chunk per utterance unless it
+ * exceeds the window); mels may be NULL.  Outputs per utterance, released with xdtts_free.  Same bits as n_utt calls of
+ * xdtts_synthesize_ids; on an error nothing is returned. */
+xdtts_status xdtts_synthesize_sequence(xdtts_tacotron2 *h, xdtts_griffinlim *g, const int64_t *const *ids,
+                                       const size_t *n_ids, const size_t *const *splits, const size_t *n_splits,
+                                       int32_t n_utt, const xdtts_infer_opts *opts, float **mels,
+                                       size_t *n_frames, float **audios, size_t *n_samples);
+
 /* ---- host-side front of Tacotron2::infer (stays on the CPU side of the FFI) ---------------- */
 /* generate_id_list -- src/tacotron2/mod.rs:90-122: 148 symbols; token text of an id. */
 int32_t xdtts_symbol_count(void);

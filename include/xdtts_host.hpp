@@ -196,6 +196,50 @@ inline std::vector<std::pair<Array2, std::vector<float>>> infer_many(const Tacot
   return out;
 }
 
+// XdTts::infer for a sequence of sentences, each decoded alone as the reference does (a loop over src/lib.rs:122-141), the vocoder
+// of one overlapped with the encoder of the next (xdtts_synthesize_sequence): what `app` would call for a text of several sentences.
+inline std::vector<std::pair<Array2, std::vector<float>>> infer_sequence(const Tacotron2 &model, const GriffinLim &vocoder,
+                                                                           const std::vector<std::vector<Unit>> &texts,
+                                                                           const xdtts_infer_opts *opts = nullptr) {
+  xdtts_infer_opts o;
+  xdtts_infer_opts_default(&o);
+  if (opts) o = *opts;
+  const size_t n_utt = texts.size();
+  std::vector<std::vector<int64_t>> ids(n_utt);
+  std::vector<std::vector<size_t>> splits(n_utt);
+  std::vector<const int64_t *> ids_p(n_utt);
+  std::vector<const size_t *> sp_p(n_utt);
+  std::vector<size_t> n_ids(n_utt), n_sp(n_utt);
+  for (size_t u = 0; u < n_utt; ++u) {
+    for (const Unit &x : texts[u]) {
+      const int64_t id = xdtts_unit_id(x.token.c_str(), x.is_character ? 1 : 0);
+      if (id >= 0) ids[u].push_back(id);  // units with no id are dropped, mod.rs:403-406
+    }
+    splits[u].resize(ids[u].size() + 2);
+    size_t n = 0;
+    check(xdtts_find_splits(ids[u].data(), ids[u].size(), (size_t)o.max_chunk, splits[u].data(), splits[u].size(), &n));
+    splits[u].resize(n);
+    ids_p[u] = ids[u].data();
+    n_ids[u] = ids[u].size();
+    sp_p[u] = splits[u].data();
+    n_sp[u] = n;
+  }
+  std::vector<float *> mels(n_utt, nullptr), audios(n_utt, nullptr);
+  std::vector<size_t> nf(n_utt, 0), ns(n_utt, 0);
+  check(xdtts_synthesize_sequence(model.raw(), vocoder.raw(), ids_p.data(), n_ids.data(), sp_p.data(), n_sp.data(), (int32_t)n_utt, &o, mels.data(),
+                                  nf.data(), audios.data(), ns.data()));
+  std::vector<std::pair<Array2, std::vector<float>>> out(n_utt);
+  for (size_t i = 0; i < n_utt; ++i) {
+    out[i].first.rows = 80;
+    out[i].first.cols = nf[i];
+    out[i].first.data.assign(mels[i], mels[i] + 80 * nf[i]);
+    out[i].second.assign(audios[i], audios[i] + ns[i]);
+    xdtts_free(mels[i]);
+    xdtts_free(audios[i]);
+  }
+  return out;
+}
+
 // XdTts::infer's output stage (src/lib.rs:145-157): RTF, `(sample * i16::MAX as f32) as i16`,
 // mono 22050 Hz 16-bit WAV (WAV_SPEC, src/lib.rs:25-30).
 inline std::vector<int16_t> to_i16(const std::vector<float> &audio) {

@@ -105,6 +105,7 @@ SYMBOLS = {
     "xdtts_griffinlim_free": (None, [_VP]),
     "xdtts_synthesize_ids": (_I32, [_VP, _VP, _VP, _SZ, _VP, _SZ, C.POINTER(InferOpts), C.POINTER(_PF), C.POINTER(_SZ), C.POINTER(_PF), C.POINTER(_SZ)]),
     "xdtts_synthesize_batch": (_I32, [_VP, _VP, _VP, _VP, _I32, _I32, _VP, _I32, C.POINTER(InferOpts), _VP, _VP, _VP, _VP, _VP]),
+    "xdtts_synthesize_sequence": (_I32, [_VP, _VP, _VP, _VP, _VP, _VP, _I32, C.POINTER(InferOpts), _VP, _VP, _VP, _VP]),
     "xdtts_symbol_count": (_I32, []),
     "xdtts_symbol_token": (C.c_char_p, [_I32]),
     "xdtts_unit_id": (C.c_int64, [C.c_char_p, _I32]),
@@ -651,3 +652,21 @@ def synthesize_batch(tacotron2, vocoder, utterance_chunks, opts=None, fixed_step
     )
     out_m = [_take(mels[u], N_MEL * nf[u], (N_MEL, nf[u])) for u in range(n_utt)] if want_mels else None
     return out_m, [_take(audios[u], ns[u], (ns[u],)) for u in range(n_utt)]
+
+
+def synthesize_sequence(tacotron2, vocoder, ids_list, splits_list=None, opts=None, want_mels=True):
+    """XdTts::infer (src/lib.rs:110-159) for a sequence of utterances, each decoded alone as `synthesize` does, the vocoder of one
+    overlapped with the encoder of the next (xdtts_synthesize_sequence).  Returns (mels or None, audios)."""
+    n = len(ids_list)
+    idv = [np.ascontiguousarray(x, dtype=np.int64) for x in ids_list]
+    spv = [None if (splits_list is None or splits_list[u] is None) else np.ascontiguousarray(splits_list[u], dtype=np.uintp) for u in range(n)]
+    ids_p = (C.c_void_p * n)(*[x.ctypes.data for x in idv])
+    n_ids = (C.c_size_t * n)(*[x.size for x in idv])
+    sp_p = (C.c_void_p * n)(*[(None if s is None else s.ctypes.data) for s in spv])
+    n_sp = (C.c_size_t * n)(*[(0 if s is None else s.size) for s in spv])
+    mels = (_PF * n)() if want_mels else None
+    audios = (_PF * n)()
+    nf, ns = (C.c_size_t * n)(), (C.c_size_t * n)()
+    _check(lib.xdtts_synthesize_sequence(tacotron2._h, vocoder._h, ids_p, n_ids, sp_p, n_sp, n, C.byref(opts) if opts else None, mels, nf, audios, ns))
+    out_m = [_take(mels[u], N_MEL * nf[u], (N_MEL, nf[u])) for u in range(n)] if want_mels else None
+    return out_m, [_take(audios[u], ns[u], (ns[u],)) for u in range(n)]

@@ -152,6 +152,14 @@ struct PinnedGuard {
   PinnedGuard(PinnedGuard &&o) noexcept : p(o.p) { o.p = nullptr; }
   PinnedGuard(const PinnedGuard &) = delete;
   PinnedGuard &operator=(const PinnedGuard &) = delete;
+  PinnedGuard &operator=(PinnedGuard &&o) noexcept {
+    if (this != &o) {
+      if (p) pinned_pool().put(p);
+      p = o.p;
+      o.p = nullptr;
+    }
+    return *this;
+  }
   ~PinnedGuard() {
     if (p) pinned_pool().put(p);
   }
@@ -351,6 +359,7 @@ struct xdtts_tacotron2 {
   static constexpr int PROBE_AFTER = 64;
   DevBuf<float> pp0, ppA, ppB, mel_dev;
   std::vector<long> pp_sig;  // layout (items, frames, allocations) whose padding is known to be zero in pp0 / ppA / ppB
+  std::function<void()> before_decoder;  // enqueued between the encoder and the frame loop of infer_batch_device (or empty)
   int *host_ctl = nullptr;  // pinned mirror of ctlblk: [0..1] ctl, [HOST_ENC_ERR] / [HOST_DEC_ERR] the engines' error words, [HOST_NF ..] nframes
   static constexpr int HOST_ENC_ERR = 2, HOST_DEC_ERR = 3, HOST_NF = 4, CTL_INTS = HOST_NF + 4096;
 
@@ -1113,6 +1122,7 @@ struct xdtts_tacotron2 {
     HIP_CHECK(hipEventRecord(ev.e[1], stream));
     // (the cooperative BiLSTM's error word comes back with the decoder's own final fetch: same block, same copy)
     if (batched_mode) w.ensure_batched_layout(blob, stream);
+    if (before_decoder) before_decoder();  // (xdtts_synthesize_sequence: the frame loop waits for the previous utterance's vocoder)
     DecoderBufs d = decoder_bufs(B, T, memory.p, pmem.p, o, batched_mode ? 1 : 0);
     if (batched_mode) d.item_perm = item_perm.p;
     if (fixed_per_item || o.fixed_frames_per_id > 0.f) d.use_gate = 0;
@@ -2258,6 +2268,34 @@ static void gl_iterate_and_fetch(xdtts_griffinlim *g, const GlBufs &b, const flo
   fail(XDTTS_ERR_HIP, "Griffin-Lim: the fallback engine reported an exchange failure");
 }
 
+// The two halves of gl_run_from_device_mel for a caller that overlaps the vocoder with other work (xdtts_synthesize_sequence):
+// everything enqueued on g->stream, nothing waited for; then the wait, the engine's error word and -- after a timed-out
+// exchange -- the request again on the fallback engine (S is intact until the next enqueue).  Caller holds g->mu and the chip lock.
+static void gl_enqueue_from_device_mel(xdtts_griffinlim *g, const float *mel_dev_ptr, int F, PinnedGuard &host) {
+  GlBufs b = g->bufs(F);
+  const size_t N = (size_t)g->hop * (size_t)(F - 1);
+  HIP_CHECK(hipEventRecord(g->ev.e[0], g->stream));
+  g->mel_to_linear(mel_dev_ptr, F);
+  HIP_CHECK(hipEventRecord(g->ev.e[1], g->stream));
+  g->probe_tick();
+  g->iterate(b, nullptr, g->iters);
+  launch_gl_output_normalise(g->audio.p, nullptr, 1, 0, (int)N, g->gopts.output_normalise, g->gopts.rms_target, g->norm_parts.p, g->stream);
+  HIP_CHECK(hipEventRecord(g->ev.e[2], g->stream));
+  host = PinnedGuard(N);
+  HIP_CHECK(hipMemcpyAsync(host.p, g->audio.p, N * sizeof(float), hipMemcpyDeviceToHost, g->stream));
+  g->fetch_error_word();
+}
+static void gl_collect(xdtts_griffinlim *g, int F, PinnedGuard &host, float **audio, size_t *n_samples) {
+  g->finish_timings();  // (drains the stream)
+  if (g->persistent_failed()) {
+    host = PinnedGuard();
+    gl_iterate_and_fetch(g, g->bufs(F), nullptr, g->iters, audio, n_samples, true);
+    return;
+  }
+  *audio = host.release();
+  *n_samples = (size_t)g->hop * (size_t)(F - 1);
+}
+
 static void gl_run_from_device_mel(xdtts_griffinlim *g, const float *mel_dev_ptr, int F, float **audio, size_t *n_samples) {
   GlBufs b = g->bufs(F);
   HIP_CHECK(hipEventRecord(g->ev.e[0], g->stream));
@@ -2667,6 +2705,76 @@ xdtts_status xdtts_synthesize_ids(xdtts_tacotron2 *h, xdtts_griffinlim *g, const
     h->finish_timings();  // (stream sync: the mel has landed)
     *mel = mel_host.release();
     *n_frames = (size_t)total;
+  });
+}
+
+// XdTts::infer for a SEQUENCE of utterances, one after the other as the reference runs them (src/lib.rs:110-159: each utterance
+// decoded alone, batch 1) -- but software-pipelined across the two halves: the frame loop owns every CU (weights in the register
+// files), so nothing can run beside it; what can overlap is utterance u's vocoder (mel -> linear, Griffin-Lim, normalise: its own
+// stream) with utterance u + 1's ENCODER (embedding, three convolutions, BiLSTM on 16 CUs, memory layer).  The frame loop of
+// u + 1 is ordered behind the vocoder of u by an event (two grids that each want the chip co-resident never meet), and the host
+// collects u's audio while u + 1 decodes.  Same bits as xdtts_synthesize_ids called once per utterance.
+xdtts_status xdtts_synthesize_sequence(xdtts_tacotron2 *h, xdtts_griffinlim *g, const int64_t *const *ids, const size_t *n_ids,
+                                       const size_t *const *splits, const size_t *n_splits, int32_t n_utt, const xdtts_infer_opts *opts,
+                                       float **mels, size_t *n_frames, float **audios, size_t *n_samples) {
+  return guard([&] {
+    if (!h || !g || !ids || !n_ids || !n_frames || !audios || !n_samples || n_utt <= 0) fail(XDTTS_ERR_BAD_ARG, "null argument / no utterance");
+    if (h->device != g->device) fail(XDTTS_ERR_BAD_ARG, "tacotron2 and griffin-lim handles live on different devices");
+    for (int u = 0; u < n_utt; ++u) {
+      audios[u] = nullptr;
+      n_frames[u] = n_samples[u] = 0;
+      if (mels) mels[u] = nullptr;
+      if (!ids[u] || n_ids[u] == 0) fail(XDTTS_ERR_BAD_ARG, "utterance %d is empty", u);
+    }
+    std::lock_guard<std::mutex> lk(h->mu);
+    std::lock_guard<std::mutex> lk2(g->mu);
+    std::lock_guard<ChipLock> chip(chip_mutex(h->device));  // the whole sequence: co-resident launches of two streams are in flight
+    const xdtts_infer_opts o = resolve_opts(opts);
+    struct Hook {  // (the hook never outlives this call, whatever throws)
+      xdtts_tacotron2 *h;
+      ~Hook() { h->before_decoder = nullptr; }
+    } unhook{h};
+    struct Drain {  // pinned buffers do not go back to the pool with copies in flight
+      hipStream_t a, b;
+      ~Drain() {
+        (void)hipStreamSynchronize(a);
+        (void)hipStreamSynchronize(b);
+      }
+    } drain{h->stream, g->stream};
+    std::vector<PinnedGuard> mel_host(n_utt), audio_host(n_utt);
+    std::vector<int> total(n_utt, 0);
+    std::vector<float *> audio_out(n_utt, nullptr);
+    auto release_all = [&]() {
+      for (int u = 0; u < n_utt; ++u)
+        if (audio_out[u]) pinned_pool().put(audio_out[u]);
+    };
+    try {
+      for (int u = 0; u < n_utt; ++u) {
+        std::vector<int64_t> padded;
+        std::vector<int> lens;
+        chunks_from_splits(ids[u], n_ids[u], splits ? splits[u] : nullptr, (splits && n_splits) ? n_splits[u] : 0, o.max_chunk, padded, lens);
+        if (u > 0) h->before_decoder = [&] { HIP_CHECK(hipStreamWaitEvent(h->stream, g->ev.e[2], 0)); };  // vocoder of u - 1 done (its audio copy is behind it on g->stream)
+        h->infer_batch_device(padded.data(), lens.data(), (int)lens.size(), o.max_chunk, o, nullptr, &total[u]);
+        h->before_decoder = nullptr;
+        if (total[u] < 2) fail(XDTTS_ERR_BAD_ARG, "utterance %d: mel has %d frame(s); the vocoder needs at least 2", u, total[u]);
+        // the frame loop of u has drained, and it waited for the vocoder of u - 1: collect that audio now
+        if (u > 0) gl_collect(g, total[u - 1], audio_host[u - 1], &audio_out[u - 1], &n_samples[u - 1]);
+        mel_host[u] = PinnedGuard((size_t)N_MEL * total[u]);
+        HIP_CHECK(hipStreamWaitEvent(g->stream, h->ev.e[3], 0));  // the vocoder reads the mel behind the post-net
+        HIP_CHECK(hipMemcpyAsync(mel_host[u].p, h->mel_dev.p, (size_t)N_MEL * total[u] * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+        gl_enqueue_from_device_mel(g, h->mel_dev.p, total[u], audio_host[u]);
+      }
+      gl_collect(g, total[n_utt - 1], audio_host[n_utt - 1], &audio_out[n_utt - 1], &n_samples[n_utt - 1]);
+      h->finish_timings();  // (stream sync: every mel has landed)
+    } catch (...) {
+      release_all();
+      throw;
+    }
+    for (int u = 0; u < n_utt; ++u) {
+      audios[u] = audio_out[u];
+      n_frames[u] = (size_t)total[u];
+      if (mels) mels[u] = mel_host[u].release();
+    }
   });
 }
 
