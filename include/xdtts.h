@@ -339,7 +339,8 @@ xdtts_status xdtts_synthesize_batch(xdtts_tacotron2 *h, xdtts_griffinlim *g, con
  * encoder of utterance u + 1 (the frame loop in between owns the whole GPU; it is ordered behind the previous vocoder).
  * ids[u] / n_ids[u] / splits[u] / n_splits[u] as in xdtts_synthesize_ids (splits may be NULL: one chunk per utterance unless it
  * exceeds the window); mels may be NULL.  Outputs per utterance, released with xdtts_free.  Same bits as n_utt calls of
- * xdtts_synthesize_ids; on an error nothing is returned. */
+ * xdtts_synthesize_ids; on an error nothing is returned.  xdtts_tacotron2_last_timings / xdtts_griffinlim_last_timings then
+ * report the SUMS over the sequence (HIP events per utterance). */
 xdtts_status xdtts_synthesize_sequence(xdtts_tacotron2 *h, xdtts_griffinlim *g, const int64_t *const *ids,
                                        const size_t *n_ids, const size_t *const *splits, const size_t *n_splits,
                                        int32_t n_utt, const xdtts_infer_opts *opts, float **mels,

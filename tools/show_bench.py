@@ -5,7 +5,7 @@ print("value %.0f %s  ms/step %.3f  x_realtime %.0f" % (d["value"], d["unit"], d
 print("phases", {k: round(v, 3) for k, v in d["phase_ms_per_utterance"].items()})
 r = d["roofline"]; print("roofline frac %.3f  us/step %.2f  traffic %s" % (r["frac"], r["us_per_step"], r["traffic"]))
 e = d.get("extra") or {}
-for k in ("headline_pipelined", "headline_gate_on", "headline_30_iterations"):
+for k in ("headline_one_call_per_utterance", "headline_gate_on", "headline_30_iterations"):
     if k in e and "mel_frames_per_s" in e[k]:
         print("%s: %.0f frames/s, %.3f ms per utterance" % (k, e[k]["mel_frames_per_s"], e[k]["ms_per_utterance"]))
 if "config3" in e:

@@ -2744,6 +2744,15 @@ xdtts_status xdtts_synthesize_sequence(xdtts_tacotron2 *h, xdtts_griffinlim *g, 
     std::vector<PinnedGuard> mel_host(n_utt), audio_host(n_utt);
     std::vector<int> total(n_utt, 0);
     std::vector<float *> audio_out(n_utt, nullptr);
+    // timing events per utterance (the post-net of u ends while the host is already enqueuing u + 1): utterance u records into a
+    // fresh set, read when everything has drained; xdtts_*_last_timings then report the SUMS over the sequence
+    std::vector<Events> per(n_utt);
+    for (Events &e : per) e.create();
+    float gsum[3] = {0.f, 0.f, 0.f};
+    int steps_sum = 0;
+    auto add_gl = [&]() {
+      for (int i = 0; i < 3; ++i) gsum[i] += g->last_ms[i];
+    };
     auto release_all = [&]() {
       for (int u = 0; u < n_utt; ++u)
         if (audio_out[u]) pinned_pool().put(audio_out[u]);
@@ -2754,18 +2763,37 @@ xdtts_status xdtts_synthesize_sequence(xdtts_tacotron2 *h, xdtts_griffinlim *g, 
         std::vector<int> lens;
         chunks_from_splits(ids[u], n_ids[u], splits ? splits[u] : nullptr, (splits && n_splits) ? n_splits[u] : 0, o.max_chunk, padded, lens);
         if (u > 0) h->before_decoder = [&] { HIP_CHECK(hipStreamWaitEvent(h->stream, g->ev.e[2], 0)); };  // vocoder of u - 1 done (its audio copy is behind it on g->stream)
+        for (int i = 0; i < 4; ++i) std::swap(h->ev.e[i], per[u].e[i]);  // (per[u] now holds what the handle had: utterance u - 1's set, or its own)
         h->infer_batch_device(padded.data(), lens.data(), (int)lens.size(), o.max_chunk, o, nullptr, &total[u]);
         h->before_decoder = nullptr;
+        steps_sum += h->last_steps;
         if (total[u] < 2) fail(XDTTS_ERR_BAD_ARG, "utterance %d: mel has %d frame(s); the vocoder needs at least 2", u, total[u]);
         // the frame loop of u has drained, and it waited for the vocoder of u - 1: collect that audio now
-        if (u > 0) gl_collect(g, total[u - 1], audio_host[u - 1], &audio_out[u - 1], &n_samples[u - 1]);
+        if (u > 0) {
+          gl_collect(g, total[u - 1], audio_host[u - 1], &audio_out[u - 1], &n_samples[u - 1]);
+          add_gl();
+        }
         mel_host[u] = PinnedGuard((size_t)N_MEL * total[u]);
         HIP_CHECK(hipStreamWaitEvent(g->stream, h->ev.e[3], 0));  // the vocoder reads the mel behind the post-net
         HIP_CHECK(hipMemcpyAsync(mel_host[u].p, h->mel_dev.p, (size_t)N_MEL * total[u] * sizeof(float), hipMemcpyDeviceToHost, h->stream));
         gl_enqueue_from_device_mel(g, h->mel_dev.p, total[u], audio_host[u]);
       }
       gl_collect(g, total[n_utt - 1], audio_host[n_utt - 1], &audio_out[n_utt - 1], &n_samples[n_utt - 1]);
-      h->finish_timings();  // (stream sync: every mel has landed)
+      add_gl();
+      h->finish_timings();  // (stream sync: every mel has landed; last_ms = the last utterance's phases)
+      float hsum[4] = {h->last_ms[0], h->last_ms[1], h->last_ms[2], h->last_ms[3]};
+      for (int u = 1; u < n_utt; ++u) {  // utterance u - 1's events sit in per[u]
+        float ms = 0.f;
+        for (int i = 0; i < 3; ++i) {
+          HIP_CHECK(hipEventElapsedTime(&ms, per[u].e[i], per[u].e[i + 1]));
+          hsum[i] += ms;
+        }
+        HIP_CHECK(hipEventElapsedTime(&ms, per[u].e[0], per[u].e[3]));
+        hsum[3] += ms;
+      }
+      for (int i = 0; i < 4; ++i) h->last_ms[i] = hsum[i];
+      for (int i = 0; i < 3; ++i) g->last_ms[i] = gsum[i];
+      h->last_steps = steps_sum;
     } catch (...) {
       release_all();
       throw;
