@@ -88,3 +88,44 @@ def test_sequence_is_faster_than_the_calls_one_by_one(pkg, model):
     print("8 headline utterances: one by one %.3f ms, as a sequence %.3f ms" % (best_loop * 1e3, best_seq * 1e3))
     assert best_seq < 0.99 * best_loop, (best_seq, best_loop)
     voc.close()
+
+
+def test_sequence_survives_a_timed_out_exchange_in_either_half(pkg, model, capfd):
+    """Inside a sequence the co-resident engines keep their fault policy: a Griffin-Lim launch whose exchange times out (test hook:
+    a tiny poll limit + a straggler workgroup) is run again on the fallback engine when its audio is collected -- S is still intact,
+    the next vocoder has not been enqueued -- and a frame loop that loses a workgroup is decoded again on the launch-per-stage
+    engine; every utterance still comes out right, and the engines come back after a reset."""
+    import os
+
+    voc = pkg.create_griffin_lim(iters=12, seed=3)
+    ids = [synth_ids(n, seed=70 + i) for i, n in enumerate([40, 33, 52])]
+    o = pkg.default_opts(fixed_frames_per_id=2.0, dropout_seed=2)
+    want = [pkg.synthesize(model, voc, x, opts=o) for x in ids]
+    os.environ["XDTTS_GL_SPINS"] = "50"
+    os.environ["XDTTS_GL_SLOW"] = "2"
+    try:
+        mels, audios = pkg.synthesize_sequence(model, voc, ids, None, opts=o)
+    finally:
+        del os.environ["XDTTS_GL_SPINS"], os.environ["XDTTS_GL_SLOW"]
+    assert "persistent Griffin-Lim exchange timed out" in capfd.readouterr().err
+    for (m1, a1), m2, a2 in zip(want, mels, audios):
+        assert np.array_equal(m1, m2)
+        assert a1.shape == a2.shape and float(np.sqrt(np.mean((a1 - a2) ** 2))) <= 1e-4   # (the fallback engine: same audio to fp32 drift)
+    voc.close()
+    voc = pkg.create_griffin_lim(iters=12, seed=3)
+    os.environ["XDTTS_PERSIST_FAULT"] = "131"
+    os.environ["XDTTS_PERSIST_SPINS"] = "20000"
+    try:
+        mels, audios = pkg.synthesize_sequence(model, voc, ids, None, opts=o)
+    finally:
+        del os.environ["XDTTS_PERSIST_FAULT"], os.environ["XDTTS_PERSIST_SPINS"]
+    assert "persistent decoder exchange timed out" in capfd.readouterr().err
+    assert model.engine_state()["decoder_persistent"] == 0
+    for (m1, _a1), m2 in zip(want, mels):
+        assert m1.shape == m2.shape and float(np.sqrt(np.mean((m1 - m2) ** 2))) <= 1e-5
+    model.engine_reset()
+    mels, audios = pkg.synthesize_sequence(model, voc, ids, None, opts=o)
+    assert model.engine_state()["decoder_persistent"] == 1
+    for (m1, a1), m2, a2 in zip(want, mels, audios):
+        assert np.array_equal(m1, m2) and np.array_equal(a1, a2)
+    voc.close()
