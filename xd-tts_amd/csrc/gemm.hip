@@ -416,7 +416,9 @@ void launch_gemm_nt(const GemmArgs &g, hipStream_t s) {
   // 64x64 tiles once they fill the chip at least twice over (XDTTS_GEMM_TILE=32|64: developer comparison aid)
   static const int forced = getenv("XDTTS_GEMM_TILE") ? atoi(getenv("XDTTS_GEMM_TILE")) : 0;
   const long tiles64 = (long)((g.N + 63) / 64) * ((g.M + 63) / 64) * g.batch;
-  const bool big = forced ? forced == 64 : (g.N >= 64 && tiles64 >= 512);
+  // (short and very wide -- the context fold of the persistent decoder, M = T = 100 rows x 8273 columns x K = 512 per chunk: its second
+  // 64-row tile is 36 % full; measured 33.4 us with 32x32 tiles, 39.5 with 64x64, 44.4 with 32x64)
+  const bool big = forced ? forced == 64 : (g.N >= 64 && tiles64 >= 512 && !(g.M <= 128 && g.N >= 4096));
   // row tiles per XCD when A (unique bytes: rows x lda) outweighs W -- the batches; XDTTS_GEMM_XCD=0|1 forces it (comparison aid)
   static const int forced_x = getenv("XDTTS_GEMM_XCD") ? atoi(getenv("XDTTS_GEMM_XCD")) : -1;
   long rows = 0;
