@@ -129,3 +129,44 @@ def test_sequence_survives_a_timed_out_exchange_in_either_half(pkg, model, capfd
     for (m1, a1), m2, a2 in zip(want, mels, audios):
         assert np.array_equal(m1, m2) and np.array_equal(a1, a2)
     voc.close()
+
+
+def test_a_sequence_beside_other_handles_on_the_same_gpu(pkg, blob):
+    """One thread streams a sequence through its handles while another thread calls xdtts_synthesize_ids on a second pair of handles of
+    the same GPU: the sequence keeps the per-GPU lock from its first launch to its last collect, the other thread's co-resident
+    launches wait their turn -- same bits as the serial runs, nobody falls off the fast engines."""
+    import threading
+
+    m1, m2 = pkg.Tacotron2.from_blob(blob), pkg.Tacotron2.from_blob(blob)
+    v1, v2 = pkg.create_griffin_lim(iters=20, seed=1), pkg.create_griffin_lim(iters=20, seed=1)
+    ids = [synth_ids(n, seed=90 + i) for i, n in enumerate([70, 45, 88, 31])]
+    o = pkg.default_opts(fixed_frames_per_id=2.5, dropout_seed=6)
+    want = [pkg.synthesize(m1, v1, x, opts=o) for x in ids]
+    out, errs = {}, []
+
+    def seq():
+        try:
+            for _ in range(3):
+                out["seq"] = pkg.synthesize_sequence(m1, v1, ids, None, opts=o)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    def single():
+        try:
+            for _ in range(3):
+                out["single"] = [pkg.synthesize(m2, v2, x, opts=o) for x in ids]
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=seq), threading.Thread(target=single)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for u, (m, a) in enumerate(want):
+        assert np.array_equal(out["seq"][0][u], m) and np.array_equal(out["seq"][1][u], a)
+        assert np.array_equal(out["single"][u][0], m) and np.array_equal(out["single"][u][1], a)
+    assert m1.engine_state()["decoder_persistent"] == 1 and m2.engine_state()["decoder_persistent"] == 1
+    for h in (v1, v2, m1, m2):
+        h.close()
