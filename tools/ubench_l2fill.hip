@@ -25,8 +25,10 @@ __device__ __forceinline__ void wait_vm() {
 }
 
 // NW waves per block; each wave walks `steps` k-steps of its K-slice (wrapping), D ahead
-template <int MODE, int D, int NTA, int NW>
-__global__ __launch_bounds__(64 * NW) void k_fill(const float4 *__restrict__ X, float *sink, int steps) {
+template <int MODE, int D, int NTA, int NW, int PRIO = 0>
+__global__ __launch_bounds__(64 * NW) void k_fill(const float4 *__restrict__ X, float *sink, int steps, unsigned long long *stamps) {
+  const unsigned long long t0 = wall_clock64();
+  if (PRIO && blockIdx.x < gridDim.x / 2) __builtin_amdgcn_s_setprio(PRIO);  // the first half of the grid = the product's main blocks
   constexpr int RX = D + 1, JJ = KSTEPS / NW;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fi = lane & 15, fg = lane >> 4;
@@ -129,6 +131,10 @@ __global__ __launch_bounds__(64 * NW) void k_fill(const float4 *__restrict__ X, 
 #pragma unroll
   for (int t = 0; t < NTA; ++t) s += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
   if (s == 12345.678f) sink[blockIdx.x * blockDim.x + tid] = s;
+  if (stamps && tid == 0) {
+    stamps[2 * blockIdx.x] = t0;
+    stamps[2 * blockIdx.x + 1] = wall_clock64();
+  }
 }
 
 static float *d_x, *d_sink;
@@ -150,12 +156,12 @@ static void run(int bpc, int steps, int gi, const char *label) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * NW), lds, 0, reinterpret_cast<const float4 *>(d_x), d_sink, st);
+  hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * NW), lds, 0, reinterpret_cast<const float4 *>(d_x), d_sink, st, (unsigned long long *)nullptr);
   CK(hipDeviceSynchronize());
   float best = 1e30f;
   for (int rep = 0; rep < 5; ++rep) {
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * NW), lds, 0, reinterpret_cast<const float4 *>(d_x), d_sink, st);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * NW), lds, 0, reinterpret_cast<const float4 *>(d_x), d_sink, st, (unsigned long long *)nullptr);
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms;
@@ -171,6 +177,29 @@ static void run(int bpc, int steps, int gi, const char *label) {
     printf("%-28s bpc %d waves %d D %d NTA %d occ %d: %9.1f us  %6.1f GB/s per CU  %5.1f TB/s chip  %5.1f B/clk/CU%s", label, bpc, NW, D, NTA, occ, us,
            bytes_cu / us * 1e-3, 256.0 * bytes_cu / us * 1e-6, bytes_cu / (us * 2400.0), (MODE == 2 || MODE == 3) ? "" : "\n");
   if (MODE == 2 || MODE == 3) printf("  x%.2f of MFMA-only\n", us / mfma_ref_us[gi]);
+}
+
+// two blocks per CU of the same loop: when does the first half of the grid (s_setprio PRIO) finish, when the second?
+template <int MODE, int D, int NTA, int PRIO>
+static void run_prio(int steps, const char *label) {
+  constexpr int NW = 8, RX = D + 1;
+  auto fn = k_fill<MODE, D, NTA, NW, PRIO>;
+  unsigned long long *st;
+  CK(hipMalloc((void **)&st, 1024 * 16));
+  const int stp = steps / RX * RX;
+  double hi = 0, lo = 0;
+  for (int rep = 0; rep < 3; ++rep) {
+    hipLaunchKernelGGL(fn, dim3(512), dim3(64 * NW), 0, 0, reinterpret_cast<const float4 *>(d_x), d_sink, stp, st);
+    CK(hipDeviceSynchronize());
+    static unsigned long long h[1024];
+    CK(hipMemcpy(h, st, sizeof h, hipMemcpyDeviceToHost));
+    unsigned long long tmin = ~0ull;
+    for (int b = 0; b < 512; ++b) tmin = h[2 * b] < tmin ? h[2 * b] : tmin;
+    hi = lo = 0;
+    for (int b = 0; b < 512; ++b) (b < 256 ? hi : lo) += 0.01 * (double)(h[2 * b + 1] - tmin) / 256.0;
+  }
+  printf("%-28s D %d NTA %d prio %d: first half of the grid done at %7.1f us, second half at %7.1f us (mean block end)\n", label, D, NTA, PRIO, hi, lo);
+  CK(hipFree(st));
 }
 
 int main(int argc, char **argv) {
@@ -218,5 +247,14 @@ int main(int argc, char **argv) {
   run<3, 4, 4, 8>(1, steps, 1, "glds + mfma");
   run<3, 4, 4, 4>(1, steps, 2, "glds + mfma");
   run<3, 8, 4, 4>(1, steps, 2, "glds + mfma");
+  printf("-- priority between the two blocks of a CU (product geometry, 2 x 8 waves)\n");
+  run_prio<4, 1, 4, 0>(steps, "mfma only");
+  run_prio<4, 1, 4, 3>(steps, "mfma only");
+  run_prio<2, 1, 4, 0>(steps, "regs + mfma");
+  run_prio<2, 1, 4, 3>(steps, "regs + mfma");
+  run_prio<2, 3, 4, 0>(steps, "regs + mfma");
+  run_prio<2, 3, 4, 3>(steps, "regs + mfma");
+  run_prio<2, 2, 2, 3>(steps, "regs + mfma");
+  run_prio<2, 4, 2, 3>(steps, "regs + mfma");
   return 0;
 }

@@ -11,6 +11,7 @@
 
 #include <fcntl.h>
 #include <sys/file.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <cerrno>
 #include <cstring>
@@ -233,6 +234,8 @@ class ChipLock {
       if (*c == ':' || *c == '/') *c = '_';
     const std::string path = std::string(dir) + "/xdtts_chip_" + bus + ".lock";
     fd = ::open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+    if (fd >= 0) (void)::fchmod(fd, 0666);  // (the creator's umask must not lock a second user out; fails harmlessly for a non-owner)
+    if (fd < 0) fd = ::open(path.c_str(), O_RDONLY | O_CLOEXEC);  // another user's 0644 file, or fs.protected_regular in a sticky directory: flock needs no write access
     if (fd < 0) {
       // the caller asked for cross-process serialisation and cannot have it: an error, not a warning (without the lock two
       // processes time each other's co-resident launches out into the fallback engines)
@@ -653,7 +656,8 @@ struct xdtts_tacotron2 {
   // Small lock-step batches run the persistent weight-stationary kernel (decoder_persistent.hip)
   // when its 256-workgroup grid can be co-resident; XDTTS_DECODER=launch forces the
   // launch-per-stage path (developer comparison aid).
-  // 3..8 chunks: the persistent MFMA engine (decoder_persistent8.hip), one launch for the whole loop.  It shares the persistent
+  // 3..16 chunks: the persistent MFMA engine (decoder_persistent8.hip: 4 / 8 chunk slots, decoder_persistent16.hip: 16), one launch
+  // for the whole loop.  It shares the persistent
   // engine's fate: a timed-out exchange or a refused launch demotes both (persist_state), the request runs again on the
   // launch-per-stage engine.
   int p8_state = -1;  // -1 unknown, 0 off (XDTTS_P8=0, the device cannot host the grid, or an exchange timed out), 1 usable
@@ -665,7 +669,7 @@ struct xdtts_tacotron2 {
     const char *e = getenv("XDTTS_DECODER");
     if (e && std::string(e) == "launch") return false;
     if (p8_state < 0) {
-      p8_probe_ok = p8_wanted && decoder_p8_supported(device, P8_B_MAX, PERSIST_T_MAX);
+      p8_probe_ok = p8_wanted && decoder_p8_supported(device, 8, PERSIST_T_MAX) && decoder_p8_supported(device, P8_B_MAX, PERSIST_T_MAX);  // (the 8- and the 16-slot kernel)
       p8_state = p8_probe_ok ? 1 : 0;
     }
     // like the persistent engine: the cause of a timed-out exchange (another process holding CUs) may be transient
@@ -1975,7 +1979,7 @@ xdtts_status xdtts_tacotron2_decoder_steps(xdtts_tacotron2 *h, int32_t engine, i
         fail(XDTTS_ERR_HIP, "persistent decoder exchange timed out (grid not co-resident)");
       }
     } else if (engine == 3) {
-      if (!decoder_p8_supported(h->device, P8_B_MAX, PERSIST_T_MAX))
+      if (!decoder_p8_supported(h->device, B, PERSIST_T_MAX))
         fail(XDTTS_ERR_HIP, "persistent MFMA engine not available on this device (its 256-workgroup grid cannot be co-resident)");
       std::lock_guard<ChipLock> chip(chip_mutex(h->device));
       launch_decoder_prenet(d, h->w, st);  // x(step0) = prenet(decoder_input)
@@ -2734,13 +2738,6 @@ xdtts_status xdtts_synthesize_sequence(xdtts_tacotron2 *h, xdtts_griffinlim *g, 
       xdtts_tacotron2 *h;
       ~Hook() { h->before_decoder = nullptr; }
     } unhook{h};
-    struct Drain {  // pinned buffers do not go back to the pool with copies in flight
-      hipStream_t a, b;
-      ~Drain() {
-        (void)hipStreamSynchronize(a);
-        (void)hipStreamSynchronize(b);
-      }
-    } drain{h->stream, g->stream};
     std::vector<PinnedGuard> mel_host(n_utt), audio_host(n_utt);
     std::vector<int> total(n_utt, 0);
     std::vector<float *> audio_out(n_utt, nullptr);
@@ -2748,6 +2745,16 @@ xdtts_status xdtts_synthesize_sequence(xdtts_tacotron2 *h, xdtts_griffinlim *g, 
     // fresh set, read when everything has drained; xdtts_*_last_timings then report the SUMS over the sequence
     std::vector<Events> per(n_utt);
     for (Events &e : per) e.create();
+    // Declared BEHIND the pinned buffers and the event sets, i.e. destroyed BEFORE them: whatever throws (utterance u's chunking
+    // fails while utterance u - 1's mel copy, vocoder and audio copy are still in flight), both streams drain first and only then
+    // do the buffers go back to the shared pool and the events get destroyed.
+    struct Drain {
+      hipStream_t a, b;
+      ~Drain() {
+        (void)hipStreamSynchronize(a);
+        (void)hipStreamSynchronize(b);
+      }
+    } drain{h->stream, g->stream};
     float gsum[3] = {0.f, 0.f, 0.f};
     int steps_sum = 0;
     auto add_gl = [&]() {
@@ -2795,6 +2802,8 @@ xdtts_status xdtts_synthesize_sequence(xdtts_tacotron2 *h, xdtts_griffinlim *g, 
       for (int i = 0; i < 3; ++i) g->last_ms[i] = gsum[i];
       h->last_steps = steps_sum;
     } catch (...) {
+      (void)hipStreamSynchronize(h->stream);  // (nothing in flight writes into a buffer that is handed back below)
+      (void)hipStreamSynchronize(g->stream);
       release_all();
       throw;
     }

@@ -34,19 +34,16 @@
 #include <cstdio>
 #include <cstdlib>
 
-#include "device_utils.h"
-#include "kernels.h"
+#include "p8_exchange.h"
 
 namespace xdtts {
 
 namespace {
 
-typedef unsigned long long u64;
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int PT = 256, NW = PT / 64, NBMAX = P8_B_MAX, P_NCU = ATT_RNN / 4, TP = PERSIST_T_MAX;
+constexpr int PT = 256, NW = PT / 64, NBMAX = 8, GSLOTS = P8_B_MAX, P_NCU = ATT_RNN / 4, TP = PERSIST_T_MAX;  // GSLOTS: chunk slots the granule arrays are laid out for (the 16-slot kernel's too)
 constexpr int ATTN_CU = 8, PRE_CU = 16, EP_LD = TP, MEL_GL = 96, WPAD = TP + 32;
-constexpr unsigned P_SPIN_LIMIT = 1u << 21, ACT_BIT = 0x80000000u;
+constexpr unsigned P_SPIN_LIMIT = 1u << 21;
 #ifndef XDTTS_P8_ATTN_SCHED
 #define XDTTS_P8_ATTN_SCHED 0
 #endif
@@ -59,116 +56,8 @@ static_assert(NBMAX == 8 && ATT_RNN == DEC_RNN && P_NCU == 256 && (ATTN_CU + PRE
 static_assert(TP == 128 && PRENET == PT && EMB == 2 * PT && ATT_RNN == 4 * PT, "thread <-> granule maps below");
 
 // chunk slots of the kernel instance that serves a batch of B
-__host__ __device__ constexpr int p8_slots(int B) { return B <= 4 ? 4 : NBMAX; }
+__host__ __device__ constexpr int p8_slots(int B) { return B <= 4 ? 4 : (B <= NBMAX ? NBMAX : P8_B_MAX); }
 
-__device__ __forceinline__ void publish(u64 *slot, unsigned tag, float v) {
-  __hip_atomic_store(slot, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ u64 peek(const u64 *slot) { return __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-struct PollCtl {
-  int *err;
-  unsigned limit;
-};
-__device__ __forceinline__ bool give_up(unsigned &spins, const PollCtl &pc) {
-  if (++spins > pc.limit || ((spins & 127u) == 0 && __hip_atomic_load(pc.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-    atomicExch(pc.err, 1);
-    return true;
-  }
-  __builtin_amdgcn_s_sleep(1);
-  return false;
-}
-// N granules at base[at(i)] (those of the bit mask `need`), all loads in flight together; every value is handed to
-// sink(i, value, tag) the moment its tag matches -- nothing is kept in registers behind the loads themselves.  A timed-out slot
-// is never delivered.  EVERY round issues all N loads (a granule that is not wanted, or has been delivered, is asked for again --
-// or the first wanted one in its place): with the loads themselves under per-lane conditions, lanes were handed the value of
-// ANOTHER granule of the same round now and then (four neighbouring lanes = one 32-byte sector at a time, caught by comparing
-// the LDS copy with the granule it came from: the chunk-1 value in chunk 0's place).  That was a 512-thread build that spilled
-// 1.3 kB per lane; the form alone does not misdeliver (tools/ubench_condload.hip: 0 wrong values in 2 x 3000 x 256 gathers of
-// 4..32 granules per thread, conditional or not), so the culprit was probably the spill code around the divergent loads -- the
-// kernel as it is has no scratch, and keeps the unconditional form.
-__device__ __forceinline__ void nap(int n) {
-#pragma unroll 1
-  for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
-}
-template <int N, class At>
-__device__ __forceinline__ void gather_issue(u64 (&v)[N], const u64 *base, unsigned need, At at) {
-  const int first = need ? __ffs(need) - 1 : 0;
-  unsigned zero = 0u;
-  asm volatile("" : "+v"(zero));  // (opaque: the N addresses are formed next to their loads, not kept in 2 N registers across the loop)
-#pragma unroll
-  for (int i = 0; i < N; ++i) v[i] = peek(base + (zero + at(((need >> i) & 1u) ? i : first)));
-}
-// v: the first round's loads, issued by the caller some work ago (gather_issue)
-template <int N, class At, class Sink>
-__device__ __forceinline__ unsigned gather_from(u64 (&v)[N], const u64 *base, unsigned want, unsigned need, const PollCtl &pc, At at, Sink sink) {
-  unsigned pending = N < 32 ? need & ((1u << (N & 31)) - 1u) : need, spins = 0;
-  need = pending;
-  while (pending) {
-    if (spins) gather_issue<N>(v, base, need, at);
-#pragma unroll
-    for (int i = 0; i < N; ++i)
-      if ((pending >> i) & 1u) {
-        const unsigned t = (unsigned)(v[i] >> 32);
-        if ((t & ~ACT_BIT) == want) {
-          sink(i, __uint_as_float((unsigned)v[i]), t);
-          pending &= ~(1u << i);
-        }
-      }
-    if (pending && give_up(spins, pc)) return spins;
-  }
-  return spins;  // failed rounds
-}
-template <int N, class At, class Sink>
-__device__ __forceinline__ unsigned gather(const u64 *base, unsigned want, unsigned need, const PollCtl &pc, At at, Sink sink) {
-  u64 v[N];
-  need = N < 32 ? need & ((1u << (N & 31)) - 1u) : need;
-  if (need) gather_issue<N>(v, base, need, at);
-  return gather_from<N>(v, base, want, need, pc, at, sink);
-}
-// The same for a write-once slab of plain values: N 16-byte loads at byte offsets at(i) of `slab`, a quad is delivered once none
-// of its four words is the fill pattern (they are four dword stores of one producer, or one 16-byte store).  First round sc1,
-// retries sc0 sc1.
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-constexpr unsigned UNWRITTEN = 0xffffffffu;
-__device__ __forceinline__ unsigned value_bits(float v) {  // what a producer stores: never the fill pattern
-  const unsigned b = __float_as_uint(v);
-  return b == UNWRITTEN ? 0x7fc00000u : b;
-}
-__device__ __forceinline__ void put(unsigned *slot, unsigned bits) { __hip_atomic_store(slot, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <int N, class At, class Sink>
-__device__ __forceinline__ unsigned gather16(const unsigned *slab, unsigned need, const PollCtl &pc, At at, Sink sink) {
-  unsigned pending = need & ((1u << N) - 1u), spins = 0;
-  const int first = pending ? __ffs(pending) - 1 : 0;
-  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)slab, 0, 0x7fffffff, 0x00020000);
-  while (pending) {
-    u32x4 v[N];
-    unsigned zero = 0u;
-    asm volatile("" : "+v"(zero));
-    if (spins == 0) {
-#pragma unroll
-      for (int i = 0; i < N; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(zero + at(((need >> i) & 1u) ? i : first)), 0, 16);
-    } else {
-#pragma unroll
-      for (int i = 0; i < N; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b128(r, (int)(zero + at(((need >> i) & 1u) ? i : first)), 0, 17);
-    }
-#pragma unroll
-    for (int i = 0; i < N; ++i)
-      if (((pending >> i) & 1u) && v[i].x != UNWRITTEN && v[i].y != UNWRITTEN && v[i].z != UNWRITTEN && v[i].w != UNWRITTEN) {
-        sink(i, v[i]);
-        pending &= ~(1u << i);
-      }
-    if (pending && give_up(spins, pc)) return spins;
-    asm volatile("" ::: "memory");
-  }
-  return spins;  // failed rounds
-}
-__device__ __forceinline__ float4 as_f4(u32x4 v) { return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)); }
-__device__ __forceinline__ float4 lds4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
-
-struct P8Weights {
-  const float4 *att_w, *dec_w, *q_w, *proj_w;
-  const float *att_b, *dec_b, *v_w, *loc_fused, *proj_b, *pre0T, *pre1T;
-};
 
 // NQ b128 loads of the wave's slice of one state segment (seg: LDS base of the segment in B order [k/4][NB][4]; q0: the wave's
 // first column quad-of-quads), 4 MFMAs each, into acc.  A[q] = the lane's four weights of columns 16 (q0 + q) + 4 kk .. + 3.
@@ -788,14 +677,14 @@ __global__ void k_p8_seed_at(P8Bufs g, const int *limits, const float *x, int st
 // Exchange memory of a launch of `nsteps` steps of B chunks, in 8-byte words: the two granule edges (two step parities) and the
 // four write-once rings (one slab per step; x one more, for the step after the last)
 static size_t ring_values(int B, int nsteps) { return (size_t)p8_slots(B) * ((size_t)(nsteps + 1) * PRENET + (size_t)nsteps * (ATT_RNN + EMB + DEC_RNN)); }
-size_t p8_exchange_words(int B, int nsteps) { return (size_t)2 * NBMAX * (ATTN_CU * EP_LD + MEL_GL) + (ring_values(B, nsteps) + 1) / 2; }
+size_t p8_exchange_words(int B, int nsteps) { return (size_t)2 * GSLOTS * (ATTN_CU * EP_LD + MEL_GL) + (ring_values(B, nsteps) + 1) / 2; }
 
 P8Bufs p8_bufs(unsigned long long *base, int *err, int B, int nsteps) {
   P8Bufs g{};
   const size_t nb = (size_t)p8_slots(B);
   g.ep = base;
-  g.mel = g.ep + (size_t)2 * NBMAX * ATTN_CU * EP_LD;
-  g.rx = reinterpret_cast<unsigned *>(g.mel + (size_t)2 * NBMAX * MEL_GL);
+  g.mel = g.ep + (size_t)2 * GSLOTS * ATTN_CU * EP_LD;
+  g.rx = reinterpret_cast<unsigned *>(g.mel + (size_t)2 * GSLOTS * MEL_GL);
   g.rhatt = g.rx + nb * (size_t)(nsteps + 1) * PRENET;
   g.rctx = g.rhatt + nb * (size_t)nsteps * ATT_RNN;
   g.rhdec = g.rctx + nb * (size_t)nsteps * EMB;
@@ -804,18 +693,21 @@ P8Bufs p8_bufs(unsigned long long *base, int *err, int B, int nsteps) {
   g.delay[0] = g.delay[2] = 16;
   g.delay[1] = 64;
   g.delay[4] = 24;
-  if (const char *e = getenv("XDTTS_P8_DELAY")) sscanf(e, "%d,%d,%d,%d,%d", &g.delay[0], &g.delay[1], &g.delay[2], &g.delay[3], &g.delay[4]);  // developer sweep
+  g.delay[5] = 16;
+  if (nb > NBMAX) g.delay[4] = g.delay[5] = 0;  // 16-slot kernel: its role workgroups run MFMAs between a publish and the poll that answers it
+  if (const char *e = getenv("XDTTS_P8_DELAY")) sscanf(e, "%d,%d,%d,%d,%d,%d", &g.delay[0], &g.delay[1], &g.delay[2], &g.delay[3], &g.delay[4], &g.delay[5]);  // developer sweep
   return g;
 }
 
 static void fill_exchange(const DecoderBufs &d, const P8Bufs &g, hipStream_t s) {
-  HIP_CHECK(hipMemsetAsync(g.ep, 0, (size_t)2 * NBMAX * (ATTN_CU * EP_LD + MEL_GL) * sizeof(unsigned long long), s));
+  HIP_CHECK(hipMemsetAsync(g.ep, 0, (size_t)2 * GSLOTS * (ATTN_CU * EP_LD + MEL_GL) * sizeof(unsigned long long), s));
   HIP_CHECK(hipMemsetAsync(g.rx, 0xff, ring_values(d.B, g.ring_steps) * sizeof(unsigned), s));
 }
 
 // The grid must be co-resident: one workgroup per CU on a 256-CU part, nothing else of ours running.
 bool decoder_p8_supported(int device, int B, int T) {
-  if (B < 1 || B > NBMAX || T > TP) return false;
+  if (B < 1 || B > P8_B_MAX || T > TP) return false;
+  if (B > NBMAX) return decoder_p16_supported(device, T);
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) return false;
   if (prop.multiProcessorCount < P_NCU) return false;
@@ -838,7 +730,7 @@ void launch_p8_seed_at(const DecoderBufs &d, const P8Bufs &g, const int *limits_
 }
 
 void launch_decoder_p8(const DecoderBufs &d, const DeviceWeights &w, const P8Bufs &g, int nsteps, hipStream_t s) {
-  if (d.B < 1 || d.B > NBMAX || d.T > TP) fail(XDTTS_ERR_BAD_ARG, "persistent MFMA decoder: %d chunks of %d encoder steps (max %d, %d)", d.B, d.T, NBMAX, TP);
+  if (d.B < 1 || d.B > P8_B_MAX || d.T > TP) fail(XDTTS_ERR_BAD_ARG, "persistent MFMA decoder: %d chunks of %d encoder steps (max %d, %d)", d.B, d.T, P8_B_MAX, TP);
   if (nsteps > g.ring_steps) fail(XDTTS_ERR_BAD_ARG, "persistent MFMA decoder: %d steps on an exchange laid out for %d", nsteps, g.ring_steps);
   P8Weights pw{};
   pw.att_w = reinterpret_cast<const float4 *>(w.att_w.p);
@@ -852,6 +744,10 @@ void launch_decoder_p8(const DecoderBufs &d, const DeviceWeights &w, const P8Buf
   pw.proj_b = w.proj_b.p;
   pw.pre0T = w.pre0T.p;
   pw.pre1T = w.pre1T.p;
+  if (d.B > NBMAX) {  // 9..16 chunks: the 16-slot kernel (decoder_persistent16.hip), same exchange, same seed
+    launch_decoder_p16(d, pw, g, nsteps, s);
+    return;
+  }
   const void *fn = p8_slots(d.B) == 4 ? reinterpret_cast<const void *>(k_decoder_persistent8<4>) : reinterpret_cast<const void *>(k_decoder_persistent8<NBMAX>);
 #ifdef XDTTS_P8_PROFILE
   static unsigned long long *prof_dev = nullptr;

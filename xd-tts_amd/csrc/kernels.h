@@ -142,14 +142,14 @@ void launch_decoder_persistent(const DecoderBufs &d, const DeviceWeights &w, con
 
 // ---- persistent weight-stationary decoder for 3..8 chunks (decoder_persistent8.hip): the LSTMs of all chunks as one MFMA
 // stream per wave, the context as a sixth exchange ------------------------------------------------------------------------
-constexpr int P8_B_MAX = 8;
+constexpr int P8_B_MAX = 16;  // 3..8 chunks: k_decoder_persistent8<4 / 8>; 9..16: k_decoder_persistent16 (same exchange layout, 16 chunk slots)
 constexpr int P8_STEPS_MAX = 16384;  // longest request it takes: 190 s of speech, 1.5 GB of ring at 8 chunk slots
 struct P8Bufs {
   unsigned *rx, *rhatt, *rctx, *rhdec;  // write-once rings of plain values [step][chunk slots][n], 0xFFFFFFFF = not yet written
-  unsigned long long *ep, *mel;         // {tag, value} granules, [2 step parities][P8_B_MAX][n] each
+  unsigned long long *ep, *mel;         // {tag, value} granules, [2 step parities][chunk slots][n] each (row strides: the serving kernel's slot count)
   int *err;          // set by a workgroup whose bounded spin ran out
   int spins, fault;  // test hooks: poll limit (0 = default) and a workgroup (index + 1) that never runs
-  int delay[5];      // naps (64 clocks each) before the first poll of h_att / ctx / h_dec / x / the partial energies
+  int delay[6];      // naps (64 clocks each) before the first poll of h_att / ctx / h_dec / x / the partial energies / the mel rows (16-slot kernel)
   int ring_steps;    // steps the rings are laid out for
   unsigned long long *prof;  // developer build (-DXDTTS_P8_PROFILE): [workgroup][32] phase clocks
 };
@@ -161,6 +161,13 @@ void launch_p8_seed_at(const DecoderBufs &d, const P8Bufs &g, const int *limits_
 // Runs up to `nsteps` decoder steps of d.B <= 8 chunks in one launch (ends early when every chunk has stopped); frames / gates /
 // nframes are complete on return, the state is written back, ctl[0] = steps executed.
 void launch_decoder_p8(const DecoderBufs &d, const DeviceWeights &w, const P8Bufs &g, int nsteps, hipStream_t s);
+// the 16-slot kernel behind the two functions above (decoder_persistent16.hip)
+struct P8Weights {
+  const float4 *att_w, *dec_w, *q_w, *proj_w;
+  const float *att_b, *dec_b, *v_w, *loc_fused, *proj_b, *pre0T, *pre1T;
+};
+bool decoder_p16_supported(int device, int T);
+void launch_decoder_p16(const DecoderBufs &d, const P8Weights &w, const P8Bufs &g, int nsteps, hipStream_t s);
 
 // ---- NT GEMM on the f32 MFMA: C = act(A W^T + bias) (+R) ---------------------------------------
 struct GemmArgs {
