@@ -52,14 +52,14 @@ def snapshot(states, T):
 
 
 def chunks_for(orc, blob, B):
-    lens = [37, 91, 12, 58, 23, 100, 64, 5][:B]
+    lens = [37, 91, 12, 58, 23, 100, 64, 5, 77, 19, 46, 83, 30, 68, 9, 52][:B]
     enc = [encode(orc, blob, n, seed=31 + i) for i, n in enumerate(lens)]
     mem = np.stack([e[0] for e in enc])
     pm = np.stack([e[1] for e in enc])
     return lens, mem, pm
 
 
-@pytest.mark.parametrize("engine,B", [("persistent", 1), ("persistent", 2), ("batched", 6), ("launch", 3), ("persistent8", 3), ("persistent8", 4), ("persistent8", 8)])
+@pytest.mark.parametrize("engine,B", [("persistent", 1), ("persistent", 2), ("batched", 6), ("launch", 3), ("persistent8", 3), ("persistent8", 4), ("persistent8", 8), ("persistent8", 9), ("persistent8", 16)])
 def test_teacher_forced_step_all_nine_outputs_per_engine(pkg, model, orc, blob, engine, B):
     lens, mem, pm = chunks_for(orc, blob, B)
     T = mem.shape[1]
@@ -83,7 +83,7 @@ def test_teacher_forced_step_all_nine_outputs_per_engine(pkg, model, orc, blob, 
     assert worst > 0  # two different implementations really were compared
 
 
-@pytest.mark.parametrize("engine,B", [("persistent", 1), ("persistent", 2), ("batched", 6), ("batched", 1), ("launch", 2), ("persistent8", 3), ("persistent8", 8), ("persistent8", 1)])
+@pytest.mark.parametrize("engine,B", [("persistent", 1), ("persistent", 2), ("batched", 6), ("batched", 1), ("launch", 2), ("persistent8", 3), ("persistent8", 8), ("persistent8", 1), ("persistent8", 12), ("persistent8", 16)])
 def test_written_back_state_after_a_60_step_run(pkg, model, orc, blob, engine, B):
     """n_steps = 60 from DecoderState::new (mod.rs:202-233): every frame, every gate logit and the seven state
     tensors the engine leaves behind against the oracle's after the same 60 calls."""
@@ -105,7 +105,7 @@ def test_written_back_state_after_a_60_step_run(pkg, model, orc, blob, engine, B
         assert np.abs(gst[k] - after[k]).max() <= 1e-5, (engine, k, float(np.abs(gst[k] - after[k]).max()))
 
 
-@pytest.mark.parametrize("engine,B", [("persistent", 2), ("batched", 5), ("launch", 1), ("persistent8", 5)])
+@pytest.mark.parametrize("engine,B", [("persistent", 2), ("batched", 5), ("launch", 1), ("persistent8", 5), ("persistent8", 11)])
 def test_step_hook_with_a_short_encoder_window_and_an_odd_step_count(pkg, model, orc, blob, engine, B):
     """T = 64 rows of encoder memory (not the reference's 100), 7 steps from step 3 of the oracle's run: odd counts end on the
     other ping-pong half of the launch-per-stage and batched engines."""
@@ -113,7 +113,7 @@ def test_step_hook_with_a_short_encoder_window_and_an_odd_step_count(pkg, model,
     rng = np.random.Generator(np.random.PCG64(77))
     mem = (rng.standard_normal((B, T, 512)) * 0.5).astype(np.float32)
     pm = (rng.standard_normal((B, T, 128)) * 0.5).astype(np.float32)
-    lens = [64, 41, 9, 57, 30][:B]
+    lens = [64, 41, 9, 57, 30, 22, 60, 13, 48, 35, 5][:B]
     opts = [orc.default_opts(dropout_seed=3, item=10 + b) for b in range(B)]
     sts = [orc.new_state() for _ in range(B)]
     for step in range(n0):
@@ -145,13 +145,13 @@ def test_persistent_step_hook_refuses_an_inconsistent_context(pkg, model, orc, b
                             np.zeros((3, 80), dtype=np.float32), 0, 1)  # three chunks: not the persistent engine's shape
 
 
-@pytest.mark.parametrize("engine,B", [("persistent", 1), ("persistent", 2), ("launch", 2), ("persistent8", 3), ("persistent8", 6), ("batched", 9)])
+@pytest.mark.parametrize("engine,B", [("persistent", 1), ("persistent", 2), ("launch", 2), ("persistent8", 3), ("persistent8", 6), ("persistent8", 10), ("batched", 17)])
 def test_explicit_dropout_masks_on_every_engine(pkg, orc, blob, engine, B):
     """dropout_mode 2: the caller's keep bytes [chunk][step][layer][unit] replace the seeded stream; every chunk must
     equal the oracle run with ITS masks (the batched engine sorts the chunks by length internally)."""
-    lens = [37, 91, 12, 58, 23, 100, 45, 71, 8][:B]
+    lens = [37, 91, 12, 58, 23, 100, 45, 71, 8, 66, 29, 84, 17, 53, 95, 40, 62][:B]
     ids = [synth_ids(n, seed=61 + i) for i, n in enumerate(lens)]
-    steps = [24, 40, 16, 33, 40, 9, 28, 36, 12][:B]
+    steps = [24, 40, 16, 33, 40, 9, 28, 36, 12, 31, 19, 40, 7, 26, 38, 14, 22][:B]
     rng = np.random.Generator(np.random.PCG64(99))
     masks = (rng.random((B, 40, 2, 256)) < 0.5).astype(np.uint8)
     masks[0, :, 1, :] *= 3  # any non-zero byte keeps

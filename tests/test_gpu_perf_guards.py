@@ -22,7 +22,7 @@ def _us_per_step(pkg, model, B, n=300):
     return best
 
 
-@pytest.mark.parametrize("B,bound", [(1, 12.0), (2, 15.5), (4, 20.0), (8, 23.0), (16, 36.0), (52, 54.0)])
+@pytest.mark.parametrize("B,bound", [(1, 12.0), (2, 15.5), (4, 20.0), (8, 23.0), (9, 23.0), (12, 23.0), (16, 23.0), (17, 36.0), (52, 54.0)])
 def test_decoder_engines_step_time(pkg, model, B, bound):
     us = _us_per_step(pkg, model, B)
     assert us <= bound, "B=%d: %.1f us per lock-step iteration (bound %.1f)" % (B, us, bound)

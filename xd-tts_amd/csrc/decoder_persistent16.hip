@@ -36,7 +36,10 @@ constexpr int L2C = PRENET / PRE_CU;  // layer-2 columns per projection / prenet
 #ifndef XDTTS_P16_HSPLIT
 #define XDTTS_P16_HSPLIT 4
 #endif
-constexpr int HSPLIT = XDTTS_P16_HSPLIT, HQ = 16 / HSPLIT;  // the sixteen operand quads of a hidden vector in this many gather + MFMA rounds
+#ifndef XDTTS_P16_NBUF
+#define XDTTS_P16_NBUF 2
+#endif
+constexpr int HSPLIT = XDTTS_P16_HSPLIT, HQ = 16 / HSPLIT, NBUF = XDTTS_P16_NBUF;  // NBUF: rounds of operand registers (rounds in flight)  // the sixteen operand quads of a hidden vector in this many gather + MFMA rounds
 #ifndef XDTTS_P16_AUX
 #define XDTTS_P16_AUX 16
 #endif
@@ -49,9 +52,12 @@ constexpr int AUX1 = XDTTS_P16_AUX;  // cache policy of the FIRST poll of an ope
 #endif
 constexpr bool ROLE_FIRST = XDTTS_P16_ROLE_FIRST != 0;  // role workgroups: the exchange chain first, the hidden vector's MFMAs behind the role's publish
 #ifndef XDTTS_P16_RF_SPLIT
-#define XDTTS_P16_RF_SPLIT 2
+#define XDTTS_P16_RF_SPLIT 1
 #endif
-constexpr int RF_SPLIT = XDTTS_P16_RF_SPLIT;            // ROLE_FIRST: rounds of a hidden vector's MFMAs a role workgroup runs inside its exchange's shadow (the rest behind its publish)
+#ifndef XDTTS_P16_RF_SPLIT_P
+#define XDTTS_P16_RF_SPLIT_P 0
+#endif
+constexpr int RF_SPLIT = XDTTS_P16_RF_SPLIT, RF_SPLIT_P = XDTTS_P16_RF_SPLIT_P;            // ROLE_FIRST: rounds of a hidden vector's MFMAs a role workgroup runs inside its exchange's shadow (the rest behind its publish)
 #ifndef XDTTS_P16_EARLY_BEGIN
 #define XDTTS_P16_EARLY_BEGIN 0
 #endif
@@ -104,7 +110,7 @@ __device__ __forceinline__ unsigned operand_gather(u32x4 (&v)[N], const unsigned
 // step are kept in registers across the whole loop) + the instruction's immediate offset.
 template <int NQ>
 struct OpBuf {
-  u32x4 b[2][NQ];
+  u32x4 b[NBUF][NQ];
 };
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t slab_rsrc(const unsigned *slab) { return __builtin_amdgcn_make_buffer_rsrc((void *)slab, 0, 0x7fffffff, 0x00020000); }
 template <int NQ>
@@ -116,8 +122,8 @@ template <int NQ>
 __device__ __forceinline__ void stream_begin(OpBuf<NQ> &ob, const unsigned *slab, unsigned base) {
   const __amdgpu_buffer_rsrc_t r = slab_rsrc(slab);
   asm volatile("" : "+v"(base));
-  stream_issue<NQ>(ob.b[0], r, base, 0);
-  stream_issue<NQ>(ob.b[1], r, base, 1);
+#pragma unroll
+  for (int rd = 0; rd < NBUF; ++rd) stream_issue<NQ>(ob.b[rd], r, base, rd);
 }
 template <int NQ, int R, int FROM = 0, int TO = R, class F>
 __device__ __forceinline__ void stream_finish(OpBuf<NQ> &ob, const unsigned *slab, unsigned base, bool on, const PollCtl &pc, F consume) {
@@ -125,7 +131,7 @@ __device__ __forceinline__ void stream_finish(OpBuf<NQ> &ob, const unsigned *sla
   asm volatile("" : "+v"(base));
 #pragma unroll
   for (int rd = FROM; rd < TO; ++rd) {
-    u32x4(&v)[NQ] = ob.b[rd & 1];
+    u32x4(&v)[NQ] = ob.b[rd % NBUF];
     unsigned pending = 0u, spins = 0;
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
@@ -144,7 +150,7 @@ __device__ __forceinline__ void stream_finish(OpBuf<NQ> &ob, const unsigned *sla
       asm volatile("" ::: "memory");
     }
     consume(rd, v);
-    if (rd + 2 < R) stream_issue<NQ>(v, r, base, rd + 2);
+    if (rd + NBUF < R) stream_issue<NQ>(v, r, base, rd + NBUF);
   }
 }
 // one quad whose first-round load `v` is in flight: polled until complete
@@ -684,9 +690,10 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent16(DecoderBufs d, P8Bu
       stream_finish<HQ, HSPLIT, decltype(from)::value, decltype(to)::value>(db, slab_d, dbase, act_n, pc,
                                                                             [&](int rd, const u32x4(&dq)[HQ]) { mfma_two<HQ>(accD, acc2, dd, dq, HQ * rd); });
     };
+    using IP = std::integral_constant<int, RF_SPLIT_P>;
     if (!(ROLE_FIRST && pre_on)) h_dec_mfmas(I0{}, IR{});
     else {
-      h_dec_mfmas(I0{}, IH{});  // (in the time the mel rows travel)
+      h_dec_mfmas(I0{}, IP{});  // (in the time the mel rows travel)
       nap(g.delay[5]);
     }
     P16_MARK(15);
@@ -753,7 +760,7 @@ __global__ __launch_bounds__(PT) void k_decoder_persistent16(DecoderBufs d, P8Bu
         }
         put(g.rx + (slot + NB + rb) * PRENET + L2C * rk + (tid + oz), (value_bits(o) & 0x7fffffffu) | (nxt ? 0u : 0x80000000u));  // (x >= 0; a -0.0 must not read as "stopped")
       }
-      if (ROLE_FIRST) h_dec_mfmas(IH{}, IR{});
+      if (ROLE_FIRST) h_dec_mfmas(IP{}, IR{});
     }
     accD += acc2;
     P16_MARK(16);
