@@ -85,7 +85,7 @@ def edge_floor(pkg, device):
         return None, {"error": repr(e)}
 
 
-def cpu_baseline():
+def cpu_baseline(parity_dir=None):
     """The CPU ports of the same algorithm on this box's host cores, each on the full config-2 utterance
     once (oracle/cpu_baseline.py, one process per leg with a hard timeout): the single-thread C oracle
     (the reference's execution model), the same source with OpenMP, and a torch-CPU restatement.  The
@@ -96,9 +96,10 @@ def cpu_baseline():
     ncpu = os.cpu_count() or 1
     nthr = min(ncpu, 32)
 
-    def leg(name, threads):
+    def leg(name, threads, extra_arg=None):
         try:
-            r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), name, str(threads)], capture_output=True, text=True, timeout=150)
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), name, str(threads)] + ([extra_arg] if extra_arg else []),
+                               capture_output=True, text=True, timeout=150)
             if r.returncode != 0:
                 return {"error": r.stderr.strip().splitlines()[-1] if r.stderr.strip() else "rc %d" % r.returncode}
             return json.loads(r.stdout.strip().splitlines()[-1])
@@ -107,7 +108,7 @@ def cpu_baseline():
         except Exception as e:   # a baseline leg must never take the bench line down
             return {"error": repr(e)}
 
-    out = leg("c1", 1)
+    out = leg("c1", 1, parity_dir)
     log("cpu baseline: 1 thread done")
     out["kind"] = "port"
     out["host_cores"] = ncpu
@@ -118,6 +119,20 @@ def cpu_baseline():
     out["all_cores_torch"] = leg("torch", nthr)
     log("cpu baseline: torch done")
     return out
+
+
+def parity_check(parity_dir):
+    """The checker beside the number (oracle/cpu_baseline.py parity, its own process, after the timed region): the mel and the
+    30- / 60-iteration audio of the FIRST TIMED utterance against the oracle on the same inputs."""
+    import subprocess
+
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "parity", parity_dir], capture_output=True, text=True, timeout=300)
+        if r.returncode != 0:
+            return {"error": r.stderr.strip().splitlines()[-1] if r.stderr.strip() else "rc %d" % r.returncode}
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)}
 
 
 def log(msg):
@@ -275,6 +290,7 @@ def main():
         "steps": K,
         "warmup": args.warmup,
         "ms_per_step": elapsed / K * 1e3,
+        "ms_per_step_one_call": None,   # (filled below: the same K utterances as K synchronous calls, the headline form of rounds 1-4)
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -284,8 +300,9 @@ def main():
             "workload": "BASELINE.json configs[1]: batch=1 utterance, 120 phoneme ids -> chunks %s (window 100) -> %d mel frames (gate disabled) -> %d-iter Griffin-Lim -> %d samples"
             % (lens, frames, GL_ITERS, samples),
             "utterances_per_gpu_per_step": 1,
-            "submission": "the K utterances of a rank as one xdtts_synthesize_sequence call: batch 1 per utterance, vocoder(u) beside encoder(u + 1); "
-                          "extra.headline_one_call_per_utterance = K synchronous xdtts_synthesize_ids calls (rounds 1-4's headline)",
+            "submission": "the K utterances of a rank as one xdtts_synthesize_sequence call: batch 1 per utterance, vocoder(u) beside encoder(u + 1) -- "
+                          "`value` / `ms_per_step` (rounds 5-6).  The round-over-round series of rounds 1-4 is the one-call-per-utterance form: top-level "
+                          "`ms_per_step_one_call` / `value_one_call` (= extra.headline_one_call_per_utterance), K synchronous xdtts_synthesize_ids calls",
             "parallelism": "utterance-shard x%d (xd-tts_amd/shard.py, no data-path collective)" % world,
         },
         "audio_samples_per_s": samples * K * world / elapsed,
@@ -338,6 +355,22 @@ def main():
     }
 
     log("headline done: %.0f frames/s" % value)
+    # What the parity leg checks (after everything timed): the FIRST TIMED utterance's mel as it came back from the timed call, the
+    # GPU's mel -> linear of it and the un-normalised 30- / 60-iteration audio from that S and the seeded phase (the audio of the
+    # timed call itself is the 60-iteration one behind the output normalisation; asserted equal to it up to that scaling below)
+    parity_dir = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and np.array_equal(seq[0], _ids0):
+        import tempfile
+
+        parity_dir = tempfile.mkdtemp(prefix="xdtts_parity_")
+        np.save(os.path.join(parity_dir, "mel_gpu.npy"), mels[0])
+        S_gpu = vocoder.mel_to_linear(mels[0])
+        np.save(os.path.join(parity_dir, "S_gpu.npy"), S_gpu)
+        np.save(os.path.join(parity_dir, "a30_gpu.npy"), vocoder.infer_linear(S_gpu, iters=30))
+        a60 = vocoder.infer_linear(S_gpu, iters=60)
+        np.save(os.path.join(parity_dir, "a60_gpu.npy"), a60)
+        scale = float(np.dot(audios[0].astype(np.float64), a60.astype(np.float64)) / max(np.dot(a60.astype(np.float64), a60.astype(np.float64)), 1e-30))
+        timed_audio_is_that_audio = float(np.sqrt(np.mean((audios[0].astype(np.float64) - scale * a60.astype(np.float64)) ** 2)))
     extra = {}
     if args.check_shared_utterance:
         import hashlib
@@ -383,6 +416,8 @@ def main():
                 m1, a1 = pkg.synthesize(model, vocoder, utterances[g], splits=sp, opts=opts)
             barrier()
             es = max_over_ranks(time.perf_counter() - ts0)
+            out["ms_per_step_one_call"] = es / K * 1e3
+            out["value_one_call"] = frames * K * world / es
             extra["headline_one_call_per_utterance"] = {
                 "workload": "configs[1]'s K utterances through K xdtts_synthesize_ids calls (strictly sequential, the reference's loop)",
                 "mel_frames_per_s": frames * K * world / es, "ms_per_utterance": es / K * 1e3, "x_realtime": (samples / SAMPLE_RATE) / (es / K),
@@ -565,9 +600,18 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline()
+                out["cpu_baseline"] = cpu_baseline(parity_dir)
             except Exception as e:  # noqa: BLE001
                 out["cpu_baseline"] = {"error": repr(e)}
+            if parity_dir:
+                out["parity"] = parity_check(parity_dir)
+                out["parity"]["timed_audio_vs_scaled_60it_audio_rms"] = timed_audio_is_that_audio   # (the timed call's audio = that audio x the G6 level)
+                log("parity leg done")
+                import shutil
+
+                shutil.rmtree(parity_dir, ignore_errors=True)
+            else:
+                out["parity"] = None
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

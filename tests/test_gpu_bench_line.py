@@ -38,3 +38,14 @@ def test_bench_prints_one_contract_line():
     cb = out["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["unit"] == "mel-frames/s" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
     assert out["value"] > 20 * cb["value"]   # (north_star: >= 20x real time is a far lower bar; the CPU port runs ~1.5x real time per core)
+    # the line certifies itself: the first TIMED utterance's mel and its 30- / 60-iteration audio against the
+    # oracle on the same inputs, computed after the timed region by the cpu_baseline machinery
+    par = out["parity"]
+    assert par["mel_shape_equal"] and par["frames"] == 800
+    assert par["mel_rms"] <= 1e-4 and par["audio_rms_30it"] <= 1e-4 and par["mel_to_linear_rel_rms"] <= 1e-5   # the north star's tolerance, literally
+    assert par["audio_rms_60it"] > 0 and par["audio_f32_vs_f64_60it"] > 0
+    assert par["audio_gpu_vs_f64_60it"] <= 2 * par["audio_f32_vs_f64_60it"] + 1e-6                           # 60 iterations: bounded by fp32's own drift
+    assert par["timed_audio_vs_scaled_60it_audio_rms"] <= 1e-6                                                # the timed call's audio IS that audio (x the output level)
+    assert par["north_star_1e-4"]["mel"] and par["north_star_1e-4"]["audio_30it"]
+    # both headline forms are first-class keys (filled when the extras run)
+    assert "ms_per_step_one_call" in out and "one-call-per-utterance" in out["config"]["submission"]
