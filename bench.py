@@ -356,8 +356,8 @@ def main():
 
     log("headline done: %.0f frames/s" % value)
     # What the parity leg checks (after everything timed): the FIRST TIMED utterance's mel as it came back from the timed call, the
-    # GPU's mel -> linear of it and the un-normalised 30- / 60-iteration audio from that S and the seeded phase (the audio of the
-    # timed call itself is the 60-iteration one behind the output normalisation; asserted equal to it up to that scaling below)
+    # GPU's mel -> linear of it and the un-normalised 30- / 60-iteration audio from that S and the oracle's seeded phase table (the audio
+    # of the timed call itself is the 60-iteration one from the in-kernel stream behind the output normalisation: compared with that below)
     parity_dir = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and np.array_equal(seq[0], _ids0):
         import tempfile
@@ -366,9 +366,13 @@ def main():
         np.save(os.path.join(parity_dir, "mel_gpu.npy"), mels[0])
         S_gpu = vocoder.mel_to_linear(mels[0])
         np.save(os.path.join(parity_dir, "S_gpu.npy"), S_gpu)
-        np.save(os.path.join(parity_dir, "a30_gpu.npy"), vocoder.infer_linear(S_gpu, iters=30))
-        a60 = vocoder.infer_linear(S_gpu, iters=60)
-        np.save(os.path.join(parity_dir, "a60_gpu.npy"), a60)
+        import subprocess
+
+        subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "phase", parity_dir, str(frames)], capture_output=True, timeout=120)
+        p0 = np.load(os.path.join(parity_dir, "p0.npy"))   # the oracle's seeded phase table (seed 0): GPU and oracle start from the same bits
+        np.save(os.path.join(parity_dir, "a30_gpu.npy"), vocoder.infer_linear(S_gpu, phase0=p0, iters=30))
+        np.save(os.path.join(parity_dir, "a60_gpu.npy"), vocoder.infer_linear(S_gpu, phase0=p0, iters=60))
+        a60 = vocoder.infer_linear(S_gpu, iters=60)        # ... and from the in-kernel seeded stream, as the timed call ran it
         scale = float(np.dot(audios[0].astype(np.float64), a60.astype(np.float64)) / max(np.dot(a60.astype(np.float64), a60.astype(np.float64)), 1e-30))
         timed_audio_is_that_audio = float(np.sqrt(np.mean((audios[0].astype(np.float64) - scale * a60.astype(np.float64)) ** 2)))
     extra = {}

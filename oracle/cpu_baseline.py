@@ -9,7 +9,7 @@ vocoder (src/lib.rs:141).  TEST/BASELINE INFRASTRUCTURE ONLY.
          leaves its mel there (mel_oracle.npy) for the parity leg
   parity <dir>: the CHECKER beside the timed number -- <dir> holds what the GPU produced for the first timed utterance (mel_gpu.npy:
          its mel; S_gpu.npy: the GPU's mel -> linear of it; a30_gpu.npy / a60_gpu.npy: the GPU's un-normalised 30- / 60-iteration
-         Griffin-Lim audio from that S and the seeded phase); prints their RMS distances from the oracle's outputs on the same
+         Griffin-Lim audio from that S and the phase of p0.npy, which the "phase" leg wrote there beforehand); prints their RMS distances from the oracle's outputs on the same
          inputs (bench.py's "parity" object)
   omp    the same source built with -fopenmp          (row C2; bit-identical results)
   torch  oracle/torch_cpu.py: MKL/oneDNN + pocketfft  (row C3)
@@ -56,7 +56,7 @@ def parity(d):
     pinv = orc.pinv(orc.mel_filter_bank())
     S32 = orc.mel_to_linear(pinv, mel_gpu, power=1.7)
     out["mel_to_linear_rel_rms"] = rms(S, S32) / float(np.sqrt(np.mean(S32.astype(np.float64) ** 2)))
-    p0 = orc.phase_init(0, 513, S.shape[-1] if S.shape[0] == 513 else S.shape[0])
+    p0 = np.load(os.path.join(d, "p0.npy"))               # (the "phase" leg's: what the GPU was handed)
     a30, a60 = np.load(os.path.join(d, "a30_gpu.npy")), np.load(os.path.join(d, "a60_gpu.npy"))
     f32_30, f32_60 = orc.griffinlim(S, phase0=p0, iters=30), orc.griffinlim(S, phase0=p0, iters=60)
     f64_60 = orc64.griffinlim(S, phase0=p0, iters=60)
@@ -74,6 +74,13 @@ def parity(d):
 
 def main():
     leg = sys.argv[1]
+    if leg == "phase":  # the seeded initial phase (seed 0) of an F-frame utterance as the oracle draws it -> <dir>/p0.npy, so that GPU and oracle start from the same bits
+        import numpy as np
+        import oracle
+
+        np.save(os.path.join(sys.argv[2], "p0.npy"), oracle.Oracle("f32").phase_init(0, 513, int(sys.argv[3])))
+        print(json.dumps({"ok": True}))
+        return None
     if leg == "parity":
         return parity(sys.argv[2])
     threads = int(sys.argv[2]) if len(sys.argv) > 2 else 1

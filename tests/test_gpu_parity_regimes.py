@@ -187,14 +187,14 @@ def test_200_free_running_steps_stay_as_close_to_f64_as_the_f32_oracle(pkg, orc,
         assert np.abs(gst[k] - after[k]).max() <= 1e-5 * scale, (regime, engine, k, float(np.abs(gst[k] - after[k]).max()), scale)
 
 
-GATE_LENS = [37, 91, 12, 58, 23, 100, 64, 5]
+GATE_LENS = [37, 91, 12, 58, 23, 100, 64, 5, 77, 19, 46, 83, 30]
 
 
 @pytest.mark.parametrize("regime", ["trained-20240327", "trained-7"])
-@pytest.mark.parametrize("B", [1, 2, 5, 8])
+@pytest.mark.parametrize("B", [1, 2, 5, 8, 13])
 def test_natural_gate_stops_at_the_oracles_frame(pkg, orc, regime, B):
     """No rigged gate row: the logit wanders across logit(0.6) by itself.  B = 1: persistent engine; 2: the pair (the survivor
-    continues alone); 5, 8: the small-batch engine; each chunk stops on its own and the frames up to there are the oracle's."""
+    continues alone); 5, 8, 13: the small-batch engines (8 / 16 chunk slots); each chunk stops on its own and the frames up to there are the oracle's."""
     blob, model = handle(pkg, orc, regime, natural_gate=True)
     ids = [synth_ids(n, seed=40 + i) for i, n in enumerate(GATE_LENS[:B])]
     mels = model.infer_batch(ids, opts=pkg.default_opts(dropout_seed=3, max_steps=300))
@@ -248,7 +248,7 @@ def test_infer_end_to_end_on_the_config3_batch(pkg, orc, regime):
         worst = max(worst, rms(mels[b], ref) / max(1.0, float(np.abs(ref).max())))
     assert worst <= 1e-5, (regime, worst)
     _report("config3_mel_rel_rms/%s" % regime, worst)
-    for n in (5, 8):   # the small-batch engine on the same weights
+    for n in (5, 8, 13):   # the small-batch engines (8 and 16 chunk slots) on the same weights
         sub = model.infer_batch(chunks[:n], opts=pkg.default_opts(dropout_seed=1), fixed_steps=steps[:n])
         for b in range(n):
             ref = orc.infer_chunk(blob, chunks[b], orc.default_opts(fixed_steps=steps[b], dropout_seed=1, item=b))

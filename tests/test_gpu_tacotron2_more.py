@@ -256,7 +256,7 @@ def test_large_batch_runs_lstms_on_mfma(pkg, model, orc, blob):
 
 
 def test_large_batch_with_gate(pkg, orc, blob):
-    ids_list = [synth_ids(20 + 3 * i, seed=70 + i) for i in range(9)]
+    ids_list = [synth_ids(20 + 3 * i, seed=70 + i) for i in range(17)]
     padded = np.zeros(100, dtype=np.int64)
     padded[: len(ids_list[0])] = ids_list[0]
     mem, pm = orc.encoder(blob, padded)
@@ -296,10 +296,10 @@ def _handle(pkg, blob, p8):
         del os.environ["XDTTS_P8"]
 
 
-@pytest.mark.parametrize("n", [5, 9, 64])
+@pytest.mark.parametrize("n", [5, 17, 64])
 def test_one_launch_attention_at_the_batch_size_limits(pkg, orc, blob, n):
     """5 chunks is the smallest lock-step batch of the MFMA path (20 of the 256 blocks of k_att_lstm_attention turn
-    into attention blocks; with the 3..8-chunk engine off -- by default 9 is the smallest), 64 the largest that keeps the
+    into attention blocks; with the 3..16-chunk engines off -- by default 17 is the smallest), 64 the largest that keeps the
     attention LSTM and the attention in one launch (all 256 do)."""
     rng = np.random.Generator(np.random.PCG64(40 + n))
     ids_list = [synth_ids(int(x), seed=700 + i) for i, x in enumerate(rng.integers(4, 90, size=n))]
@@ -373,7 +373,7 @@ def test_batched_path_with_a_larger_window(pkg, model, orc, blob):
         assert mels[b].shape == (80, st) and rms(mels[b], ref) <= 1e-5, b
 
 
-def _batch_case(n=12):
+def _batch_case(n=17):  # (from 17 chunks on a lock-step batch runs on the two-launch batched engine)
     ids_list = [synth_ids(18 + 5 * i, seed=500 + i) for i in range(n)]
     steps = [5 + (3 * i) % 7 for i in range(n)]
     return ids_list, steps
@@ -460,7 +460,7 @@ def test_two_launch_form_agrees_with_the_prenet_launch(pkg, orc, blob):
                 assert out[tail][b].shape == (80, steps[b]) and rms(out[tail][b], ref) <= 1e-5, (n, tail, b)
         assert all(rms(a, c) <= 1e-5 for a, c in zip(out[True], out[False]))
         assert any(not np.array_equal(a, c) for a, c in zip(out[True], out[False]))  # (the two forms really are different code)
-    ids_list = [synth_ids(20 + 3 * i, seed=70 + i) for i in range(9)]
+    ids_list = [synth_ids(20 + 3 * i, seed=70 + i) for i in range(17)]
     padded = np.zeros(100, dtype=np.int64)
     padded[: len(ids_list[0])] = ids_list[0]
     mem, pm = orc.encoder(blob, padded)
@@ -480,7 +480,7 @@ def test_lost_attention_block_falls_back(pkg, orc, blob, capfd, form):
     """The blocks of a chunk wait for each other's partial energies inside one launch.  With one block never
     publishing (test hook) the bounded spins run out, the error word is set, and the handle decodes the request
     again with separate kernels: correct frames, a message on stderr, no hang; engine_reset restores the fast form."""
-    ids_list, steps = _batch_case(9)  # (3..8 chunks have an engine of their own: decoder_persistent8.hip)
+    ids_list, steps = _batch_case(17)  # (3..16 chunks have engines of their own: decoder_persistent8.hip / decoder_persistent16.hip)
     os.environ["XDTTS_ATT_FUSED"] = form
     os.environ["XDTTS_ATT_FAULT"] = "3"     # block 2 = chunk 0's third attention block in either form
     os.environ["XDTTS_ATT_SPINS"] = "20000"
@@ -508,7 +508,7 @@ def test_lost_h_dec_in_the_two_launch_form_falls_back(pkg, orc, blob, capfd):
     """In the two-launch form the four tail blocks of a chunk wait, inside the decoder-LSTM launch, for the h_dec granules of all
     256 LSTM blocks.  With one block never publishing (test hook) the bounded spins run out, the error word is set and the
     handle decodes the request again with separate kernels: correct frames, a message on stderr, no hang."""
-    ids_list, steps = _batch_case(9)
+    ids_list, steps = _batch_case(17)
     os.environ["XDTTS_TAIL_FAULT"] = "7"
     os.environ["XDTTS_ATT_SPINS"] = "20000"
     try:
@@ -530,7 +530,8 @@ def test_lost_h_dec_in_the_two_launch_form_falls_back(pkg, orc, blob, capfd):
 def test_gemm_tile_shapes_give_identical_results(tmp_path):
     """k_gemm_nt picks 32x32 tiles for the single-utterance shapes and 64x64 once a grid fills the chip twice;
     both accumulate every output element's K products in ascending order, so a batch decoded with either
-    shape forced (XDTTS_GEMM_TILE is read once per process: two child processes) is bit-identical."""
+    shape forced (XDTTS_GEMM_TILE is read once per process: two child processes) is bit-identical.  (Split-K -- the single-utterance
+    shapes -- groups a tile's K products by slice: off here, XDTTS_GEMM_SPLITK=1; its own parity is every single-utterance test.)"""
     import subprocess
     import sys
 
@@ -549,7 +550,7 @@ def test_gemm_tile_shapes_give_identical_results(tmp_path):
     out = {}
     for tile in ("32", "64"):
         path = str(tmp_path / ("mels_%s.npz" % tile))
-        env = dict(os.environ, XDTTS_GEMM_TILE=tile)
+        env = dict(os.environ, XDTTS_GEMM_TILE=tile, XDTTS_GEMM_SPLITK="1")
         r = subprocess.run([sys.executable, "-c", script, path], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         with np.load(path) as z:

@@ -62,7 +62,7 @@ def test_two_handles_and_one_vocoder_interleaved(pkg, blob):
         for j, (mel, audio) in res.items():
             assert np.array_equal(mel, serial[j][0]) and np.array_equal(audio, serial[j][1]), j
     # a batched decode (cooperative attention launch) on one handle beside persistent decodes on the other
-    ids6 = [synth_ids(20 + 9 * i, seed=70 + i) for i in range(9)]
+    ids6 = [synth_ids(20 + 4 * i, seed=70 + i) for i in range(17)]  # (17 chunks: the two-launch batched engine; up to 16 run on the persistent MFMA engines)
     ob = pkg.default_opts(fixed_steps=18, dropout_seed=4)
     want_b = [x.copy() for x in m1.infer_batch(ids6, opts=ob)]
     got_b, got_s = run_threads([lambda: [x.copy() for x in m1.infer_batch(ids6, opts=ob)],

@@ -401,6 +401,28 @@ struct xdtts_tacotron2 {
   }
 
   // ---- encoder.onnx (mod.rs:379): ids [B][T] on device -> memory, pmem -------------------------
+  // every dense contraction of the handle goes through here: split-K where it pays (gemm.hip: gemm_splitk_plan), the slices'
+  // meeting place and the tiles' arrival counters owned by the handle (one stream: launches never overlap)
+  DevBuf<float> gemm_ws;
+  DevBuf<unsigned> gemm_cnt;
+  void run_gemm(GemmArgs &g) {
+    size_t wsf = 0, tiles = 0;
+    int tile = 0;
+    const int sk = gemm_splitk_plan(g, &wsf, &tiles, &tile);
+    if (sk > 1) {
+      if (tiles > gemm_cnt.n) {
+        gemm_cnt.alloc(std::max<size_t>(tiles, 4096));
+        HIP_CHECK(hipMemsetAsync(gemm_cnt.p, 0, gemm_cnt.n * sizeof(unsigned), stream));
+      }
+      gemm_ws.alloc(wsf);
+      g.splitk = sk;
+      g.tile = tile;
+      g.ws = gemm_ws.p;
+      g.cnt = gemm_cnt.p;
+    }
+    launch_gemm_nt(g, stream);
+  }
+
   void run_encoder(int B, int T) {
     const int pad = (ENC_K - 1) / 2, TP = T + 2 * pad;
     const size_t padded = (size_t)B * TP * EMB;
@@ -436,7 +458,7 @@ struct xdtts_tacotron2 {
       g.K = ENC_K * EMB;
       g.batch = B;
       g.act = 1;
-      launch_gemm_nt(g, stream);
+      run_gemm(g);
       std::swap(src, dst);
     }
     for (int d = 0; d < 2; ++d) {  // BiLSTM input projections for all T at once
@@ -453,7 +475,7 @@ struct xdtts_tacotron2 {
       g.N = 4 * ENC_H;
       g.K = EMB;
       g.batch = B;
-      launch_gemm_nt(g, stream);
+      run_gemm(g);
     }
     // a demoted encoder probes the cooperative recurrence again by itself (its own counter: the decoder's re-probe does not
     // depend on it, and a batched decode never passes through use_persistent)
@@ -494,7 +516,7 @@ struct xdtts_tacotron2 {
     g.N = ATT_DIM;
     g.K = EMB;
     g.batch = B;
-    launch_gemm_nt(g, stream);
+    run_gemm(g);
   }
 
   // dropout_mode 2 (SURVEY 8(b) "explicit(mask ptr)"): the caller's keep bytes [B][steps][2][256] go to the device; every
@@ -1046,7 +1068,7 @@ struct xdtts_tacotron2 {
         g.ldr = N_MEL;
         g.strideR = (long)frame_stride;
       }
-      launch_gemm_nt(g, stream);
+      run_gemm(g);
       if (i == 0) src = ppB.p;  // (layers 1.. ping-pong between the two 512-channel buffers)
       std::swap(src, dst);
     }

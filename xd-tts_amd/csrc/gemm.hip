@@ -65,6 +65,11 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs g) {
   // takes another row tile and keeps it for gridDim.x consecutive visits, i.e. the column tiles of one row tile share an XCD
   // (the row tiles of all items of a batch are numbered through, so the XCDs get equal shares whatever the items' lengths).
   int bx = blockIdx.x, by = blockIdx.y, z = blockIdx.z;
+  // split-K (plain mapping only): grid z = item x K-slice.  The slices of a tile meet in a workspace; the last one to arrive sums
+  // them in slice order (the same bits whatever the arrival order) and runs the epilogue.
+  const int nks = g.splitk > 1 ? g.splitk : 1;
+  const int ks = nks > 1 ? (int)blockIdx.z % nks : 0;
+  if (nks > 1) z = (int)blockIdx.z / nks;
   if (g.xcd_rows) {  // grid (column tiles, row tiles of ALL items rounded up to 8, 1): row tile G of the batch -> XCD G % 8
     const int nx = gridDim.x, L = bx + nx * by, j = L % (8 * nx);
     int G = (L / (8 * nx)) * 8 + (j & 7);
@@ -98,7 +103,13 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs g) {
     b_ok[r] = n0 + lr + 32 * r < g.N;
     b_src[r] = g.W + (size_t)(b_ok[r] ? n0 + lr + 32 * r : g.N - 1) * g.K + lc;
   }
-  const int nslab = (g.K + BK - 1) / BK;
+  // this block's K range [kbeg, kbeg + KL): whole slabs per slice
+  const int kper = ((g.K + BK - 1) / BK + nks - 1) / nks * BK, kbeg = ks * kper, KL = min(g.K - kbeg, kper);
+#pragma unroll
+  for (int r = 0; r < MT; ++r) a_src[r] += kbeg;
+#pragma unroll
+  for (int r = 0; r < NT; ++r) b_src[r] += kbeg;
+  const int nslab = (KL + BK - 1) / BK;
   const int fi = lane & 15, fg = lane >> 4;
   f32x4 acc[MT][NT];
 #pragma unroll
@@ -122,13 +133,13 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs g) {
   // Buffer (s + 2) % 3 held slab s - 1, whose fragments every wave read before the barrier that ended step s - 2.
 #define GEMM_FETCH(SLAB, Q)                                                                 \
   do {                                                                                      \
-    const int k0_ = ((SLAB) < nslab && (SLAB) * BK + lc < g.K) ? (SLAB) * BK : 0;           \
+    const int k0_ = ((SLAB) < nslab && (SLAB) * BK + lc < KL) ? (SLAB) * BK : 0;           \
     _Pragma("unroll") for (int r_ = 0; r_ < MT; ++r_) Q.a[r_] = *reinterpret_cast<const float4 *>(a_src[r_] + k0_); \
     _Pragma("unroll") for (int r_ = 0; r_ < NT; ++r_) Q.b[r_] = *reinterpret_cast<const float4 *>(b_src[r_] + k0_); \
   } while (0)
 #define GEMM_STAGE(SLAB, BUF, Q)                                                            \
   do {                                                                                      \
-    const bool kok_ = (SLAB) * BK + lc < g.K; /* K is a multiple of 16, not always of 32 */ \
+    const bool kok_ = (SLAB) * BK + lc < KL; /* K is a multiple of 16, not always of 32 */ \
     /* no `cond ? Q : zero4` on the vector class: it selects between ADDRESSES and sends the  \
        prefetch registers to scratch */                                                      \
     _Pragma("unroll") for (int r_ = 0; r_ < MT; ++r_) {                                     \
@@ -250,6 +261,45 @@ __global__ __launch_bounds__(256) void k_gemm_nt(GemmArgs g) {
 #undef GEMM_READ
 #undef GEMM_STAGE
 #undef GEMM_FETCH
+  if (nks > 1) {
+    // the slices' partial tiles, lane-linear [tile][slice][MFMA tile (i, j)][wave][lane] float4: plain 16-byte stores, one
+    // agent-scope release per block, then the ticket
+    __shared__ int s_last;
+    const size_t tile_id = ((size_t)z * gridDim.y + by) * gridDim.x + bx;
+    // write-through (sc1) 16-byte stores, drained, then a relaxed ticket; the reducer reads with sc1 loads: no release / acquire
+    // fence (a fence per block -- buffer_wbl2 -- cost more than the split gained: post-net 0.153 -> 0.19 ms at two slices)
+    float *wsb = g.ws + tile_id * nks * (MT * NT * 1024);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)wsb, 0, 0x7fffffff, 0x00020000);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        u32x4 v;
+        v.x = __float_as_uint(acc[i][j][0]), v.y = __float_as_uint(acc[i][j][1]), v.z = __float_as_uint(acc[i][j][2]), v.w = __float_as_uint(acc[i][j][3]);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)(((ks * MT * NT + i * NT + j) * 256 + tid) * 16), 0, 16);
+      }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned t = __hip_atomic_fetch_add(g.cnt + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = t == (unsigned)(nks - 1);
+      if (s_last) __hip_atomic_store(g.cnt + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (every slice has arrived: ready for the next launch)
+    }
+    __syncthreads();
+    if (!s_last) return;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < nks; ++k) {
+          const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(((k * MT * NT + i * NT + j) * 256 + tid) * 16), 0, 16);
+          v += (f32x4){__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w)};
+        }
+        acc[i][j] = v;
+      }
+  }
   // epilogue: D register r of lane l holds row (l>>4)*4 + r, column l&15 of its 16x16 tile
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
@@ -410,6 +460,44 @@ void launch_copy_rows(const float *src, size_t src_stride, float *dst, size_t ds
   HIP_CHECK(hipGetLastError());
 }
 
+// Split-K for the single-utterance shapes: M = 100..800 rows of 32x32 tiles put 100..400 blocks of four waves on 256 CUs -- one or
+// two waves per SIMD, each a dependent MFMA chain behind a barrier per slab.  With the K range cut in 2..4 slices the same launch
+// holds 3-4 blocks per CU; the slices meet in the launch (k_gemm_nt).  Returns the slice count (1 = no split) and what the caller
+// must provide: `ws_floats` of workspace, `tiles` zero-initialised counters (the kernel leaves them zero).
+int gemm_splitk_plan(const GemmArgs &g, size_t *ws_floats, size_t *tiles, int *tile) {
+  *ws_floats = *tiles = 0;
+  *tile = 0;
+  static const int forced = getenv("XDTTS_GEMM_SPLITK") ? atoi(getenv("XDTTS_GEMM_SPLITK")) : -1;  // developer comparison aids (0 / 1: off)
+  static const int forced_t = getenv("XDTTS_GEMM_SPLIT_TILE") ? atoi(getenv("XDTTS_GEMM_SPLIT_TILE")) : 0;
+  if (forced == 0 || forced == 1) return 1;
+  long rows = 0, t32 = 0, t64 = 0;
+  for (int z = 0; z < g.batch; ++z) {
+    const int m = g.ragged ? g.Mz[z] : g.M;
+    rows += m;
+    t32 += (long)((m + 31) / 32) * ((g.N + 31) / 32);
+    t64 += (long)((m + 63) / 64) * ((g.N + 63) / 64);
+  }
+  const long tiles64 = (long)((g.N + 63) / 64) * ((g.M + 63) / 64) * g.batch;
+  const bool big = g.N >= 64 && tiles64 >= 512 && !(g.M <= 128 && g.N >= 4096);
+  if (big || rows * g.lda > (long)g.N * g.K) return 1;  // the chip is full without it / the row-tile-per-XCD mapping: batches, not split
+  const int nslab = (g.K + 31) / 32;
+  // Measured (profiles/r06_gemm_splitk.txt, configs[1]'s utterance): it pays where the tiles do not even give every CU a block -- the
+  // encoder's M = 100 rows (128 blocks: 0.305 -> 0.277 ms per utterance at four slices) -- and not where they already do: the
+  // post-net's three 512 -> 512 layers at F = 800 (416 blocks of 32x32) stay at 0.150-0.152 ms with 2 or 4 slices, and with 64x64
+  // tiles x 4 / 6 / 8 slices (XDTTS_GEMM_SPLIT_TILE=64) they take 0.199 / 0.174 / 0.188 ms: that kernel is bound by the instructions it
+  // issues per slab, not by how few waves it has.  Hence: 32x32 tiles, up to four slices, only while the grid stays within ~2 blocks per CU.
+  const int tb = forced_t ? forced_t : 32;
+  const long blocks = tb == 64 ? t64 : t32;
+  int sk = forced > 1 ? forced : (int)std::min<long>(4, 512 / std::max<long>(blocks, 1));
+  sk = std::min(sk, nslab / 8);  // at least 8 slabs per slice (the pipeline's prologue is 6 deep)
+  if (sk < 2) return 1;
+  const long grid_tiles = (long)((g.N + tb - 1) / tb) * ((g.M + tb - 1) / tb) * g.batch;
+  *tile = tb;
+  *tiles = (size_t)grid_tiles;
+  *ws_floats = (size_t)grid_tiles * sk * tb * tb;
+  return sk;
+}
+
 void launch_gemm_nt(const GemmArgs &g, hipStream_t s) {
   if (g.ragged && g.batch > GEMM_RAGGED_MAX) fail(XDTTS_ERR_BAD_ARG, "gemm: ragged batch of %d", g.batch);
   if (g.K % 16 != 0 || g.lda % 4 != 0) fail(XDTTS_ERR_BAD_ARG, "gemm: K=%d lda=%ld not supported", g.K, g.lda);
@@ -418,7 +506,7 @@ void launch_gemm_nt(const GemmArgs &g, hipStream_t s) {
   const long tiles64 = (long)((g.N + 63) / 64) * ((g.M + 63) / 64) * g.batch;
   // (short and very wide -- the context fold of the persistent decoder, M = T = 100 rows x 8273 columns x K = 512 per chunk: its second
   // 64-row tile is 36 % full; measured 33.4 us with 32x32 tiles, 39.5 with 64x64, 44.4 with 32x64)
-  const bool big = forced ? forced == 64 : (g.N >= 64 && tiles64 >= 512 && !(g.M <= 128 && g.N >= 4096));
+  const bool big = g.tile ? g.tile == 64 : (forced ? forced == 64 : (g.N >= 64 && tiles64 >= 512 && !(g.M <= 128 && g.N >= 4096)));
   // row tiles per XCD when A (unique bytes: rows x lda) outweighs W -- the batches; XDTTS_GEMM_XCD=0|1 forces it (comparison aid)
   static const int forced_x = getenv("XDTTS_GEMM_XCD") ? atoi(getenv("XDTTS_GEMM_XCD")) : -1;
   long rows = 0;
@@ -434,6 +522,8 @@ void launch_gemm_nt(const GemmArgs &g, hipStream_t s) {
     ny = (int)((tiles + 7) / 8 * 8);
     nz = 1;
   }
+  if (a.splitk > 1 && (a.xcd_rows || !a.ws || !a.cnt)) a.splitk = 1;  // (gemm_splitk_plan never asks for it there)
+  if (a.splitk > 1) nz *= a.splitk;
   if (big)
     hipLaunchKernelGGL((k_gemm_nt<64, 64>), dim3(nx, ny, nz), dim3(256), 0, s, a);
   else

@@ -194,7 +194,14 @@ struct GemmArgs {
   float alpha, beta;
   int r_before_act;
   int xcd_rows;       // set by launch_gemm_nt: block -> tile mapping that keeps a row tile's column tiles on one XCD (gemm.hip)
+  // split-K (gemm_splitk_plan): K slices per tile (0 / 1 = none), their meeting place [tiles][slices][1024 floats] and the tiles'
+  // arrival counters (zero between launches)
+  int splitk;
+  float *ws;
+  unsigned *cnt;
+  int tile;           // 0: launch_gemm_nt's own choice; 32 / 64: the plan's
 };
+int gemm_splitk_plan(const GemmArgs &g, size_t *ws_floats, size_t *tiles, int *tile);
 constexpr int GEMM_RAGGED_MAX = 64;  // (the argument block stays under 1 KB)
 void launch_gemm_nt(const GemmArgs &g, hipStream_t s);
 
