@@ -321,6 +321,7 @@ struct xdtts_tacotron2 {
   DevBuf<unsigned long long> att_exchange;
   DevBuf<float> att_part;  // early partial pre-activations of the attention LSTM (DecoderBufs::att_part)
   DevBuf<float> dec_part;  // two-launch form: early partial of the decoder LSTM's h_dec columns (DecoderBufs::dec_part)
+  DevBuf<unsigned> h_ring;  // two-launch form: h_att per step as a write-once ring (DecoderBufs::hring)
   DevBuf<unsigned long long> tail_exchange;  // two-launch form: h_dec and mel granules (DecoderBufs::hdg, melg)
   // batched mode: energies, softmax and context in one launch (XDTTS_ATT_FUSED=0: the two-kernel form; also after
   // an exchange of that launch timed out)
@@ -629,6 +630,23 @@ struct xdtts_tacotron2 {
               if (!no_dh) {
                 dec_part.alloc((size_t)(DEC_RNN / 4) * 4 * 64 * 4);
                 d.dec_part = dec_part.p;
+                // ... and h_att(s) as a write-once ring too, so that the decoder LSTM's h_att columns are multiplied inside the attention
+                // launch (kernels.h: DecoderBufs::hring): one slab of 4 kB per chunk slot and step -- 262 MB at 64 slots x 1000 steps;
+                // a request capped beyond 1 GiB of ring (or with no room for it) keeps the 1536-column pass
+                // Built, parity-green, measured and NOT the default (profiles/r06_config3_hring_rejected.txt): the decoder-LSTM launch shrinks by
+                // 3.3 us per iteration at configs[2] and the attention launch grows by 3.6-4.4 -- its extra blocks read 48-64 MB of fresh
+                // cross-XCD data per step inside the launch at the ~6.5 TB/s every in-launch bulk edge on this chip has shown (round 3),
+                // 8-10 us for what a grid boundary delivers in 2.  XDTTS_HRING=1 enables it.
+                static const bool want_hr = getenv("XDTTS_HRING") != nullptr && getenv("XDTTS_HRING")[0] == '1';
+                const size_t ring_words = (size_t)ms * ATT_RNN * Bpad;
+                if (want_hr && ring_words * sizeof(unsigned) <= ((size_t)1 << 30)) try {
+                  h_ring.alloc(ring_words);
+                  d.hring = h_ring.p;
+                  d.hring_steps = ms;
+                } catch (const Error &e) {
+                  if (e.code != XDTTS_ERR_OOM) throw;
+                  (void)hipGetLastError();
+                }
               }
             }
           }
@@ -953,6 +971,8 @@ struct xdtts_tacotron2 {
     // persistent engine's, such launches of different handles never overlap
     std::unique_lock<ChipLock> chip;
     if (d.hg) chip = std::unique_lock<ChipLock>(chip_mutex(device));
+    if (d.hring)  // the slabs of the steps this request can reach: "not yet written"
+      HIP_CHECK(hipMemsetAsync(d.hring, 0xff, (size_t)std::min(max_lim, d.hring_steps) * ATT_RNN * d.Bpad * sizeof(unsigned), stream));
     if (!d.use_gate) {  // deterministic work: every chunk runs to its cap
       while (launched + GRAPH_STEPS <= max_lim) {
         replay_steps(d);
@@ -998,6 +1018,7 @@ struct xdtts_tacotron2 {
         d2.att_part = nullptr;
         d2.hdg = d2.melg = nullptr;
         d2.dec_part = nullptr;
+        d2.hring = nullptr;
         return run_decoder(d2, lim);  // (no `after`: the caller enqueues its work behind this decode)
       }
     }
@@ -2026,6 +2047,7 @@ xdtts_status xdtts_tacotron2_decoder_steps(xdtts_tacotron2 *h, int32_t engine, i
       std::unique_lock<ChipLock> chip;
       if (d.hg) chip = std::unique_lock<ChipLock>(chip_mutex(h->device));
       if (engine == 0) launch_decoder_location(d, h->w, st);  // (the batched prenet launch computes them itself)
+      if (d.hring) HIP_CHECK(hipMemsetAsync(d.hring, 0xff, (size_t)d.hring_steps * ATT_RNN * d.Bpad * sizeof(unsigned), st));
       launch_decoder_early(d, h->w, 0, st);  // (batched engine: the first attention-LSTM pass's early partial, from the imported state)
       launch_decoder_prologue(d, h->w, st);  // (two-launch form: x and location features of the first step; d.dec_in = decoder_input)
       for (int i = 0; i < n_steps; ++i) {

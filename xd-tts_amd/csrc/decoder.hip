@@ -905,6 +905,11 @@ __device__ __forceinline__ void lstm_mfma_pass(const DecoderBufs &d, int n0, int
             h_out[(size_t)n * ATT_RNN + unit] = hn;
         }
         hf_out[((size_t)blk * d.Bpad + n) * 4 + fg] = hn;
+        if (KIND == 0 && d.hring) {  // ... and into this step's slab of the write-once ring (the same launch's extra blocks poll it)
+          const unsigned hb = __float_as_uint(hn);
+          __hip_atomic_store(d.hring + ((size_t)step * (ATT_RNN / 4) + blk) * d.Bpad * 4 + (size_t)n * 4 + fg, hb == 0xffffffffu ? 0x7fc00000u : hb, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (TAIL && !(d.tail_fault && blk == d.tail_fault - 1)) granule_store(d.hdg + (size_t)n * DEC_RNN + unit, (unsigned)step + 1u, hn);
       }
     }
@@ -961,9 +966,12 @@ __device__ __forceinline__ unsigned hw_place() {  // (xcc << 16) | HW_ID: which 
 // blocks are a latency chain; the decoder-LSTM launch of step s then multiplies [h_att(s) ; ctx(s)] only.  hcur: half of dec_hf.
 constexpr int EARLY_K0 = PRENET / 16, EARLY_KS = (ATT_COLS - PRENET) / 16;  // k-steps 16 .. 111 of the 112
 constexpr int EARLY_K0_D = (ATT_RNN + EMB) / 16, EARLY_KS_D = DEC_RNN / 16;  // decoder LSTM: k-steps 96 .. 159 of the 160
-template <int NTA, int KIND = 0>
+#ifndef XDTTS_HRING_AUX
+#define XDTTS_HRING_AUX 16  // cache policy of the first poll of a ring quad (16 = sc1; retries: sc0 sc1)
+#endif
+template <int NTA, int KIND = 0, bool HIN = false>
 __device__ __forceinline__ void att_early_partial(const DecoderBufs &d, int hcur, int blk, const float4 *__restrict__ Wm, float *lds,
-                                                  unsigned long long t_entry = 0, int step = 0) {
+                                                  unsigned long long t_entry = 0, int step = 0, unsigned long long active = ~0ull) {
   constexpr int NWV = MFMA_WAVES, K0 = KIND ? EARLY_K0_D : EARLY_K0, KS = KIND ? EARLY_KS_D : EARLY_KS, JJ = KS / NWV;
   constexpr int KSTEPS = (KIND ? DEC_COLS : ATT_COLS) / 16;
   static_assert(KS % NWV == 0, "whole k-steps per wave");
@@ -1019,6 +1027,69 @@ __device__ __forceinline__ void att_early_partial(const DecoderBufs &d, int hcur
 #pragma unroll
     for (int t = 0; t < NTA; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, xv[t].w, acc[t], 0, 0, 0);
   }
+  if constexpr (HIN) {
+    // KIND 1, two-launch form with d.hring: the decoder LSTM's h_att(s) columns too -- k-steps 0 .. 63 of its weights against the vector
+    // the attention-LSTM blocks of THIS launch are publishing into the step's ring slab.  Every 16-byte operand quad (k-quad 4 j + fg,
+    // chunk) has one producer block; it is polled (sc1, retries sc0 sc1) until none of its words is the fill pattern, one k-step
+    // ahead of the MFMAs.  Lanes of chunks that do not run this step take zeros and wait for nobody.
+    constexpr int JH = (ATT_RNN / 16) / NWV;  // 8 k-steps per wave
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(d.hring + (size_t)step * ATT_RNN * d.Bpad), 0, 0x7fffffff, 0x00020000);
+    const float4 *wh = Wm + ((size_t)blk * KSTEPS + wave * JH) * 64 + lane;
+    const unsigned spin_limit = d.att_spins > 0 ? (unsigned)d.att_spins : AB_SPIN_LIMIT;
+    bool on[NTA];
+#pragma unroll
+    for (int t = 0; t < NTA; ++t) on[t] = (active >> (16 * t + fi)) & 1ull;
+    auto voff = [&](int jj, int t) { return (int)((((unsigned)(4 * (wave * JH + jj) + fg) * (unsigned)d.Bpad) + 16u * t + fi) * 16u); };
+    // (operand quads DH k-steps ahead: a poll of another XCD's fresh data takes ~1.3 us whatever it finds, a k-step's MFMAs 0.2 us)
+    constexpr int DH = NTA <= 2 ? 6 : (NTA == 3 ? 4 : 3);
+    u32x4 hb[DH][NTA];
+    float4 wv2[DH];
+#pragma unroll
+    for (int p = 0; p < DH; ++p) {
+#pragma unroll
+      for (int t = 0; t < NTA; ++t) hb[p][t] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff(p, t), 0, XDTTS_HRING_AUX);
+      wv2[p] = wh[(size_t)p * 64];
+    }
+#pragma unroll
+    for (int jj = 0; jj < JH; ++jj) {
+      u32x4(&v)[NTA] = hb[jj % DH];
+      unsigned pending = 0u, spins = 0;
+#pragma unroll
+      for (int t = 0; t < NTA; ++t) {
+        pending |= (on[t] && (v[t].x == 0xffffffffu || v[t].y == 0xffffffffu || v[t].z == 0xffffffffu || v[t].w == 0xffffffffu)) ? 1u << t : 0u;
+        if (!on[t]) v[t] = (u32x4){0u, 0u, 0u, 0u};
+      }
+      while (pending) {
+        if (++spins > spin_limit || ((spins & 127u) == 0 && __hip_atomic_load(d.att_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+          atomicExch(d.att_err, 1);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for (int t = 0; t < NTA; ++t)
+          if ((pending >> t) & 1u) v[t] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff(jj, t), 0, 17);
+#pragma unroll
+        for (int t = 0; t < NTA; ++t)
+          if (((pending >> t) & 1u) && v[t].x != 0xffffffffu && v[t].y != 0xffffffffu && v[t].z != 0xffffffffu && v[t].w != 0xffffffffu) pending &= ~(1u << t);
+        asm volatile("" ::: "memory");
+      }
+      const float4 wv = wv2[jj % DH];
+#pragma unroll
+      for (int t = 0; t < NTA; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, __uint_as_float(v[t].x), acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NTA; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, __uint_as_float(v[t].y), acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NTA; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.z, __uint_as_float(v[t].z), acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < NTA; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, __uint_as_float(v[t].w), acc[t], 0, 0, 0);
+      if (jj + DH < JH) {  // the slot just consumed: the operands DH k-steps on
+#pragma unroll
+        for (int t = 0; t < NTA; ++t) v[t] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff(jj + DH, t), 0, XDTTS_HRING_AUX);
+        wv2[jj % DH] = wh[(size_t)(jj + DH) * 64];
+      }
+    }
+  }
 #ifdef XDTTS_LSTM_PROBE
   ep[1] = wall_clock64();
 #endif
@@ -1041,11 +1112,22 @@ __device__ __forceinline__ void att_early_partial(const DecoderBufs &d, int hcur
 }
 // the role as a whole: tiles by the chunks still active at step `next`
 template <int KIND = 0>
-__device__ __forceinline__ void att_early_role(const DecoderBufs &d, int next, int hcur, int blk, const float4 *__restrict__ Wm, float *lds, unsigned long long t_entry) {
+__device__ __forceinline__ void att_early_role(const DecoderBufs &d, int next, int hcur, int blk, const float4 *__restrict__ Wm, float *lds, unsigned long long t_entry,
+                                               bool hin = false) {
   const int lane = threadIdx.x & 63;
   const bool a = lane < d.B && next < d.nframes[min(lane, d.B - 1)];  // (a chunk the next prenet launch stops still counts: its tile's partial is not read then)
   const unsigned long long m = __ballot(a);
   const int nta = m ? (63 - __clzll((long long)m)) / 16 + 1 : 0;
+  if (KIND == 1 && hin) {  // (the attention launch's extra blocks, with the ring: + the h_att(s) columns, polled inside the launch)
+    switch (nta) {
+      case 1: att_early_partial<1, KIND, KIND == 1>(d, hcur, blk, Wm, lds, t_entry, next, m); break;
+      case 2: att_early_partial<2, KIND, KIND == 1>(d, hcur, blk, Wm, lds, t_entry, next, m); break;
+      case 3: att_early_partial<3, KIND, KIND == 1>(d, hcur, blk, Wm, lds, t_entry, next, m); break;
+      case 4: att_early_partial<4, KIND, KIND == 1>(d, hcur, blk, Wm, lds, t_entry, next, m); break;
+      default: break;
+    }
+    return;
+  }
   switch (nta) {
     case 1: att_early_partial<1, KIND>(d, hcur, blk, Wm, lds, t_entry, next); break;
     case 2: att_early_partial<2, KIND>(d, hcur, blk, Wm, lds, t_entry, next); break;
@@ -1268,7 +1350,17 @@ __global__ __launch_bounds__(64 * MFMA_WAVES) void k_lstm_mfma(DecoderBufs d, in
     wa[rt] = (KIND == 1 && wave < 4 && mrow < MEL_LD) ? reinterpret_cast<const float *>(Wepi)[((size_t)blk * MEL_LD + mrow) * 4 + fg] : 0.f;
   }
   if (KIND == 1 && d.hdg) {  // two-launch form: h_dec as granules, then the chunk's projection / prenet tail
-    if (d.dec_part) {  // ... and the h_dec(s-1) columns were multiplied by the attention launch's extra blocks: [h_att ; ctx] only
+    if (d.dec_part && d.hring) {  // ... and so were the h_att(s) columns (polled from the ring inside that launch): the 512 context columns only
+      constexpr int C0S = KIND == 1 ? ATT_RNN : 0, CNS = KIND == 1 ? EMB : NCOLS;
+      const float4 *ws = Wm + ((size_t)blk * (NCOLS / 16) + C0S / 16 + wave * (CNS / NW / 16)) * 64 + lane;
+      switch (nta) {
+        case 1: lstm_mfma_pass<NCOLS, KIND, 1, NoHook, C0S, CNS, KIND == 1, KIND == 1>(d, n0, cur, step, blk, ws, bz, wa, s_acc, m, t_entry); break;
+        case 2: lstm_mfma_pass<NCOLS, KIND, 2, NoHook, C0S, CNS, KIND == 1, KIND == 1>(d, n0, cur, step, blk, ws, bz, wa, s_acc, m, t_entry); break;
+        case 3: lstm_mfma_pass<NCOLS, KIND, 3, NoHook, C0S, CNS, KIND == 1, KIND == 1>(d, n0, cur, step, blk, ws, bz, wa, s_acc, m, t_entry); break;
+        case 4: lstm_mfma_pass<NCOLS, KIND, 4, NoHook, C0S, CNS, KIND == 1, KIND == 1>(d, n0, cur, step, blk, ws, bz, wa, s_acc, m, t_entry); break;
+        default: return;
+      }
+    } else if (d.dec_part) {  // ... and the h_dec(s-1) columns were multiplied by the attention launch's extra blocks: [h_att ; ctx] only
       constexpr int CNS = KIND == 1 ? ATT_RNN + EMB : NCOLS;
       const float4 *ws = Wm + ((size_t)blk * (NCOLS / 16) + wave * (CNS / NW / 16)) * 64 + lane;
       switch (nta) {
@@ -1788,7 +1880,7 @@ __global__ __launch_bounds__(64 * MFMA_WAVES, TWO ? 4 : 2) void k_att_lstm_atten
   const float wa[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   __shared__ __attribute__((aligned(16))) float s_acc[NW * 4 * 64 * 4];
   if (TWO && (int)blockIdx.x >= NBLK) {  // blocks 256..511 (with d.dec_part): the early partial of THIS step's decoder-LSTM pass over h_dec(s-1)
-    att_early_role<1>(d, d.ctl[0] + i, cur, (int)blockIdx.x - NBLK, dec_wm, s_acc, 0);
+    att_early_role<1>(d, d.ctl[0] + i, cur, (int)blockIdx.x - NBLK, dec_wm, s_acc, 0, d.hring != nullptr);
     return;
   }
   // blocks 4 b .. 4 b + 3 are the attention blocks of chunk b; their loads for that phase go out as soon as the wave has
@@ -1899,6 +1991,7 @@ static void enqueue_steps(const DecoderBufs &d, const DeviceWeights &w, int i0, 
   DecoderBufs dd = d;                                    // what the decoder-LSTM launch sees
   if (!two) dd.hdg = dd.melg = nullptr;
   if (!two) dd.dec_part = nullptr;
+  if (!two) dd.hring = nullptr;
   const TailWeights tw{reinterpret_cast<const float4 *>(w.proj_w.p), w.proj_b.p, w.pre0T.p, w.pre1T.p, w.loc_conv.p, w.loc_denseT.p};
   for (int i = i0; i < i0 + nsteps; ++i) {
     const int cur = i & 1;

@@ -78,6 +78,13 @@ struct DecoderBufs {
   int att_spins, att_fault;  // test hooks: poll limit (0 = default) and a block (index + 1) that never publishes its energies
   int tail_fault;            // test hook, two-launch form: a decoder-LSTM block (index + 1) that never publishes its h_dec granules
   int att_slow;              // test hook: a block (index + 1) of both batched launches that stalls ~7 us at a different point of every step
+  // Two-launch form, round 6: h_att(s) ALSO as a write-once ring of plain values in B-operand order [step][1024 / 4][Bpad][4]
+  // (0xFFFFFFFF = not yet written; a value is its own arrival flag, decoder_persistent16.hip), so that the extra blocks of the
+  // attention launch multiply the decoder LSTM's h_att columns INSIDE that launch, behind its h_dec columns, while the attention
+  // chain runs -- the decoder-LSTM launch's critical pass then covers the 512 context columns only.  null = that pass covers
+  // [h_att ; ctx] (1536 columns) as before.  hring_steps: steps the ring is laid out for.
+  unsigned *hring;
+  int hring_steps;
 };
 constexpr int ATT_EXCHANGE_BLOCKS = 8;  // granule rows per chunk (CTX_BLOCKS in decoder.hip)
 // [B][T][128] -> [B][32][T][4]
