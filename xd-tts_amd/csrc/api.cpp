@@ -627,6 +627,11 @@ struct xdtts_tacotron2 {
               d.hdg = tail_exchange.p;
               d.melg = d.hdg + (size_t)B * DEC_RNN;
               static const bool no_dh = getenv("XDTTS_NO_DHEARLY") != nullptr;  // developer comparison aid
+              // (built, parity-green, measured, NOT the default -- profiles/r06_config3_hfirst_rejected.txt: the decoder-LSTM launch loses 1.5 us
+              // per configs[2] iteration, the attention launch gains 4.5: eight more k-steps per wave ahead of the attention cell are eight more
+              // operand round trips at the one or two k-steps of look-ahead a 128-register wave has, not work hidden in the wait for x)
+              static const bool want_hf = getenv("XDTTS_HFIRST") != nullptr && getenv("XDTTS_HFIRST")[0] == '1';
+              d.att_hfirst = want_hf ? 1 : 0;
               if (!no_dh) {
                 dec_part.alloc((size_t)(DEC_RNN / 4) * 4 * 64 * 4);
                 d.dec_part = dec_part.p;
@@ -1019,6 +1024,7 @@ struct xdtts_tacotron2 {
         d2.hdg = d2.melg = nullptr;
         d2.dec_part = nullptr;
         d2.hring = nullptr;
+        d2.att_hfirst = 0;
         return run_decoder(d2, lim);  // (no `after`: the caller enqueues its work behind this decode)
       }
     }

@@ -762,19 +762,25 @@ struct NoHook {
 // PART, adds the early partial of the remaining columns (DecoderBufs::att_part) in the cell-update waves.
 // TAIL (decoder LSTM, two-launch form): h_dec leaves as granules d.hdg for the chunk's projection / prenet blocks of the same
 // launch (dec_tail_chunk) instead of the partial-mel rows the prenet launch would sum.
-template <int NCOLS, int KIND, int NTA, class Hook = NoHook, int C0 = 0, int CN = NCOLS, bool PART = false, bool TAIL = false>
+// C1 / CN1 (round 6): a FIRST range [C1, C1 + CN1) multiplied ahead of [C0, C0 + CN) -- the attention launch runs its h_att(s-1)
+// columns (data two launches old) before the prenet columns x(s), whose first loads take ~4 us to arrive from the other XCDs' tail
+// blocks; wsrc is then the BLOCK's first k-step (k-step 0 of its rows), not the wave's.
+template <int NCOLS, int KIND, int NTA, class Hook = NoHook, int C0 = 0, int CN = NCOLS, bool PART = false, bool TAIL = false, int C1 = 0, int CN1 = 0>
 __device__ __forceinline__ void lstm_mfma_pass(const DecoderBufs &d, int n0, int cur, int step, int blk, const float4 *__restrict__ wsrc,
                                                const float4 bz, const float (&wa)[6], float *s_acc, unsigned long long active,
                                                unsigned long long d_probe_entry = 0, Hook after_loop = Hook()) {  // active: bit j = chunk n0 + j still runs at this step
-  constexpr int NW = MFMA_WAVES, KW = CN / NW, JJ = KW / 16;
-  static_assert(CN % (16 * NW) == 0 && C0 % 16 == 0, "whole k-steps per wave");
+  constexpr int NW = MFMA_WAVES, KW = CN / NW, JJ0 = KW / 16, JJ1 = CN1 / NW / 16, JJ = JJ0 + JJ1;
+  static_assert(CN % (16 * NW) == 0 && C0 % 16 == 0 && CN1 % (16 * NW) == 0 && C1 % 16 == 0, "whole k-steps per wave");
   constexpr int N0 = KIND == 0 ? PRENET : ATT_RNN, N1 = EMB;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fi = lane & 15, fg = lane >> 4;  // (wave index as a scalar: the segment choice in src() below is then scalar code, not exec-masked branches)
   const float4 *seg0 = reinterpret_cast<const float4 *>(KIND == 0 ? d.xf : d.att_hf[cur ^ 1]);
   const float4 *seg1 = reinterpret_cast<const float4 *>(d.ctxf);
   const float4 *seg2 = reinterpret_cast<const float4 *>(KIND == 0 ? d.att_hf[cur] : d.dec_hf[cur]);
+  // k-step of the weight rows / first column that loop step jj multiplies (wave-uniform)
+  auto kstep = [&](int jj) { return CN1 == 0 ? C0 / 16 + wave * JJ0 + jj : (jj < JJ1 ? C1 / 16 + wave * JJ1 + jj : C0 / 16 + wave * JJ0 + (jj - JJ1)); };
+  auto w_at = [&](int jj) { return CN1 == 0 ? wsrc + (size_t)jj * 64 : wsrc + (size_t)kstep(jj) * 64; };
   auto src = [&](int jj) {  // first 16-byte vector of this lane for k-step jj (wave-uniform segment choice)
-    const int col = C0 + wave * KW + 16 * jj;
+    const int col = 16 * kstep(jj);
     const float4 *sb = col < N0 ? seg0 + (size_t)(col >> 2) * d.Bpad
                                 : (col < N0 + N1 ? seg1 + (size_t)((col - N0) >> 2) * d.Bpad : seg2 + (size_t)((col - N0 - N1) >> 2) * d.Bpad);
     return sb + (size_t)fg * d.Bpad + n0 + fi;
@@ -822,7 +828,7 @@ __device__ __forceinline__ void lstm_mfma_pass(const DecoderBufs &d, int n0, int
   float4 ring[RX][NTA], wring[8];
 #pragma unroll
   for (int p = 0; p < (DW > DX ? DW : DX) && p < JJ; ++p) {
-    if (p < DW) wring[p] = wsrc[(size_t)p * 64];  // plain loads: with the non-temporal hint of the GEMV kernels the 52-chunk iteration took 2.3 us longer
+    if (p < DW) wring[p] = *w_at(p);  // plain loads: with the non-temporal hint of the GEMV kernels the 52-chunk iteration took 2.3 us longer
                                       // (the 71 MB of weights fit the 256 MB Infinity Cache and are read again 50 us later)
     if (p < DX) {
       const float4 *sp = src(p);
@@ -849,7 +855,7 @@ __device__ __forceinline__ void lstm_mfma_pass(const DecoderBufs &d, int n0, int
       for (int t = 0; t < NTA; ++t) ring[(jj + DX) % RX][t] = sp[16 * t];  // (non-temporal: 38.5 -> 45 us per iteration, the 32 CUs of an XCD share these lines in L2)
     }
     asm volatile("" ::: "memory");
-    if (jj + DW < JJ) wring[(jj + DW) % 8] = wsrc[(size_t)(jj + DW) * 64];
+    if (jj + DW < JJ) wring[(jj + DW) % 8] = *w_at(jj + DW);
     asm volatile("" ::: "memory");
     // (the asm fences order memory operations only: the MFMAs of the NEXT k-step, whose operands are in flight already, are free
     // to be hoisted above this k-step's loads, and then every load is waited for right behind its issue -- seen in the ISA after an
@@ -969,10 +975,10 @@ constexpr int EARLY_K0_D = (ATT_RNN + EMB) / 16, EARLY_KS_D = DEC_RNN / 16;  // 
 #ifndef XDTTS_HRING_AUX
 #define XDTTS_HRING_AUX 16  // cache policy of the first poll of a ring quad (16 = sc1; retries: sc0 sc1)
 #endif
-template <int NTA, int KIND = 0, bool HIN = false>
+template <int NTA, int KIND = 0, bool HIN = false, bool SHORT = false>
 __device__ __forceinline__ void att_early_partial(const DecoderBufs &d, int hcur, int blk, const float4 *__restrict__ Wm, float *lds,
                                                   unsigned long long t_entry = 0, int step = 0, unsigned long long active = ~0ull) {
-  constexpr int NWV = MFMA_WAVES, K0 = KIND ? EARLY_K0_D : EARLY_K0, KS = KIND ? EARLY_KS_D : EARLY_KS, JJ = KS / NWV;
+  constexpr int NWV = MFMA_WAVES, K0 = KIND ? EARLY_K0_D : EARLY_K0, KS = KIND ? EARLY_KS_D : (SHORT ? EMB / 16 : EARLY_KS), JJ = KS / NWV;  // SHORT: the 512 context columns only (DecoderBufs::att_hfirst)
   constexpr int KSTEPS = (KIND ? DEC_COLS : ATT_COLS) / 16;
   static_assert(KS % NWV == 0, "whole k-steps per wave");
 #ifdef XDTTS_LSTM_PROBE
@@ -1124,6 +1130,16 @@ __device__ __forceinline__ void att_early_role(const DecoderBufs &d, int next, i
       case 2: att_early_partial<2, KIND, KIND == 1>(d, hcur, blk, Wm, lds, t_entry, next, m); break;
       case 3: att_early_partial<3, KIND, KIND == 1>(d, hcur, blk, Wm, lds, t_entry, next, m); break;
       case 4: att_early_partial<4, KIND, KIND == 1>(d, hcur, blk, Wm, lds, t_entry, next, m); break;
+      default: break;
+    }
+    return;
+  }
+  if (KIND == 0 && d.att_hfirst) {  // (the attention launch multiplies its h_att columns itself: the context columns only here)
+    switch (nta) {
+      case 1: att_early_partial<1, KIND, false, KIND == 0>(d, hcur, blk, Wm, lds, t_entry, next); break;
+      case 2: att_early_partial<2, KIND, false, KIND == 0>(d, hcur, blk, Wm, lds, t_entry, next); break;
+      case 3: att_early_partial<3, KIND, false, KIND == 0>(d, hcur, blk, Wm, lds, t_entry, next); break;
+      case 4: att_early_partial<4, KIND, false, KIND == 0>(d, hcur, blk, Wm, lds, t_entry, next); break;
       default: break;
     }
     return;
@@ -1891,6 +1907,17 @@ __global__ __launch_bounds__(64 * MFMA_WAVES, TWO ? 4 : 2) void k_att_lstm_atten
   auto hook = [&]() {
     if (attn) attention_loads<512, true>(L, d, i, cur, b, part, Wq, v_w);  // (the late group follows the publish of h: attention_chunk)
   };
+  if (EARLY && TWO && d.att_hfirst) {  // + its own h_att(s-1) columns, ahead of the prenet columns (att_part then holds the context columns only)
+    constexpr int HC = EARLY && TWO ? ATT_RNN : 0;
+    const float4 *wblk = Wm + (size_t)blk * (ATT_COLS / 16) * 64 + lane;
+    switch (nta) {
+      case 1: lstm_mfma_pass<ATT_COLS, 0, 1, decltype(hook), 0, CN, EARLY, false, ATT_IN, HC>(d, 0, cur, step, blk, wblk, bz, wa, s_acc, m, 0, hook); break;
+      case 2: lstm_mfma_pass<ATT_COLS, 0, 2, decltype(hook), 0, CN, EARLY, false, ATT_IN, HC>(d, 0, cur, step, blk, wblk, bz, wa, s_acc, m, 0, hook); break;
+      case 3: lstm_mfma_pass<ATT_COLS, 0, 3, decltype(hook), 0, CN, EARLY, false, ATT_IN, HC>(d, 0, cur, step, blk, wblk, bz, wa, s_acc, m, 0, hook); break;
+      case 4: lstm_mfma_pass<ATT_COLS, 0, 4, decltype(hook), 0, CN, EARLY, false, ATT_IN, HC>(d, 0, cur, step, blk, wblk, bz, wa, s_acc, m, 0, hook); break;
+      default: return;
+    }
+  } else
   switch (nta) {
     case 1: lstm_mfma_pass<ATT_COLS, 0, 1, decltype(hook), 0, CN, EARLY>(d, 0, cur, step, blk, wsrc, bz, wa, s_acc, m, 0, hook); break;
     case 2: lstm_mfma_pass<ATT_COLS, 0, 2, decltype(hook), 0, CN, EARLY>(d, 0, cur, step, blk, wsrc, bz, wa, s_acc, m, 0, hook); break;
@@ -1992,6 +2019,7 @@ static void enqueue_steps(const DecoderBufs &d, const DeviceWeights &w, int i0, 
   if (!two) dd.hdg = dd.melg = nullptr;
   if (!two) dd.dec_part = nullptr;
   if (!two) dd.hring = nullptr;
+  if (!two) dd.att_hfirst = 0;
   const TailWeights tw{reinterpret_cast<const float4 *>(w.proj_w.p), w.proj_b.p, w.pre0T.p, w.pre1T.p, w.loc_conv.p, w.loc_denseT.p};
   for (int i = i0; i < i0 + nsteps; ++i) {
     const int cur = i & 1;

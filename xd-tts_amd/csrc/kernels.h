@@ -85,6 +85,10 @@ struct DecoderBufs {
   // [h_att ; ctx] (1536 columns) as before.  hring_steps: steps the ring is laid out for.
   unsigned *hring;
   int hring_steps;
+  // Two-launch form, round 6: the attention launch multiplies its OWN h_att(s-1) columns (1024 of the 1792) ahead of the prenet
+  // columns -- old data, in the ~4 us its first loads of x(s) take to arrive -- and att_part, written by the decoder-LSTM launch's
+  // extra blocks, covers the 512 context columns only: 1024 columns x chunks of matrix work leave the launch that is bound by it.
+  int att_hfirst;
 };
 constexpr int ATT_EXCHANGE_BLOCKS = 8;  // granule rows per chunk (CTX_BLOCKS in decoder.hip)
 // [B][T][128] -> [B][32][T][4]
