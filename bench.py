@@ -560,19 +560,20 @@ def main():
             log("config5 done")
           except Exception as e:  # noqa: BLE001  (the headline line must still be printed)
             extra["config5"] = {"error": repr(e)}
-        # ---- a handful of concurrent sentences: lock-step batches of 3..8 chunks on their own engine ---------------
+        # ---- a handful of concurrent sentences: lock-step batches of 3..16 chunks on their own engines (17: the batched engine beside them) ----
         if rank == 0:
           try:
             sb = {"workload": "lock-step decoder loop of B chunks of 60..99 ids, 200 frames each (src/phonemes.rs:677-680: the batched / parallel sentences at the size "
                               "a server with a few concurrent utterances has), decoder loop alone", "runs": []}
-            for B in (3, 4, 8):
+            for B in (3, 4, 8, 9, 12, 16, 17):
                 chunks = [wl.synth_ids(60 + (7 * b) % 40, seed=10 + b) for b in range(B)]
                 o = pkg.default_opts(dropout_seed=1)
                 for _ in range(2):
                     model.infer_batch(chunks, opts=o, fixed_steps=[200] * B)
                 ms = model.last_timings()["decoder_ms"]
                 sb["runs"].append({"chunks": B, "us_per_iteration": ms * 1e3 / 200, "mel_frames_per_s": B * 200 / (ms * 1e-3)})
-            sb["engine"] = "k_decoder_persistent8 (one persistent launch, LSTMs of all chunks on the matrix cores)" if model.engine_state()["decoder_persistent8"] == 1 else "fallback engines"
+            sb["engine"] = ("3..8 chunks: k_decoder_persistent8, 9..16: k_decoder_persistent16 (one persistent launch, LSTMs of all chunks on the matrix cores); "
+                            "17: the two-launch batched engine") if model.engine_state()["decoder_persistent8"] == 1 else "fallback engines"
             # four sentences that arrive together: one xdtts_synthesize_batch call against four xdtts_synthesize_ids calls
             import time as _t
             four = [wl.synth_ids(95, seed=30 + u) for u in range(4)]

@@ -84,6 +84,14 @@ void xdtts_infer_opts_default(xdtts_infer_opts *opts);
  * with a constant operand, and the graph input / output names the reference binds (xdtts_model_dir_describe). */
 xdtts_status xdtts_tacotron2_load(const char *dir, int32_t device_id, xdtts_tacotron2 **out);
 
+/* device_id of every constructor: a HIP device index, or XDTTS_DEVICE_DEFAULT = the process's default GPU -- environment variable
+ * XDTTS_DEVICE (read at every handle creation), 0 without it.  The reference's constructors take no device
+ * (`Tacotron2::load(path)`, `GriffinLim::new(..)`, src/lib.rs:40-58): a host that keeps their signatures passes XDTTS_DEVICE_DEFAULT
+ * and is spread over the GPUs of a node by one process per GPU with XDTTS_DEVICE = its rank.
+ * xdtts_default_device(): what XDTTS_DEVICE_DEFAULT resolves to now, or -1 (XDTTS_DEVICE is not a device index; xdtts_last_error). */
+#define XDTTS_DEVICE_DEFAULT (-1)
+int32_t xdtts_default_device(void);
+
 /* The host half of Tacotron2::load: reads `dir` (ONNX graphs or tacotron2.xdtw, as above) into a
  * caller-held flat fp32 blob in canonical tensor order (n_floats == xdtts_tensor_total()).  Needs no
  * device; xdtts_tacotron2_load(dir) == this + xdtts_tacotron2_load_blob. */

@@ -45,12 +45,13 @@ struct Unit {
 
 class Tacotron2 {
  public:
-  static Tacotron2 load(const std::string &path, int device_id = 0) {
+  // (device_id: XDTTS_DEVICE_DEFAULT = the process's default GPU, environment variable XDTTS_DEVICE -- the reference's load(path) takes none)
+  static Tacotron2 load(const std::string &path, int device_id = XDTTS_DEVICE_DEFAULT) {
     xdtts_tacotron2 *h = nullptr;
     check(xdtts_tacotron2_load(path.c_str(), device_id, &h));
     return Tacotron2(h);
   }
-  static Tacotron2 synthetic(uint32_t seed = 20240327u, float rec_scale = 1.0f, int device_id = 0) {
+  static Tacotron2 synthetic(uint32_t seed = 20240327u, float rec_scale = 1.0f, int device_id = XDTTS_DEVICE_DEFAULT) {
     xdtts_tacotron2 *h = nullptr;
     check(xdtts_tacotron2_load_synthetic(seed, rec_scale, device_id, &h));
     return Tacotron2(h);
@@ -107,7 +108,7 @@ inline Array2 create_mel_filter_bank(float sample_rate, size_t n_fft, size_t n_m
 
 class GriffinLim {
  public:
-  GriffinLim(const Array2 &mel_basis, size_t noverlap, float power, size_t iter, float momentum, int device_id = 0) {
+  GriffinLim(const Array2 &mel_basis, size_t noverlap, float power, size_t iter, float momentum, int device_id = XDTTS_DEVICE_DEFAULT) {
     check(xdtts_griffinlim_new(mel_basis.data.data(), mel_basis.rows, mel_basis.cols, noverlap, power, iter, momentum,
                                device_id, &g_));
   }
@@ -138,7 +139,7 @@ class GriffinLim {
 };
 
 // src/tacotron2/mod.rs:441-458
-inline GriffinLim create_griffin_lim(int device_id = 0) {
+inline GriffinLim create_griffin_lim(int device_id = XDTTS_DEVICE_DEFAULT) {
   const Array2 mel_basis = create_mel_filter_bank(22050.0f, 1024, 80, 0.0f, 8000.0f);
   return GriffinLim(mel_basis, 1024 - 256, 1.7f, 30, 0.99f, device_id);
 }

@@ -287,3 +287,23 @@ def test_the_loaded_library_was_built_from_the_sources_in_the_tree(pkg):
     info = pkg.build_info()
     assert info["arch"] == "gfx950"
     assert info["src_sha256"] == pkg.source_hash(), "libxdtts_hip.so is stale: run `make -C xd-tts_amd` (or __graft_entry__.build())"
+
+
+def test_default_device_follows_the_environment(pkg):
+    """XDTTS_DEVICE_DEFAULT (-1) as a device_id = environment variable XDTTS_DEVICE, read at every handle creation (how a host that
+    keeps the reference's device-less constructors, src/lib.rs:40-58, is spread over a node's GPUs); xdtts_default_device says what it
+    resolves to.  Host side only: no device is touched."""
+    old = os.environ.pop("XDTTS_DEVICE", None)
+    try:
+        assert pkg.DEVICE_DEFAULT == -1 and pkg.default_device() == 0
+        os.environ["XDTTS_DEVICE"] = "5"
+        assert pkg.default_device() == 5
+        for bad in ("gpu1", "-2", "3x", "99999"):
+            os.environ["XDTTS_DEVICE"] = bad
+            with pytest.raises(pkg.XdttsError) as e:
+                pkg.default_device()
+            assert "XDTTS_DEVICE" in str(e.value)
+    finally:
+        os.environ.pop("XDTTS_DEVICE", None)
+        if old is not None:
+            os.environ["XDTTS_DEVICE"] = old

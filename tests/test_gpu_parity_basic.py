@@ -90,3 +90,36 @@ def test_mel_to_linear_parity(pkg, orc):
     assert S.shape == ref.shape == (513, 50)
     assert np.abs(S - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
     voc.close()
+
+
+def test_handles_built_through_the_shims_default_device_path_agree(pkg, blob, tmp_path):
+    """INTEGRATION.md section 1: the reference-shaped constructors (Tacotron2::load(path), GriffinLim::new(..): no device argument) pass
+    XDTTS_DEVICE_DEFAULT and land on the GPU that XDTTS_DEVICE names; load_on / new_on pass the id.  Two handle pairs on GPU 0, one
+    built each way, give the same bits; an XDTTS_DEVICE beyond the visible devices is an error, not device 0."""
+    import os
+
+    m0 = pkg.Tacotron2.from_blob(blob, device_id=0)
+    m0.save(str(tmp_path))
+    m0.close()
+    ids = synth_ids(57, seed=4)
+    o = pkg.default_opts(fixed_steps=40, dropout_seed=9)
+    old = os.environ.pop("XDTTS_DEVICE", None)
+    try:
+        os.environ["XDTTS_DEVICE"] = "0"
+        a = pkg.Tacotron2.load(str(tmp_path), device_id=pkg.DEVICE_DEFAULT)     # Tacotron2::load(path)
+        va = pkg.create_griffin_lim(device_id=pkg.DEVICE_DEFAULT, iters=30, seed=2)  # create_griffin_lim()
+        b = pkg.Tacotron2.load(str(tmp_path), device_id=0)                      # Tacotron2::load_on(path, 0)
+        vb = pkg.create_griffin_lim(device_id=0, iters=30, seed=2)              # GriffinLim::new_on(.., 0)
+        ma, aa = pkg.synthesize(a, va, ids, opts=o)
+        mb, ab = pkg.synthesize(b, vb, ids, opts=o)
+        assert np.array_equal(ma, mb) and np.array_equal(aa, ab) and ma.shape == (80, 40)
+        for h in (a, va, b, vb):
+            h.close()
+        os.environ["XDTTS_DEVICE"] = str(pkg.device_count())                    # one past the last device
+        with pytest.raises(pkg.XdttsError) as e:
+            pkg.Tacotron2.load(str(tmp_path), device_id=pkg.DEVICE_DEFAULT)
+        assert "out of range" in str(e.value)
+    finally:
+        os.environ.pop("XDTTS_DEVICE", None)
+        if old is not None:
+            os.environ["XDTTS_DEVICE"] = old

@@ -114,6 +114,7 @@ SYMBOLS = {
     "xdtts_audio_to_i16": (_I32, [_VP, _SZ, _VP]),
     "xdtts_build_info": (C.c_char_p, []),
     "xdtts_edge_floor_us": (_I32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
+    "xdtts_default_device": (C.c_int32, []),
     "xdtts_silence_samples": (_SZ, [C.c_double, _U32]),
     "xdtts_silence_samples_duration": (_SZ, [C.c_uint64, _U32, _U32]),
     "xdtts_wav_write": (_I32, [C.c_char_p, _VP, _SZ, _U32]),
@@ -296,6 +297,17 @@ def source_hash():
         with open(f, "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()
+
+
+DEVICE_DEFAULT = -1  # XDTTS_DEVICE_DEFAULT: the process's default GPU (environment variable XDTTS_DEVICE, 0 without it)
+
+
+def default_device():
+    """What device_id = DEVICE_DEFAULT resolves to now (xdtts_default_device)."""
+    v = lib.xdtts_default_device()
+    if v < 0:
+        raise XdttsError(2, lib.xdtts_last_error().decode())
+    return int(v)
 
 
 def edge_floor_us(device_id=0, steps=2000, T=100, tuned=True):

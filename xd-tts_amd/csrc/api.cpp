@@ -54,12 +54,26 @@ static xdtts_status guard(F &&f) {
   }
 }
 
-static void select_device(int device_id) {
+// XDTTS_DEVICE_DEFAULT (-1) as a device_id = "the process's default GPU": the value of the environment variable XDTTS_DEVICE (read at
+// every handle creation), 0 without it.  It is how a host that keeps the reference's constructor signatures -- Tacotron2::load(path),
+// GriffinLim::new(..) take no device (src/lib.rs:40-58) -- is spread over the 8 GPUs of a node: one process per GPU, XDTTS_DEVICE = its
+// rank; the shim's load_on / new_on pass an explicit id instead.
+static int default_device() {
+  const char *e = getenv("XDTTS_DEVICE");
+  if (!e || !*e) return 0;
+  char *end = nullptr;
+  const long v = std::strtol(e, &end, 10);
+  if (end == e || *end != 0 || v < 0 || v > 1023) fail(XDTTS_ERR_BAD_ARG, "XDTTS_DEVICE=\"%s\" is not a device index", e);
+  return (int)v;
+}
+static int select_device(int device_id) {  // returns the device actually selected
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
     fail(XDTTS_ERR_NO_DEVICE, "no HIP device visible: libxdtts_hip has no CPU fallback");
+  if (device_id == XDTTS_DEVICE_DEFAULT) device_id = default_device();
   if (device_id < 0 || device_id >= n) fail(XDTTS_ERR_BAD_ARG, "device_id %d out of range (0..%d)", device_id, n - 1);
   HIP_CHECK(hipSetDevice(device_id));
+  return device_id;
 }
 
 // Pinned host buffers handed to the caller.  hipHostMalloc/hipHostFree cost hundreds of
@@ -1191,6 +1205,10 @@ struct xdtts_tacotron2 {
         F[order[j]] = Fs[j];
         total += Fs[j];
       }
+      // (In a sequence the vocoder of the PREVIOUS utterance may still be reading mel_dev on its own stream when this runs for the next
+      // one.  DevBuf::alloc only ever grows: the buffer is kept unless this utterance is longer than every one before it, and then the
+      // hipFree inside it synchronises the whole device before the old buffer goes -- correct, at the price of that one overlap.  The
+      // post-net's own writes into a kept buffer are ordered behind the vocoder by the event the frame loop waits for, before_decoder.)
       mel_dev.alloc((size_t)N_MEL * total);
       std::vector<long> col0(B), col(B);  // the final mel keeps the caller's chunk order on the time axis (mod.rs:430)
       long off = 0;
@@ -1718,11 +1736,16 @@ xdtts_status xdtts_tacotron2_load(const char *dir, int32_t device_id, xdtts_taco
   std::vector<float> blob;
   xdtts_status st = guard([&] {
     if (!dir) fail(XDTTS_ERR_BAD_ARG, "dir is null");
-    select_device(device_id);
+    device_id = select_device(device_id);
     load_model_dir(dir, blob);
   });
   if (st != XDTTS_OK) return st;
   return make_handle(std::move(blob), device_id, out);
+}
+
+int32_t xdtts_default_device(void) {
+  int32_t v = 0;
+  return guard([&] { v = default_device(); }) == XDTTS_OK ? v : -1;
 }
 
 xdtts_status xdtts_model_dir_read(const char *dir, float *blob, size_t n_floats) {
@@ -1752,7 +1775,7 @@ xdtts_status xdtts_tacotron2_load_synthetic(uint32_t seed, float rec_scale, int3
                                             xdtts_tacotron2 **out) {
   std::vector<float> blob;
   xdtts_status st = guard([&] {
-    select_device(device_id);
+    device_id = select_device(device_id);
     synthetic_blob(seed, rec_scale, blob);
   });
   if (st != XDTTS_OK) return st;
@@ -1765,7 +1788,7 @@ xdtts_status xdtts_tacotron2_load_blob(const float *blob, size_t n_floats, int32
   xdtts_status st = guard([&] {
     if (!blob) fail(XDTTS_ERR_BAD_ARG, "blob is null");
     if (n_floats != tensor_total()) fail(XDTTS_ERR_BAD_ARG, "blob has %zu floats, expected %zu", n_floats, tensor_total());
-    select_device(device_id);
+    device_id = select_device(device_id);
     v.assign(blob, blob + n_floats);
   });
   if (st != XDTTS_OK) return st;
@@ -2149,7 +2172,7 @@ xdtts_status xdtts_tacotron2_engine_reset(xdtts_tacotron2 *h) {
 xdtts_status xdtts_edge_floor_us(int32_t device_id, int32_t steps, int32_t T, int32_t tuned, double *us_per_step) {
   return guard([&] {
     if (!us_per_step || steps < 1 || steps > 1000000 || T < 1 || T > 128) fail(XDTTS_ERR_BAD_ARG, "bad argument");
-    select_device(device_id);
+    device_id = select_device(device_id);
     std::lock_guard<ChipLock> chip(chip_mutex(device_id));  // its grid must be co-resident, like the engine's
     const double us = xdtts_edge_floor::measure(device_id, steps, T, xdtts_edge_floor::kernel_delays(tuned ? 1 : 0), 5, false);
     if (us < 0) fail(XDTTS_ERR_HIP, "edge-floor skeleton: grid not co-resident on this device, or an exchange failed");
@@ -2218,7 +2241,7 @@ xdtts_status xdtts_griffinlim_new(const float *mel_basis, size_t n_mels, size_t 
       fail(XDTTS_ERR_BAD_ARG, "hop %zu unsupported: the framed-FFT kernels are built for hop = n_fft/4 = 256 (mod.rs:456)", n_fft - noverlap);
     if (n_mels % 16 != 0) fail(XDTTS_ERR_BAD_ARG, "n_mels %zu must be a multiple of 16", n_mels);
     if (!(power > 0) || momentum < 0) fail(XDTTS_ERR_BAD_ARG, "bad power/momentum");
-    select_device(device_id);
+    device_id = select_device(device_id);
     auto g = std::make_unique<xdtts_griffinlim>();
     g->device = device_id;
     g->n_mels = (int)n_mels;
