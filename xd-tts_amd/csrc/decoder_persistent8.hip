@@ -694,7 +694,11 @@ P8Bufs p8_bufs(unsigned long long *base, int *err, int B, int nsteps) {
   g.delay[1] = 64;
   g.delay[4] = 24;
   g.delay[5] = 16;
-  if (nb > NBMAX) g.delay[4] = g.delay[5] = 0;  // 16-slot kernel: its role workgroups run MFMAs between a publish and the poll that answers it
+  if (nb > NBMAX) {  // 16-slot kernel: its role workgroups run MFMAs between a publish and the poll that answers it; twice the bytes per gather
+    g.delay[0] = g.delay[2] = 20;
+    g.delay[1] = 80;
+    g.delay[4] = g.delay[5] = 0;
+  }
   if (const char *e = getenv("XDTTS_P8_DELAY")) sscanf(e, "%d,%d,%d,%d,%d,%d", &g.delay[0], &g.delay[1], &g.delay[2], &g.delay[3], &g.delay[4], &g.delay[5]);  // developer sweep
   return g;
 }
