@@ -1,11 +1,11 @@
-"""Developer aid: long sequences on the 3..8-chunk engine (its rings hold one slab per step): three runs each must give the same bits,
+"""Developer aid: long sequences on the 3..16-chunk engines (its rings hold one slab per step): three runs each must give the same bits,
 finite values, the engine still on."""
 import importlib, sys, hashlib, numpy as np
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("xd-tts_amd"); wl = importlib.import_module("xd-tts_amd.workloads")
 m = pkg.Tacotron2.synthetic()
-for B, steps in ((8, 3000), (5, 2500), (3, 4000)):
+for B, steps in [(int(a.split(":")[0]), int(a.split(":")[1])) for a in sys.argv[1:]] or ((8, 3000), (5, 2500), (3, 4000), (16, 2500), (11, 3000)):  # optional arguments B:steps
     chunks = [wl.synth_ids(60 + (7 * b) % 40, seed=10 + b) for b in range(B)]
     o = pkg.default_opts(dropout_seed=1, max_steps=steps)
     hs = []
