@@ -378,6 +378,7 @@ struct xdtts_tacotron2 {
   DevBuf<float> pp0, ppA, ppB, mel_dev;
   std::vector<long> pp_sig;  // layout (items, frames, allocations) whose padding is known to be zero in pp0 / ppA / ppB
   std::function<void()> before_decoder;  // enqueued between the encoder and the frame loop of infer_batch_device (or empty)
+  std::function<void()> while_decoding;  // host work for the time the frame loop runs: called once everything of the decode is enqueued, before the host waits for it (or empty)
   int *host_ctl = nullptr;  // pinned mirror of ctlblk: [0..1] ctl, [HOST_ENC_ERR] / [HOST_DEC_ERR] the engines' error words, [HOST_NF ..] nframes
   static constexpr int HOST_ENC_ERR = 2, HOST_DEC_ERR = 3, HOST_NF = 4, CTL_INTS = HOST_NF + 4096;
 
@@ -782,8 +783,10 @@ struct xdtts_tacotron2 {
         HIP_CHECK(hipEventRecord(fetched, stream));
         after();
         spec_ran = true;
+        if (while_decoding) while_decoding();
         HIP_CHECK(hipEventSynchronize(fetched));
       } else {
+        if (last && while_decoding) while_decoding();
         HIP_CHECK(hipStreamSynchronize(stream));
       }
     };
@@ -2358,7 +2361,7 @@ static void gl_enqueue_from_device_mel(xdtts_griffinlim *g, const float *mel_dev
   g->iterate(b, nullptr, g->iters);
   launch_gl_output_normalise(g->audio.p, nullptr, 1, 0, (int)N, g->gopts.output_normalise, g->gopts.rms_target, g->norm_parts.p, g->stream);
   HIP_CHECK(hipEventRecord(g->ev.e[2], g->stream));
-  host = PinnedGuard(N);
+  if (!host.p) host = PinnedGuard(N);  // (the sequence hands in one it took from the pool while the frame loop ran)
   HIP_CHECK(hipMemcpyAsync(host.p, g->audio.p, N * sizeof(float), hipMemcpyDeviceToHost, g->stream));
   g->fetch_error_word();
 }
@@ -2809,7 +2812,10 @@ xdtts_status xdtts_synthesize_sequence(xdtts_tacotron2 *h, xdtts_griffinlim *g, 
     const xdtts_infer_opts o = resolve_opts(opts);
     struct Hook {  // (the hook never outlives this call, whatever throws)
       xdtts_tacotron2 *h;
-      ~Hook() { h->before_decoder = nullptr; }
+      ~Hook() {
+        h->before_decoder = nullptr;
+        h->while_decoding = nullptr;
+      }
     } unhook{h};
     std::vector<PinnedGuard> mel_host(n_utt), audio_host(n_utt);
     std::vector<int> total(n_utt, 0);
@@ -2843,9 +2849,28 @@ xdtts_status xdtts_synthesize_sequence(xdtts_tacotron2 *h, xdtts_griffinlim *g, 
         std::vector<int> lens;
         chunks_from_splits(ids[u], n_ids[u], splits ? splits[u] : nullptr, (splits && n_splits) ? n_splits[u] : 0, o.max_chunk, padded, lens);
         if (u > 0) h->before_decoder = [&] { HIP_CHECK(hipStreamWaitEvent(h->stream, g->ev.e[2], 0)); };  // vocoder of u - 1 done (its audio copy is behind it on g->stream)
+        // The pinned output buffers of utterance u are taken from the pool WHILE its frame loop runs (the host has 5.6 ms to wait there), not
+        // between the vocoder's enqueue and the next encoder's: a pool miss is a hipHostMalloc of 0.8 MB -- 0.2-0.4 ms on some boxes -- and in
+        // that place it made the next encoder start when the vocoder had finished instead of beside it (round 6: the sequence headline's two
+        // modes, 6.15-6.25 / 6.5-6.6 ms per utterance; the kernel timeline of tools/sequence_timeline.sh shows k_embed behind k_gl_persistent
+        // in the slow utterances).  Gate-less decodes only: the frame count is then known beforehand.
+        long predicted = 0;
+        if (o.fixed_steps > 0 || o.fixed_frames_per_id > 0.f)
+          for (int len : lens) {
+            const long l = o.fixed_steps > 0 ? o.fixed_steps : std::lround((double)o.fixed_frames_per_id * len);
+            predicted += std::min<long>(std::max<long>(l, 1), o.max_steps);
+          }
+        h->while_decoding = nullptr;
+        if (predicted >= 2)
+          h->while_decoding = [&, u, predicted] {
+            if (!mel_host[u].p) mel_host[u] = PinnedGuard((size_t)N_MEL * predicted);
+            if (!audio_host[u].p) audio_host[u] = PinnedGuard((size_t)g->hop * (size_t)(predicted - 1));
+          };
         for (int i = 0; i < 4; ++i) std::swap(h->ev.e[i], per[u].e[i]);  // (per[u] now holds what the handle had: utterance u - 1's set, or its own)
         h->infer_batch_device(padded.data(), lens.data(), (int)lens.size(), o.max_chunk, o, nullptr, &total[u]);
         h->before_decoder = nullptr;
+        h->while_decoding = nullptr;
+        if (predicted != total[u]) mel_host[u] = PinnedGuard(), audio_host[u] = PinnedGuard();  // (the stop rule decided otherwise: sized below)
         steps_sum += h->last_steps;
         if (total[u] < 2) fail(XDTTS_ERR_BAD_ARG, "utterance %d: mel has %d frame(s); the vocoder needs at least 2", u, total[u]);
         // the frame loop of u has drained, and it waited for the vocoder of u - 1: collect that audio now
@@ -2853,7 +2878,7 @@ xdtts_status xdtts_synthesize_sequence(xdtts_tacotron2 *h, xdtts_griffinlim *g, 
           gl_collect(g, total[u - 1], audio_host[u - 1], &audio_out[u - 1], &n_samples[u - 1]);
           add_gl();
         }
-        mel_host[u] = PinnedGuard((size_t)N_MEL * total[u]);
+        if (!mel_host[u].p) mel_host[u] = PinnedGuard((size_t)N_MEL * total[u]);
         HIP_CHECK(hipStreamWaitEvent(g->stream, h->ev.e[3], 0));  // the vocoder reads the mel behind the post-net
         HIP_CHECK(hipMemcpyAsync(mel_host[u].p, h->mel_dev.p, (size_t)N_MEL * total[u] * sizeof(float), hipMemcpyDeviceToHost, h->stream));
         gl_enqueue_from_device_mel(g, h->mel_dev.p, total[u], audio_host[u]);
