@@ -61,12 +61,33 @@ __host__ __device__ constexpr int p8_slots(int B) { return B <= 4 ? 4 : (B <= NB
 
 // NQ b128 loads of the wave's slice of one state segment (seg: LDS base of the segment in B order [k/4][NB][4]; q0: the wave's
 // first column quad-of-quads), 4 MFMAs each, into acc.  A[q] = the lane's four weights of columns 16 (q0 + q) + 4 kk .. + 3.
+#ifndef XDTTS_P8_TWO_CHAINS
+#define XDTTS_P8_TWO_CHAINS 0
+#endif
 template <int NB, int NQ, int FROM = 0, int TO = NQ>
 __device__ __forceinline__ void mfma_segment(f32x4 &acc, const float4 (&A)[NQ], const float *seg, int q0, int kk, int n) {
   // one B vector ahead of the MFMAs that consume it, and no further
   if constexpr (FROM >= TO) return;
   const float *bp = seg + ((4 * q0 + kk) * NB + n) * 4;
   float4 b = lds4(bp + FROM * 4 * NB * 4);
+#if XDTTS_P8_TWO_CHAINS
+  // two accumulator chains (x / z and y / w components): a dependent v_mfma_f32_16x16x4_f32 issues 40 cycles after its predecessor, an
+  // independent one 32 (round 6, from the 16-slot kernel).  NOT the default: this kernel sits at 256 + 253 registers, the second chain's
+  // four push it into scratch (36 spill instructions) -- 16.3 / 15.6 / 18.0 / 18.2 us at 3 / 4 / 5 / 8 chunks against 14.8 / 14.7 / 15.9 / 17.0
+  f32x4 acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = FROM; q < TO; ++q) {
+    const float4 bn = q + 1 < TO ? lds4(bp + (q + 1) * 4 * NB * 4) : b;
+    asm volatile("" ::: "memory");
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[q].x, b.x, acc, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[q].y, b.y, acc1, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(A[q].z, b.z, acc, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(A[q].w, b.w, acc1, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    b = bn;
+  }
+  acc += acc1;
+#else
 #pragma unroll
   for (int q = FROM; q < TO; ++q) {
     const float4 bn = q + 1 < TO ? lds4(bp + (q + 1) * 4 * NB * 4) : b;
@@ -78,6 +99,7 @@ __device__ __forceinline__ void mfma_segment(f32x4 &acc, const float4 (&A)[NQ], 
     __builtin_amdgcn_sched_barrier(0);
     b = bn;
   }
+#endif
 }
 
 // Developer build (-DXDTTS_P8_PROFILE): thread 0 of three workgroups (one per role) accumulates the 100 MHz wall clock between
