@@ -557,3 +557,40 @@ def test_gemm_tile_shapes_give_identical_results(tmp_path):
             out[tile] = [z[k] for k in z.files]
     assert len(out["32"]) == 24
     assert all(np.array_equal(a, b) for a, b in zip(out["32"], out["64"]))
+
+
+@pytest.mark.parametrize("switch", ["XDTTS_HRING", "XDTTS_HFIRST"])
+def test_round6_rebuilds_of_the_two_launch_engine_stay_parity_green(switch, tmp_path):
+    """The two forms of the batched iteration that round 6 built, measured and did not make the default (h_att(s) as an
+    in-launch operand ring for the decoder LSTM's h_att columns; the attention launch multiplying its own h_att(s-1) columns ahead of
+    x(s)) are still in the library behind an environment switch (read once per process: a child process).  Each must keep producing the
+    oracle's frames: 21 chunks of different lengths, fixed and different step counts, every chunk against its own oracle run."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = (
+        "import importlib, sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import torch, oracle\n"
+        "from conftest import synth_ids, rms\n"
+        "pkg = importlib.import_module('xd-tts_amd')\n"
+        "orc = oracle.Oracle('f32')\n"
+        "blob = orc.weights_synthetic(seed=20240327, rec_scale=1.0)\n"
+        "m = pkg.Tacotron2.from_blob(blob)\n"
+        "n = 21\n"
+        "ids = [synth_ids(18 + 4 * i, seed=800 + i) for i in range(n)]\n"
+        "steps = [9 + (5 * i) %% 11 for i in range(n)]\n"
+        "mels = m.infer_batch(ids, opts=pkg.default_opts(dropout_seed=23), fixed_steps=steps)\n"
+        "assert m.engine_state()['batched_attention'] == 2, m.engine_state()\n"
+        "worst = 0.0\n"
+        "for b in range(n):\n"
+        "    ref = orc.infer_chunk(blob, ids[b], orc.default_opts(fixed_steps=steps[b], dropout_seed=23, item=b))\n"
+        "    assert mels[b].shape == ref.shape, (b, mels[b].shape, ref.shape)\n"
+        "    worst = max(worst, rms(mels[b], ref))\n"
+        "print('WORST %%.3e' %% worst)\n"
+    ) % (root, os.path.join(root, "tests"))
+    r = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, **{switch: "1"}), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    worst = float([ln for ln in r.stdout.splitlines() if ln.startswith("WORST")][-1].split()[1])
+    assert worst <= 1e-5, (switch, worst)
