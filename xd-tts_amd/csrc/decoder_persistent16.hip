@@ -12,9 +12,16 @@
 //     and its MFMAs, and each vector is read once for both LSTMs that consume it (h_att(s): the decoder LSTM of step s and the
 //     attention LSTM of step s + 1, back to back);
 //   * 8 + 8 role workgroups per chunk instead of 8 + 16 (16 x 16 = the grid): a projection / prenet workgroup owns 32 layer-2
-//     columns and up to 11 rows of [W_p ; w_gate] -- two rows per wave in registers as before, the third in LDS;
-//   * a role workgroup fetches its own chunk's vector (one quad per thread, row-major into LDS) FIRST and runs its role, the
-//     sixteen operand quads per lane follow -- the step's critical chain never waits for the bulk;
+//     columns and up to 11 rows of [W_p ; w_gate];
+//   * the register file decides where the role tables live: 256 of a lane's 512 registers are LSTM weights (the 16 prenet-column
+//     operands of the attention LSTM sit in LDS), so the projection rows come from L2 every step (18 kB per wave, requested ahead of
+//     the poll they wait behind), layer 2 ([segment][input quad][column][4]), the encoder-memory slice ([t / 4][64][4]) and the gate
+//     biases live in LDS, and loop-invariant store addresses are re-formed per step.  No scratch;
+//   * ROLE FIRST: a role workgroup fetches its own chunk's vector (one quad per thread, row-major into LDS), requests the first
+//     operand rounds behind its arrival, runs its role and publishes; the attention role multiplies ONE round of h_att while its
+//     partial energies travel and the rest behind its context publish, the projection / prenet role multiplies h_dec behind its x
+//     publish -- the step's critical chain never waits for the bulk.  (The -D knobs below are the experiments of DESIGN_NOTES.md,
+//     round 6; the defaults are the measured best.)
 //   * the chunks' active bits are per-lane state (the sign of x(s), as before) combined by a ballot, shared through one LDS word.
 // Per step:  x -> [attention LSTM] -> h_att -> [query, energies] -> e -> [softmax, context] -> ctx -> [decoder LSTM] -> h_dec
 //            -> [projection rows] -> mel -> [stop rule, prenet] -> x(s+1)
