@@ -559,7 +559,7 @@ def test_gemm_tile_shapes_give_identical_results(tmp_path):
     assert all(np.array_equal(a, b) for a, b in zip(out["32"], out["64"]))
 
 
-@pytest.mark.parametrize("switch", ["XDTTS_HRING", "XDTTS_HFIRST"])
+@pytest.mark.parametrize("switch", ["XDTTS_HRING", "XDTTS_HRING=1r", "XDTTS_HFIRST"])
 def test_round6_rebuilds_of_the_two_launch_engine_stay_parity_green(switch, tmp_path):
     """The two forms of the batched iteration that round 6 built, measured and did not make the default (h_att(s) as an
     in-launch operand ring for the decoder LSTM's h_att columns; the attention launch multiplying its own h_att(s-1) columns ahead of
@@ -590,7 +590,7 @@ def test_round6_rebuilds_of_the_two_launch_engine_stay_parity_green(switch, tmp_
         "    worst = max(worst, rms(mels[b], ref))\n"
         "print('WORST %%.3e' %% worst)\n"
     ) % (root, os.path.join(root, "tests"))
-    r = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, **{switch: "1"}), capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, **{switch.split("=")[0]: (switch.split("=") + ["1"])[1]}), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     worst = float([ln for ln in r.stdout.splitlines() if ln.startswith("WORST")][-1].split()[1])
     assert worst <= 1e-5, (switch, worst)

@@ -336,6 +336,7 @@ struct xdtts_tacotron2 {
   DevBuf<float> att_part;  // early partial pre-activations of the attention LSTM (DecoderBufs::att_part)
   DevBuf<float> dec_part;  // two-launch form: early partial of the decoder LSTM's h_dec columns (DecoderBufs::dec_part)
   DevBuf<unsigned> h_ring;  // two-launch form: h_att per step as a write-once ring (DecoderBufs::hring)
+  DevBuf<unsigned> h_stage;  // ... its per-XCD copies and their counters (DecoderBufs::hstage, hcnt)
   DevBuf<unsigned long long> tail_exchange;  // two-launch form: h_dec and mel granules (DecoderBufs::hdg, melg)
   // batched mode: energies, softmax and context in one launch (XDTTS_ATT_FUSED=0: the two-kernel form; also after
   // an exchange of that launch timed out)
@@ -659,10 +660,16 @@ struct xdtts_tacotron2 {
                 // 8-10 us for what a grid boundary delivers in 2.  XDTTS_HRING=1 enables it.
                 static const bool want_hr = getenv("XDTTS_HRING") != nullptr && getenv("XDTTS_HRING")[0] == '1';
                 const size_t ring_words = (size_t)ms * ATT_RNN * Bpad;
+                static const bool want_relay = want_hr && getenv("XDTTS_HRING")[1] == 'r';  // XDTTS_HRING=1r: with the per-XCD relay
                 if (want_hr && ring_words * sizeof(unsigned) <= ((size_t)1 << 30)) try {
                   h_ring.alloc(ring_words);
                   d.hring = h_ring.p;
                   d.hring_steps = ms;
+                  if (want_relay) {
+                    h_stage.alloc((size_t)16 * ATT_RNN * Bpad + (size_t)8 * ms * 64);
+                    d.hstage = h_stage.p;
+                    d.hcnt = h_stage.p + (size_t)16 * ATT_RNN * Bpad;
+                  }
                 } catch (const Error &e) {
                   if (e.code != XDTTS_ERR_OOM) throw;
                   (void)hipGetLastError();
@@ -995,6 +1002,10 @@ struct xdtts_tacotron2 {
     if (d.hg) chip = std::unique_lock<ChipLock>(chip_mutex(device));
     if (d.hring)  // the slabs of the steps this request can reach: "not yet written"
       HIP_CHECK(hipMemsetAsync(d.hring, 0xff, (size_t)std::min(max_lim, d.hring_steps) * ATT_RNN * d.Bpad * sizeof(unsigned), stream));
+    if (d.hcnt) {
+      HIP_CHECK(hipMemsetAsync(d.hstage, 0xff, (size_t)16 * ATT_RNN * d.Bpad * sizeof(unsigned), stream));
+      HIP_CHECK(hipMemsetAsync(d.hcnt, 0, (size_t)d.hring_steps * 8 * 64 * sizeof(unsigned), stream));
+    }
     if (!d.use_gate) {  // deterministic work: every chunk runs to its cap
       while (launched + GRAPH_STEPS <= max_lim) {
         replay_steps(d);
@@ -1041,6 +1052,7 @@ struct xdtts_tacotron2 {
         d2.hdg = d2.melg = nullptr;
         d2.dec_part = nullptr;
         d2.hring = nullptr;
+        d2.hstage = d2.hcnt = nullptr;
         d2.att_hfirst = 0;
         return run_decoder(d2, lim);  // (no `after`: the caller enqueues its work behind this decode)
       }
@@ -2080,6 +2092,10 @@ xdtts_status xdtts_tacotron2_decoder_steps(xdtts_tacotron2 *h, int32_t engine, i
       if (d.hg) chip = std::unique_lock<ChipLock>(chip_mutex(h->device));
       if (engine == 0) launch_decoder_location(d, h->w, st);  // (the batched prenet launch computes them itself)
       if (d.hring) HIP_CHECK(hipMemsetAsync(d.hring, 0xff, (size_t)d.hring_steps * ATT_RNN * d.Bpad * sizeof(unsigned), st));
+      if (d.hcnt) {
+        HIP_CHECK(hipMemsetAsync(d.hstage, 0xff, (size_t)16 * ATT_RNN * d.Bpad * sizeof(unsigned), st));
+        HIP_CHECK(hipMemsetAsync(d.hcnt, 0, (size_t)d.hring_steps * 8 * 64 * sizeof(unsigned), st));
+      }
       launch_decoder_early(d, h->w, 0, st);  // (batched engine: the first attention-LSTM pass's early partial, from the imported state)
       launch_decoder_prologue(d, h->w, st);  // (two-launch form: x and location features of the first step; d.dec_in = decoder_input)
       for (int i = 0; i < n_steps; ++i) {

@@ -716,6 +716,25 @@ __global__ __launch_bounds__(256) void k_lstm(DecoderBufs d, int i, int cur, con
 // tagged 8-byte granules {tag = step + 1, value}: the in-launch exchanges of the batched kernels (comments at k_attention_b)
 typedef unsigned long long u64;
 constexpr unsigned AB_SPIN_LIMIT = 1u << 20;
+
+// One agent-scope fetch-and-add per WAVE, its result in a scalar: lane 0 alone issues it (the exec mask is narrowed and restored inside
+// the statement).  Written as one opaque statement because the compiler threads `if (lane == 0) t = atomic...; t = readfirstlane(t)`
+// through a surrounding loop into one loop for lane 0 and another for the other 63 lanes, whose readfirstlane then reads a lane that
+// never held the result (seen: round 6, the relay's ticket loop never ended).  The wave must be whole (all 64 lanes active) here.
+__device__ __forceinline__ unsigned wave_fetch_add(unsigned *p, unsigned v) {
+  unsigned r;
+  unsigned long long keep;
+  asm volatile(
+      "s_mov_b64 %1, exec\n\t"
+      "s_mov_b64 exec, 1\n\t"
+      "global_atomic_add %0, %2, %3, %4 sc0\n\t"
+      "s_waitcnt vmcnt(0)\n\t"
+      "s_mov_b64 exec, %1"
+      : "=&v"(r), "=&s"(keep)
+      : "v"(0u), "v"(v), "s"(p)
+      : "memory");
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)r);
+}
 __device__ __forceinline__ void granule_store(u64 *slot, unsigned tag, float v) {
   __hip_atomic_store(slot, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -987,6 +1006,19 @@ __device__ __forceinline__ void att_early_partial(const DecoderBufs &d, int hcur
 #endif
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fi = lane & 15, fg = lane >> 4;
   const float4 *wsrc = Wm + ((size_t)blk * KSTEPS + K0 + wave * JJ) * 64 + lane;
+  unsigned xcc = 0;
+  unsigned *rcnt = nullptr;  // per-XCD relay of the h_att ring (below): this XCD's counters of the step, [0] octets of rows drawn, [1] rows in the copy
+  if constexpr (HIN) {
+    if (d.hstage) {  // the block draws its octet now, the answer is needed after the first K-loop
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      xcc &= 7u;
+      rcnt = d.hcnt + ((size_t)xcc * d.hring_steps + step) * 64;  // (256 bytes per counter pair, the XCDs' counters far apart: not one line, not one channel)
+      if (wave == 0) {
+        const unsigned t = wave_fetch_add(rcnt, 1u);
+        if (lane == 0) reinterpret_cast<volatile unsigned *>(lds)[0] = t;
+      }
+    }
+  }
   const float4 *seg1 = reinterpret_cast<const float4 *>(d.ctxf), *seg2 = reinterpret_cast<const float4 *>(KIND ? d.dec_hf[hcur] : d.att_hf[hcur]);
   auto src = [&](int jj) {  // (wave-uniform segment choice: scalar code)
     const int col = 16 * (wave * JJ + jj);  // column behind the prenet columns (KIND 1: of h_dec)
@@ -1040,12 +1072,60 @@ __device__ __forceinline__ void att_early_partial(const DecoderBufs &d, int hcur
     // ahead of the MFMAs.  Lanes of chunks that do not run this step take zeros and wait for nobody.
     constexpr int JH = (ATT_RNN / 16) / NWV;  // 8 k-steps per wave
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(d.hring + (size_t)step * ATT_RNN * d.Bpad), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_ring = __builtin_amdgcn_make_buffer_rsrc((void *)(d.hring + (size_t)step * ATT_RNN * d.Bpad), 0, 0x7fffffff, 0x00020000);
     const float4 *wh = Wm + ((size_t)blk * KSTEPS + wave * JH) * 64 + lane;
     const unsigned spin_limit = d.att_spins > 0 ? (unsigned)d.att_spins : AB_SPIN_LIMIT;
     bool on[NTA];
 #pragma unroll
     for (int t = 0; t < NTA; ++t) on[t] = (active >> (16 * t + fi)) & 1ull;
+    // Per-XCD relay (d.hstage): 256 blocks each pulling the whole slab from the other XCDs get ~24 GB/s per CU (6 TB/s over the chip: the
+    // rate of every in-launch bulk edge on this part).  Instead the blocks that find themselves on XCD x (HW_REG_XCC_ID: a fact, not an
+    // assumption about placement) share the pull: every block draws an octet of the slab's 256 k-quad rows of [chunks][4] from the XCD's
+    // ticket counter (at entry, one atomic per block), each of its waves polls one row of it out of the ring (one quad per lane) and
+    // writes it into the XCD's own copy with plain stores (they stay in that XCD's L2); everybody polls its operands out of that copy,
+    // with L1-bypassing loads that hit the shared L2, under the ring's own rule (a quad with a fill word is not there yet).  The XCD has
+    // two copies, by step parity: whoever fills a row of this step's copy puts the fill pattern back into the same row of the other,
+    // which the previous launch is done with and the next one will poll (the host fills both at the start of a request).  Any number
+    // of blocks per XCD completes the copy: a wave whose poll stays pending looks at the ticket counter and takes an undrawn octet whole.
+    const bool relay = d.hstage != nullptr;
+    __amdgpu_buffer_rsrc_t rs = rs_ring, rs_stage = rs_ring, rs_other = rs_ring;
+    constexpr unsigned ROWS = ATT_RNN / 4, OCTETS = ROWS / NWV;
+    const bool mine = lane < 16 * NTA, wanted = mine && ((active >> lane) & 1ull);
+    auto move_row = [&](unsigned row) {  // ring -> this XCD's copy of the step, one quad per lane; the same row of the other copy back to "unwritten"
+      const int off = (int)((row * (unsigned)d.Bpad + (unsigned)lane) * 16u);
+      u32x4 v = (u32x4){0u, 0u, 0u, 0u};
+      if (wanted) {
+        unsigned spins = 0;
+        v = __builtin_amdgcn_raw_buffer_load_b128(rs_ring, off, 0, 16);
+        while (v.x == 0xffffffffu || v.y == 0xffffffffu || v.z == 0xffffffffu || v.w == 0xffffffffu) {
+          if (++spins > spin_limit || ((spins & 127u) == 0 && __hip_atomic_load(d.att_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            atomicExch(d.att_err, 1);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+          v = __builtin_amdgcn_raw_buffer_load_b128(rs_ring, off, 0, 17);
+        }
+      }
+      if (mine) {
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs_stage, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128((u32x4){0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, rs_other, off, 0, 0);
+      }
+    };
+    auto rescue = [&]() {  // octets no block has drawn (fewer than 32 of these blocks on this XCD): whoever waits long enough takes one whole
+      if ((unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(rcnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) >= OCTETS) return;
+      const unsigned t2 = wave_fetch_add(rcnt, 1u);
+      if (t2 < OCTETS)
+        for (unsigned r = 0; r < (unsigned)NWV; ++r) move_row(t2 * NWV + r);
+    };
+    if (relay) {
+      const size_t copy = (size_t)ATT_RNN * d.Bpad;
+      rs_stage = __builtin_amdgcn_make_buffer_rsrc((void *)(d.hstage + (2 * xcc + (step & 1)) * copy), 0, 0x7fffffff, 0x00020000);
+      rs_other = __builtin_amdgcn_make_buffer_rsrc((void *)(d.hstage + (2 * xcc + ((step & 1) ^ 1)) * copy), 0, 0x7fffffff, 0x00020000);
+      __syncthreads();  // the block's octet (ticket drawn at entry): one row per wave
+      const unsigned tk = (unsigned)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<volatile unsigned *>(lds)[0]);
+      if (tk < OCTETS) move_row(tk * NWV + (unsigned)wave);
+      rs = rs_stage;
+    }
     auto voff = [&](int jj, int t) { return (int)((((unsigned)(4 * (wave * JH + jj) + fg) * (unsigned)d.Bpad) + 16u * t + fi) * 16u); };
     // (operand quads DH k-steps ahead: a poll of another XCD's fresh data takes ~1.3 us whatever it finds, a k-step's MFMAs 0.2 us)
     constexpr int DH = NTA <= 2 ? 6 : (NTA == 3 ? 4 : 3);
@@ -1054,7 +1134,7 @@ __device__ __forceinline__ void att_early_partial(const DecoderBufs &d, int hcur
 #pragma unroll
     for (int p = 0; p < DH; ++p) {
 #pragma unroll
-      for (int t = 0; t < NTA; ++t) hb[p][t] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff(p, t), 0, XDTTS_HRING_AUX);
+      for (int t = 0; t < NTA; ++t) hb[p][t] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff(p, t), 0, 16);
       wv2[p] = wh[(size_t)p * 64];
     }
 #pragma unroll
@@ -1072,9 +1152,10 @@ __device__ __forceinline__ void att_early_partial(const DecoderBufs &d, int hcur
           break;
         }
         __builtin_amdgcn_s_sleep(1);
+        if (relay && (spins & 63u) == 32u) rescue();
 #pragma unroll
         for (int t = 0; t < NTA; ++t)
-          if ((pending >> t) & 1u) v[t] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff(jj, t), 0, 17);
+          if ((pending >> t) & 1u) v[t] = relay ? __builtin_amdgcn_raw_buffer_load_b128(rs, voff(jj, t), 0, 16) : __builtin_amdgcn_raw_buffer_load_b128(rs, voff(jj, t), 0, 17);  // (the XCD's copy lives in this L2: sc1 is enough)
 #pragma unroll
         for (int t = 0; t < NTA; ++t)
           if (((pending >> t) & 1u) && v[t].x != 0xffffffffu && v[t].y != 0xffffffffu && v[t].z != 0xffffffffu && v[t].w != 0xffffffffu) pending &= ~(1u << t);
@@ -1091,7 +1172,7 @@ __device__ __forceinline__ void att_early_partial(const DecoderBufs &d, int hcur
       for (int t = 0; t < NTA; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, __uint_as_float(v[t].w), acc[t], 0, 0, 0);
       if (jj + DH < JH) {  // the slot just consumed: the operands DH k-steps on
 #pragma unroll
-        for (int t = 0; t < NTA; ++t) v[t] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff(jj + DH, t), 0, XDTTS_HRING_AUX);
+        for (int t = 0; t < NTA; ++t) v[t] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff(jj + DH, t), 0, 16);
         wv2[jj % DH] = wh[(size_t)(jj + DH) * 64];
       }
     }
@@ -2019,6 +2100,7 @@ static void enqueue_steps(const DecoderBufs &d, const DeviceWeights &w, int i0, 
   if (!two) dd.hdg = dd.melg = nullptr;
   if (!two) dd.dec_part = nullptr;
   if (!two) dd.hring = nullptr;
+  if (!two) dd.hstage = dd.hcnt = nullptr;
   if (!two) dd.att_hfirst = 0;
   const TailWeights tw{reinterpret_cast<const float4 *>(w.proj_w.p), w.proj_b.p, w.pre0T.p, w.pre1T.p, w.loc_conv.p, w.loc_denseT.p};
   for (int i = i0; i < i0 + nsteps; ++i) {

@@ -85,6 +85,10 @@ struct DecoderBufs {
   // [h_att ; ctx] (1536 columns) as before.  hring_steps: steps the ring is laid out for.
   unsigned *hring;
   int hring_steps;
+  // ... and the per-XCD relay of that ring (decoder.hip, att_early_partial): hstage [8 XCDs][2 step parities][1024 / 4][Bpad][4], copies of
+  // the step's slab per XCD; hcnt [8][steps][64] = {octets of rows drawn, ..} per XCD and step (zero at the start of a request).
+  // null = every block polls the ring itself.
+  unsigned *hstage, *hcnt;
   // Two-launch form, round 6: the attention launch multiplies its OWN h_att(s-1) columns (1024 of the 1792) ahead of the prenet
   // columns -- old data, in the ~4 us its first loads of x(s) take to arrive -- and att_part, written by the decoder-LSTM launch's
   // extra blocks, covers the 512 context columns only: 1024 columns x chunks of matrix work leave the launch that is bound by it.
