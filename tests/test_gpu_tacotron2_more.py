@@ -594,3 +594,39 @@ def test_round6_rebuilds_of_the_two_launch_engine_stay_parity_green(switch, tmp_
     assert r.returncode == 0, r.stderr[-2000:]
     worst = float([ln for ln in r.stdout.splitlines() if ln.startswith("WORST")][-1].split()[1])
     assert worst <= 1e-5, (switch, worst)
+
+
+@pytest.mark.parametrize("env", [{"XDTTS_GEMM_SPLITK": "2"}, {"XDTTS_GEMM_SPLITK": "3"}, {"XDTTS_GEMM_SPLITK": "4"},
+                                 {"XDTTS_GEMM_SPLITK": "4", "XDTTS_GEMM_SPLIT_TILE": "64"}], ids=lambda e: "-".join(e.values()))
+def test_split_k_gemm_at_forced_slice_counts(env, tmp_path):
+    """k_gemm_nt's split-K (gemm.hip: grid z = item x K-slice, partial tiles through a workspace, the last arriver sums them in slice
+    order) is chosen by gemm_splitk_plan from the shape; here the slice count and the tile are forced (read once per process: a child)
+    on every single-utterance GEMM that can take them -- encoder convolutions, BiLSTM input projection, memory layer, post-net -- for
+    chunk lengths whose row counts are not multiples of the tile (1, 7, 37 ids) and the full window (100 ids): the frames must stay the
+    oracle's to 1e-5 (a slice boundary that dropped or doubled a K slab would show at 1e-2)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = (
+        "import importlib, sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import torch, oracle\n"
+        "from conftest import synth_ids, rms\n"
+        "pkg = importlib.import_module('xd-tts_amd')\n"
+        "orc = oracle.Oracle('f32')\n"
+        "blob = orc.weights_synthetic(seed=20240327, rec_scale=1.0)\n"
+        "m = pkg.Tacotron2.from_blob(blob)\n"
+        "worst = 0.0\n"
+        "for n, steps in ((1, 9), (7, 33), (37, 70), (100, 131)):\n"
+        "    ids = synth_ids(n, seed=900 + n)\n"
+        "    mel = m.infer_batch([ids], opts=pkg.default_opts(dropout_seed=5), fixed_steps=[steps])[0]\n"
+        "    ref = orc.infer_chunk(blob, ids, orc.default_opts(fixed_steps=steps, dropout_seed=5, item=0))\n"
+        "    assert mel.shape == ref.shape, (n, mel.shape, ref.shape)\n"
+        "    worst = max(worst, rms(mel, ref))\n"
+        "print('WORST %%.3e' %% worst)\n"
+    ) % (root, os.path.join(root, "tests"))
+    r = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    worst = float([ln for ln in r.stdout.splitlines() if ln.startswith("WORST")][-1].split()[1])
+    assert worst <= 1e-5, (env, worst)
